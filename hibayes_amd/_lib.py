@@ -1,0 +1,177 @@
+"""ctypes binding of libhibayes_gpu.so (include/hibayes_gpu.h).
+
+The library is the product: if it is missing or no HIP device is usable, every compute entry
+point raises — there is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhibayes_gpu.so")
+HB_MAX_FOLD = 8
+_lib = None
+
+
+class HibayesError(RuntimeError):
+    """Raised with the library's hb_last_error() text (the reference's exception texts for
+    argument validation, src/Bayes.cpp:92-117)."""
+
+    def __init__(self, status, msg):
+        super().__init__(msg)
+        self.status = status
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+INTERRUPT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+LOG_FN = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)
+
+
+class BayesArgs(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32),
+        ("y", C.c_void_p),
+        ("X_f64", C.c_void_p), ("ld_f64", C.c_int64),
+        ("X_i8", C.c_void_p), ("ld_i8", C.c_int64),
+        ("model", C.c_char_p),
+        ("Pi", C.c_void_p), ("n_pi", C.c_int32),
+        ("Kival", C.c_void_p), ("Ki", C.c_void_p),
+        ("C", C.c_void_p), ("nc", C.c_int32),
+        ("R", C.c_void_p), ("nr", C.c_int32),
+        ("fold", C.c_void_p), ("n_fold", C.c_int32),
+        ("niter", C.c_int32), ("nburn", C.c_int32), ("thin", C.c_int32),
+        ("epsl_y_J", C.c_void_p), ("epsl_Gi", C.c_void_p), ("epsl_index", C.c_void_p),
+        ("has_dfvr", C.c_int32), ("has_s2vr", C.c_int32), ("has_vg", C.c_int32), ("has_dfvg", C.c_int32),
+        ("has_s2vg", C.c_int32), ("has_ve", C.c_int32), ("has_dfve", C.c_int32), ("has_s2ve", C.c_int32),
+        ("dfvr", C.c_double), ("s2vr", C.c_double), ("vg", C.c_double), ("dfvg", C.c_double),
+        ("s2vg", C.c_double), ("ve", C.c_double), ("dfve", C.c_double), ("s2ve", C.c_double),
+        ("windindx", C.c_void_p),
+        ("outfreq", C.c_int32), ("threads", C.c_int32), ("verbose", C.c_int32),
+        ("seed", C.c_uint64),
+        ("device", C.c_int32), ("panel", C.c_int32), ("precise", C.c_int32), ("store_alpha", C.c_int32),
+        ("rank", C.c_int32), ("world", C.c_int32),
+        ("m_global", C.c_int64), ("m_offset", C.c_int64),
+        ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p),
+        ("exchange_buf", C.c_void_p),
+        ("interrupt", INTERRUPT_FN), ("interrupt_user", C.c_void_p),
+        ("log", LOG_FN), ("log_user", C.c_void_p),
+    ]
+
+
+class BayesOut(C.Structure):
+    _fields_ = [
+        ("Vg", C.c_double), ("Ve", C.c_double), ("h2", C.c_double), ("mu", C.c_double),
+        ("n_records", C.c_int32), ("nzct", C.c_int32), ("nw", C.c_int32), ("n_levels", C.c_int32),
+        ("beta", C.c_void_p), ("alpha", C.c_void_p), ("pi", C.c_void_p), ("Vr", C.c_void_p),
+        ("r_est", C.c_void_p), ("r_term_nlevels", C.c_void_p),
+        ("g", C.c_void_p), ("e", C.c_void_p), ("pip", C.c_void_p), ("gwas", C.c_void_p),
+        ("s_Vg", C.c_void_p), ("s_Ve", C.c_void_p), ("s_h2", C.c_void_p), ("s_mu", C.c_void_p),
+        ("s_beta", C.c_void_p), ("s_alpha", C.c_void_p), ("s_pi", C.c_void_p), ("s_Vr", C.c_void_p),
+        ("s_r", C.c_void_p),
+        ("alpha_sd", C.c_void_p),
+        ("setup_seconds", C.c_double), ("loop_seconds", C.c_double),
+        ("iters_done", C.c_int32),
+        ("mean_events", C.c_double),
+    ]
+
+
+class CtxParams(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("panel", C.c_int32),
+        ("precise", C.c_int32), ("m_offset", C.c_int64), ("seed", C.c_uint64),
+    ]
+
+
+class SweepIn(C.Structure):
+    _fields_ = [
+        ("model_index", C.c_int32), ("n_fold", C.c_int32), ("iter", C.c_int64),
+        ("vare", C.c_double), ("varg", C.c_double), ("s2varg_df", C.c_double), ("dfvara", C.c_double),
+        ("logpi", C.c_double * HB_MAX_FOLD), ("fold", C.c_double * HB_MAX_FOLD),
+        ("vara_fold", C.c_double * HB_MAX_FOLD),
+        ("lambda_", C.c_double), ("lambda2", C.c_double),
+        ("count_pip", C.c_int32), ("store", C.c_int32),
+    ]
+
+
+class SweepOut(C.Structure):
+    _fields_ = [
+        ("sum_g2", C.c_double), ("class_count", C.c_double * HB_MAX_FOLD), ("sum_vargL", C.c_double),
+        ("sum_r", C.c_double), ("sum_r2", C.c_double), ("var_u", C.c_double), ("n_events", C.c_double),
+    ]
+
+
+class SweepTiming(C.Structure):
+    _fields_ = [
+        ("total_ms", C.c_double), ("dot_ms", C.c_double), ("dot_launches", C.c_int32),
+        ("chain_ms", C.c_double), ("update_ms", C.c_double), ("other_ms", C.c_double),
+    ]
+
+
+# every symbol include/hibayes_gpu.h declares
+SYMBOLS = [
+    "hb_abi_version", "hb_version", "hb_last_error", "hb_device_count", "hb_exchange_count", "hb_bayes_run",
+    "hb_ctx_create", "hb_ctx_destroy", "hb_ctx_panel", "hb_ctx_ld", "hb_ctx_upload_genotype_i8",
+    "hb_ctx_upload_genotype_f64", "hb_ctx_upload_bed", "hb_ctx_generate_genotype", "hb_ctx_download_genotype",
+    "hb_ctx_marker_stats", "hb_ctx_build_gram", "hb_ctx_download_gram", "hb_ctx_set_residual",
+    "hb_ctx_get_residual", "hb_ctx_set_effects", "hb_ctx_get_effects", "hb_ctx_dot", "hb_ctx_residual_sums",
+    "hb_ctx_residual_shift", "hb_ctx_set_covariates", "hb_ctx_cov_dot", "hb_ctx_cov_axpy", "hb_ctx_set_levels",
+    "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_sweep", "hb_ctx_get_counters", "hb_ctx_set_windows",
+    "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling",
+]
+
+
+def lib():
+    """Load the shared library (once). Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). hibayes_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.hb_version.restype = C.c_char_p
+    L.hb_last_error.restype = C.c_char_p
+    L.hb_exchange_count.restype = C.c_size_t
+    L.hb_exchange_count.argtypes = [C.c_int32]
+    L.hb_bayes_run.argtypes = [C.POINTER(BayesArgs), C.POINTER(BayesOut)]
+    L.hb_ctx_create.argtypes = [C.POINTER(CtxParams), C.POINTER(C.c_void_p)]
+    L.hb_ctx_destroy.argtypes = [C.c_void_p]
+    L.hb_ctx_destroy.restype = None
+    L.hb_ctx_panel.argtypes = [C.c_void_p]
+    L.hb_ctx_ld.argtypes = [C.c_void_p]
+    L.hb_ctx_ld.restype = C.c_int64
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.hb_ctx_upload_genotype_i8.argtypes = [vp, vp, i64, i32, i32]
+    L.hb_ctx_upload_genotype_f64.argtypes = [vp, vp, i64, i32, i32]
+    L.hb_ctx_upload_bed.argtypes = [vp, vp, i64, i32, vp, i32, i32]
+    L.hb_ctx_generate_genotype.argtypes = [vp, C.c_uint64, i32]
+    L.hb_ctx_download_genotype.argtypes = [vp, vp, i64, i32, i32]
+    L.hb_ctx_marker_stats.argtypes = [vp, vp, vp, C.POINTER(dbl), C.POINTER(i32)]
+    L.hb_ctx_build_gram.argtypes = [vp, C.POINTER(dbl)]
+    L.hb_ctx_download_gram.argtypes = [vp, i32, vp]
+    L.hb_ctx_set_residual.argtypes = [vp, vp, vp]
+    L.hb_ctx_get_residual.argtypes = [vp, vp, vp]
+    L.hb_ctx_set_effects.argtypes = [vp, vp, vp, vp]
+    L.hb_ctx_get_effects.argtypes = [vp, vp, vp, vp]
+    L.hb_ctx_dot.argtypes = [vp, i32, i32, vp]
+    L.hb_ctx_residual_sums.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl)]
+    L.hb_ctx_residual_shift.argtypes = [vp, dbl]
+    L.hb_ctx_set_covariates.argtypes = [vp, vp, i32]
+    L.hb_ctx_cov_dot.argtypes = [vp, i32, C.POINTER(dbl)]
+    L.hb_ctx_cov_axpy.argtypes = [vp, i32, dbl]
+    L.hb_ctx_set_levels.argtypes = [vp, vp, i32, vp]
+    L.hb_ctx_level_sums.argtypes = [vp, i32, vp]
+    L.hb_ctx_level_axpy.argtypes = [vp, i32, vp]
+    L.hb_ctx_sweep.argtypes = [vp, C.POINTER(SweepIn), C.POINTER(SweepOut)]
+    L.hb_ctx_get_counters.argtypes = [vp, vp, vp, vp]
+    L.hb_ctx_set_windows.argtypes = [vp, vp, i32]
+    L.hb_ctx_get_windows.argtypes = [vp, vp]
+    L.hb_ctx_last_timing.argtypes = [vp, C.POINTER(SweepTiming)]
+    L.hb_ctx_set_profiling.argtypes = [vp, i32]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc:
+        raise HibayesError(rc, lib().hb_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,617 @@
+// hb_ctx.hip — device context of one genotype shard and the fine-grained C ABI on top of it.
+#include "hb_internal.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+// launch wrappers implemented in hb_kernels.hip
+int hbk_init_attrs();
+int hbk_stats(hb_ctx *c);
+int hbk_dot_all(hb_ctx *c);
+int hbk_dot_panels(hb_ctx *c, int reps);
+int hbk_reduce_ru(hb_ctx *c);
+int hbk_shift(hb_ctx *c, double a);
+int hbk_to_f32(hb_ctx *c);
+int hbk_cov_dot(hb_ctx *c, int i, double *dev_out);
+int hbk_cov_axpy(hb_ctx *c, int i, double a);
+int hbk_level_sums(hb_ctx *c, int term, double *dev_sums, int nlev);
+int hbk_level_axpy(hb_ctx *c, int term, const double *dev_delta);
+int hbk_windows(hb_ctx *c);
+int hbk_f64_to_i8(hb_ctx *c, const double *dsrc, int64_t lds, int ncols, int8_t *dst, int *dbad);
+int hbk_bed_decode(hb_ctx *c, const uint8_t *dbed, int64_t bpc, int nind, const int32_t *drows, int col0, int ncols);
+int hbk_generate(hb_ctx *c, uint64_t seed, int mono_every);
+
+static thread_local std::string g_err;
+
+void hb_set_error(const std::string &msg) { g_err = msg; }
+int hb_fail(int status, const std::string &msg)
+{
+    g_err = msg;
+    return status;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t count, bool zero = true)
+{
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T)));
+    if (zero) HB_HIP(hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+    return HB_OK;
+}
+
+extern "C" {
+
+int hb_abi_version(void) { return HB_ABI_VERSION; }
+const char *hb_version(void) { return "hibayes_amd 0.1 (gfx950)"; }
+const char *hb_last_error(void) { return g_err.c_str(); }
+
+int hb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+size_t hb_exchange_count(int32_t n) { return (size_t)2 * (size_t)n + 16; }
+
+static int auto_panel(int m)
+{
+    if (m >= 4096) return 512;
+    if (m >= 1024) return 256;
+    if (m >= 256) return 128;
+    return 64;
+}
+
+int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
+{
+    if (!p || !out) return hb_fail(HB_ERR_INVALID, "hb_ctx_create: null argument");
+    *out = nullptr;
+    if (p->n < 2 || p->m < 1) return hb_fail(HB_ERR_INVALID, "hb_ctx_create: n >= 2 and m >= 1 required");
+    const int ndev = hb_device_count();
+    if (ndev <= 0) return hb_fail(HB_ERR_NO_DEVICE, "no HIP device available: the hibayes GPU engine has no CPU fallback");
+    if (p->device < 0 || p->device >= ndev) return hb_fail(HB_ERR_INVALID, "hb_ctx_create: bad device ordinal");
+    int P = p->panel ? p->panel : auto_panel(p->m);
+    if (P != 64 && P != 128 && P != 256 && P != 512)
+        return hb_fail(HB_ERR_INVALID, "hb_ctx_create: panel must be 64, 128, 256 or 512");
+    HB_HIP(hipSetDevice(p->device));
+    hb_ctx *c = new hb_ctx();
+    c->device = p->device;
+    c->n = p->n;
+    c->m = p->m;
+    c->P = P;
+    c->npanels = (p->m + P - 1) / P;
+    c->m_pad = c->npanels * P;
+    c->ld = ((int64_t)p->n + 255) / 256 * 256;
+    c->precise = p->precise;
+    c->m_offset = p->m_offset;
+    c->seed = p->seed;
+    c->nchunks = (int)((c->ld + 4095) / 4096);
+    c->nsplit = c->nchunks;
+    int rc = HB_OK;
+#define TRY(x)                   \
+    do {                         \
+        rc = (x);                \
+        if (rc) {                \
+            hb_ctx_destroy(c);   \
+            return rc;           \
+        }                        \
+    } while (0)
+    {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return hb_fail(HB_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        }
+    }
+    TRY(hbk_init_attrs());
+    const size_t mp = (size_t)c->m_pad;
+    TRY(dev_alloc(&c->X, (size_t)c->ld * mp));
+    TRY(dev_alloc(&c->xpx, mp));
+    TRY(dev_alloc(&c->vx, mp));
+    TRY(dev_alloc(&c->g, mp));
+    TRY(dev_alloc(&c->vargL, mp));
+    TRY(dev_alloc(&c->alpha_sum, mp));
+    TRY(dev_alloc(&c->alpha_sq, mp));
+    TRY(dev_alloc(&c->tracker, mp));
+    TRY(dev_alloc(&c->nzrate, mp));
+    TRY(dev_alloc(&c->r, (size_t)c->ld));
+    TRY(dev_alloc(&c->u, (size_t)c->ld));
+    TRY(dev_alloc(&c->r32, (size_t)c->ld));
+    TRY(dev_alloc(&c->gram, mp * (size_t)P));
+    TRY(dev_alloc(&c->xinfo, 2));
+    TRY(dev_alloc(&c->thr, mp * (HB_MAX_FOLD - 1)));
+    TRY(dev_alloc(&c->invv, mp * (HB_MAX_FOLD - 1)));
+    TRY(dev_alloc(&c->sdz, mp * (HB_MAX_FOLD - 1)));
+    TRY(dev_alloc(&c->partial, mp * (size_t)c->nsplit));
+    TRY(dev_alloc(&c->dots, mp));
+    TRY(dev_alloc(&c->ev_count, (size_t)c->npanels));
+    TRY(dev_alloc(&c->ev_idx, mp));
+    TRY(dev_alloc(&c->ev_delta, mp));
+    TRY(dev_alloc(&c->acc, HB_ACC_N));
+    TRY(dev_alloc(&c->d_in, 1));
+    TRY(dev_alloc(&c->scratch, 8192));
+    {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&c->h_acc), sizeof(double) * HB_ACC_N);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_in), sizeof(hb_sweep_in));
+        if (e != hipSuccess) {
+            hb_ctx_destroy(c);
+            return hb_fail(HB_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        }
+    }
+#undef TRY
+    *out = c;
+    return HB_OK;
+}
+
+void hb_ctx_destroy(hb_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    void *ptrs[] = {c->X, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
+                    c->r32, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dots, c->ev_count, c->ev_idx,
+                    c->ev_delta, c->acc, c->d_in, c->scratch, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->h_acc) (void)hipHostFree(c->h_acc);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int hb_ctx_panel(const hb_ctx *c) { return c ? c->P : 0; }
+int64_t hb_ctx_ld(const hb_ctx *c) { return c ? c->ld : 0; }
+
+static int check_cols(hb_ctx *c, int col0, int ncols, const char *who)
+{
+    if (!c) return hb_fail(HB_ERR_INVALID, std::string(who) + ": null context");
+    if (col0 < 0 || ncols < 0 || (int64_t)col0 + ncols > c->m)
+        return hb_fail(HB_ERR_INVALID, std::string(who) + ": column range outside the shard");
+    HB_HIP(hipSetDevice(c->device));
+    return HB_OK;
+}
+
+static void invalidate(hb_ctx *c)
+{
+    c->gram_ready = false;
+    c->stats_ready = false;
+}
+
+int hb_ctx_upload_genotype_i8(hb_ctx *c, const int8_t *X, int64_t ld, int32_t col0, int32_t ncols)
+{
+    int rc = check_cols(c, col0, ncols, "hb_ctx_upload_genotype_i8");
+    if (rc) return rc;
+    if (!X || ld < c->n) return hb_fail(HB_ERR_INVALID, "hb_ctx_upload_genotype_i8: bad source");
+    HB_HIP(hipMemcpy2DAsync(c->X + (int64_t)col0 * c->ld, (size_t)c->ld, X, (size_t)ld, (size_t)c->n, (size_t)ncols,
+                            hipMemcpyHostToDevice, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    invalidate(c);
+    return HB_OK;
+}
+
+int hb_ctx_upload_genotype_f64(hb_ctx *c, const double *X, int64_t ld, int32_t col0, int32_t ncols)
+{
+    int rc = check_cols(c, col0, ncols, "hb_ctx_upload_genotype_f64");
+    if (rc) return rc;
+    if (!X || ld < c->n) return hb_fail(HB_ERR_INVALID, "hb_ctx_upload_genotype_f64: bad source");
+    const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(ncols, (int64_t)(64 << 20) / std::max(1, c->n)));
+    double *stage = nullptr;
+    int *dbad = nullptr;
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&stage), (size_t)chunk * c->n * sizeof(double)));
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&dbad), sizeof(int)));
+    HB_HIP(hipMemsetAsync(dbad, 0, sizeof(int), c->stream));
+    for (int c0 = 0; c0 < ncols && rc == HB_OK; c0 += chunk) {
+        const int nc = std::min(chunk, ncols - c0);
+        hipError_t e = hipMemcpy2DAsync(stage, (size_t)c->n * sizeof(double), X + (int64_t)(col0 + c0) * ld,
+                                        (size_t)ld * sizeof(double), (size_t)c->n * sizeof(double), (size_t)nc,
+                                        hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { rc = hb_fail(HB_ERR_HIP, hipGetErrorString(e)); break; }
+        rc = hbk_f64_to_i8(c, stage, c->n, nc, c->X + (int64_t)(col0 + c0) * c->ld, dbad);
+        if (rc == HB_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = hb_fail(HB_ERR_HIP, "sync failed");
+    }
+    int bad = 0;
+    if (rc == HB_OK && hipMemcpy(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = hb_fail(HB_ERR_HIP, "hipMemcpy failed");
+    (void)hipFree(stage);
+    (void)hipFree(dbad);
+    invalidate(c);
+    if (rc) return rc;
+    if (bad)
+        return hb_fail(HB_ERR_UNSUPPORTED,
+                       "genotype matrix holds non-integer or out-of-range values: the int8 GPU path needs integer "
+                       "codes in [-127, 127] (imputed fractional genotypes are not supported)");
+    return HB_OK;
+}
+
+int hb_ctx_upload_bed(hb_ctx *c, const uint8_t *bed, int64_t nbytes, int32_t nind, const int32_t *rows, int32_t col0,
+                      int32_t ncols)
+{
+    int rc = check_cols(c, col0, ncols, "hb_ctx_upload_bed");
+    if (rc) return rc;
+    const int64_t bpc = ((int64_t)nind + 3) / 4;
+    if (!bed || nbytes < 3 + bpc * ((int64_t)col0 + ncols)) return hb_fail(HB_ERR_INVALID, "hb_ctx_upload_bed: file image too short");
+    if (bed[0] != 0x6c || bed[1] != 0x1b || bed[2] != 0x01)
+        return hb_fail(HB_ERR_INVALID, "hb_ctx_upload_bed: not a SNP-major PLINK .bed (magic 6c 1b 01)");
+    if (!rows && nind < c->n) return hb_fail(HB_ERR_INVALID, "hb_ctx_upload_bed: fewer individuals than n");
+    if (rows)
+        for (int i = 0; i < c->n; i++)
+            if (rows[i] < 0 || rows[i] >= nind) return hb_fail(HB_ERR_INVALID, "hb_ctx_upload_bed: row index out of range");
+    uint8_t *dbed = nullptr;
+    int32_t *drows = nullptr;
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&dbed), (size_t)(bpc * ncols)));
+    HB_HIP(hipMemcpy(dbed, bed + 3 + bpc * col0, (size_t)(bpc * ncols), hipMemcpyHostToDevice));
+    if (rows) {
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&drows), sizeof(int32_t) * c->n));
+        HB_HIP(hipMemcpy(drows, rows, sizeof(int32_t) * c->n, hipMemcpyHostToDevice));
+    }
+    rc = hbk_bed_decode(c, dbed, bpc, nind, drows, col0, ncols);
+    if (rc == HB_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = hb_fail(HB_ERR_HIP, "sync failed");
+    (void)hipFree(dbed);
+    if (drows) (void)hipFree(drows);
+    invalidate(c);
+    return rc;
+}
+
+int hb_ctx_generate_genotype(hb_ctx *c, uint64_t seed, int32_t mono_every)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_generate_genotype");
+    if (rc) return rc;
+    rc = hbk_generate(c, seed, mono_every);
+    if (rc) return rc;
+    HB_HIP(hipStreamSynchronize(c->stream));
+    invalidate(c);
+    return HB_OK;
+}
+
+int hb_ctx_download_genotype(hb_ctx *c, int8_t *X, int64_t ld, int32_t col0, int32_t ncols)
+{
+    int rc = check_cols(c, col0, ncols, "hb_ctx_download_genotype");
+    if (rc) return rc;
+    HB_HIP(hipMemcpy2D(X, (size_t)ld, c->X + (int64_t)col0 * c->ld, (size_t)c->ld, (size_t)c->n, (size_t)ncols,
+                       hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
+// Armadillo's arrayops::accumulate order (two interleaved accumulators) so that sumvx agrees
+// with sum(vx) of reference src/Bayes.cpp:316 to the last bit when vx does
+static double arma_sum(const double *v, size_t n)
+{
+    double a1 = 0.0, a2 = 0.0;
+    size_t j;
+    for (j = 1; j < n; j += 2) {
+        a1 += v[j - 1];
+        a2 += v[j];
+    }
+    if ((j - 1) < n) a1 += v[j - 1];
+    return a1 + a2;
+}
+
+int hb_ctx_marker_stats(hb_ctx *c, double *xpx, double *vx, double *sumvx, int32_t *nvar0)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_marker_stats");
+    if (rc) return rc;
+    rc = hbk_stats(c);
+    if (rc) return rc;
+    std::vector<double> hv(c->m);
+    HB_HIP(hipMemcpy(hv.data(), c->vx, sizeof(double) * c->m, hipMemcpyDeviceToHost));
+    if (vx) std::memcpy(vx, hv.data(), sizeof(double) * c->m);
+    if (xpx) HB_HIP(hipMemcpy(xpx, c->xpx, sizeof(double) * c->m, hipMemcpyDeviceToHost));
+    if (sumvx) *sumvx = arma_sum(hv.data(), hv.size());
+    if (nvar0) {
+        int z = 0;
+        for (double v : hv) z += (v == 0.0);
+        *nvar0 = z;
+    }
+    return HB_OK;
+}
+
+int hb_ctx_build_gram(hb_ctx *c, double *seconds)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_build_gram");
+    if (rc) return rc;
+    if (!c->stats_ready) {
+        rc = hbk_stats(c);
+        if (rc) return rc;
+    }
+    const double amax = std::max(std::abs((double)c->xmin), std::abs((double)c->xmax));
+    if (amax * amax * (double)c->n >= 2147483647.0)
+        return hb_fail(HB_ERR_UNSUPPORTED, "genotype codes too large for the exact int32 Gram matrix at this n");
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = hb_build_gram_impl(c);
+    if (rc) return rc;
+    HB_HIP(hipStreamSynchronize(c->stream));
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    c->gram_ready = true;
+    return HB_OK;
+}
+
+int hb_ctx_download_gram(hb_ctx *c, int32_t panel_index, int32_t *G)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_download_gram");
+    if (rc) return rc;
+    if (!c->gram_ready) return hb_fail(HB_ERR_INVALID, "hb_ctx_download_gram: call hb_ctx_build_gram first");
+    if (panel_index < 0 || panel_index >= c->npanels) return hb_fail(HB_ERR_INVALID, "hb_ctx_download_gram: bad panel");
+    HB_HIP(hipMemcpy(G, c->gram + (size_t)panel_index * c->P * c->P, sizeof(int32_t) * c->P * c->P, hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
+int hb_ctx_set_residual(hb_ctx *c, const double *yadj, const double *u)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_set_residual");
+    if (rc) return rc;
+    if (yadj) {
+        HB_HIP(hipMemcpyAsync(c->r, yadj, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+        rc = hbk_to_f32(c);
+        if (rc) return rc;
+    }
+    if (u) HB_HIP(hipMemcpyAsync(c->u, u, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    return HB_OK;
+}
+
+int hb_ctx_get_residual(hb_ctx *c, double *yadj, double *u)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_get_residual");
+    if (rc) return rc;
+    HB_HIP(hipStreamSynchronize(c->stream));
+    if (yadj) HB_HIP(hipMemcpy(yadj, c->r, sizeof(double) * c->n, hipMemcpyDeviceToHost));
+    if (u) HB_HIP(hipMemcpy(u, c->u, sizeof(double) * c->n, hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
+int hb_ctx_set_effects(hb_ctx *c, const double *g, const uint8_t *tracker, const double *vargL)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_set_effects");
+    if (rc) return rc;
+    if (g) HB_HIP(hipMemcpy(c->g, g, sizeof(double) * c->m, hipMemcpyHostToDevice));
+    if (tracker) HB_HIP(hipMemcpy(c->tracker, tracker, c->m, hipMemcpyHostToDevice));
+    if (vargL) HB_HIP(hipMemcpy(c->vargL, vargL, sizeof(double) * c->m, hipMemcpyHostToDevice));
+    return HB_OK;
+}
+
+int hb_ctx_get_effects(hb_ctx *c, double *g, uint8_t *tracker, double *vargL)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_get_effects");
+    if (rc) return rc;
+    HB_HIP(hipStreamSynchronize(c->stream));
+    if (g) HB_HIP(hipMemcpy(g, c->g, sizeof(double) * c->m, hipMemcpyDeviceToHost));
+    if (tracker) HB_HIP(hipMemcpy(tracker, c->tracker, c->m, hipMemcpyDeviceToHost));
+    if (vargL) HB_HIP(hipMemcpy(vargL, c->vargL, sizeof(double) * c->m, hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
+int hb_ctx_dot(hb_ctx *c, int32_t col0, int32_t ncols, double *d)
+{
+    int rc = check_cols(c, col0, ncols, "hb_ctx_dot");
+    if (rc) return rc;
+    if (!c->stats_ready) {
+        rc = hbk_stats(c);
+        if (rc) return rc;
+    }
+    rc = hbk_dot_all(c);
+    if (rc) return rc;
+    HB_HIP(hipStreamSynchronize(c->stream));
+    HB_HIP(hipMemcpy(d, c->dots + col0, sizeof(double) * ncols, hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
+static int fetch_acc(hb_ctx *c)
+{
+    HB_HIP(hipMemcpyAsync(c->h_acc, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    return HB_OK;
+}
+
+int hb_ctx_residual_sums(hb_ctx *c, double *sum_r, double *sum_r2)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_residual_sums");
+    if (rc) return rc;
+    rc = hbk_reduce_ru(c);
+    if (rc) return rc;
+    rc = fetch_acc(c);
+    if (rc) return rc;
+    if (sum_r) *sum_r = c->h_acc[HB_ACC_SUMR];
+    if (sum_r2) *sum_r2 = c->h_acc[HB_ACC_SUMR2];
+    return HB_OK;
+}
+
+int hb_ctx_residual_shift(hb_ctx *c, double a)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_residual_shift");
+    if (rc) return rc;
+    return hbk_shift(c, a);
+}
+
+int hb_ctx_set_covariates(hb_ctx *c, const double *Cmat, int32_t nc)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_set_covariates");
+    if (rc) return rc;
+    if (c->Cmat) { (void)hipFree(c->Cmat); c->Cmat = nullptr; }
+    c->nc = 0;
+    if (!Cmat || nc <= 0) return HB_OK;
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->Cmat), sizeof(double) * (size_t)c->n * nc));
+    HB_HIP(hipMemcpy(c->Cmat, Cmat, sizeof(double) * (size_t)c->n * nc, hipMemcpyHostToDevice));
+    c->nc = nc;
+    return HB_OK;
+}
+
+int hb_ctx_cov_dot(hb_ctx *c, int32_t i, double *out)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_cov_dot");
+    if (rc) return rc;
+    if (i < 0 || i >= c->nc) return hb_fail(HB_ERR_INVALID, "hb_ctx_cov_dot: bad covariate index");
+    rc = hbk_cov_dot(c, i, c->scratch);
+    if (rc) return rc;
+    HB_HIP(hipMemcpyAsync(out, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    return HB_OK;
+}
+
+int hb_ctx_cov_axpy(hb_ctx *c, int32_t i, double a)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_cov_axpy");
+    if (rc) return rc;
+    if (i < 0 || i >= c->nc) return hb_fail(HB_ERR_INVALID, "hb_ctx_cov_axpy: bad covariate index");
+    return hbk_cov_axpy(c, i, a);
+}
+
+int hb_ctx_set_levels(hb_ctx *c, const int32_t *zid, int32_t nr, const int32_t *nlev)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_set_levels");
+    if (rc) return rc;
+    if (c->zid) { (void)hipFree(c->zid); c->zid = nullptr; }
+    if (c->lev_buf) { (void)hipFree(c->lev_buf); c->lev_buf = nullptr; }
+    c->nr = 0;
+    c->nlev.clear();
+    c->lev_first.clear();
+    if (!zid || nr <= 0) return HB_OK;
+    int tot = 0, mx = 0;
+    for (int t = 0; t < nr; t++) {
+        if (nlev[t] < 1) return hb_fail(HB_ERR_INVALID, "hb_ctx_set_levels: bad level count");
+        c->lev_first.push_back(tot);
+        c->nlev.push_back(nlev[t]);
+        tot += nlev[t];
+        mx = std::max(mx, nlev[t]);
+    }
+    for (int t = 0; t < nr; t++)
+        for (int i = 0; i < c->n; i++)
+            if (zid[(size_t)t * c->n + i] < 0 || zid[(size_t)t * c->n + i] >= nlev[t])
+                return hb_fail(HB_ERR_INVALID, "hb_ctx_set_levels: level index out of range");
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->zid), sizeof(int32_t) * (size_t)c->n * nr));
+    HB_HIP(hipMemcpy(c->zid, zid, sizeof(int32_t) * (size_t)c->n * nr, hipMemcpyHostToDevice));
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->lev_buf), sizeof(double) * (size_t)mx));
+    c->nr = nr;
+    c->lev_total = tot;
+    return HB_OK;
+}
+
+int hb_ctx_level_sums(hb_ctx *c, int32_t term, double *sums)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_level_sums");
+    if (rc) return rc;
+    if (term < 0 || term >= c->nr) return hb_fail(HB_ERR_INVALID, "hb_ctx_level_sums: bad term");
+    rc = hbk_level_sums(c, term, c->lev_buf, c->nlev[term]);
+    if (rc) return rc;
+    HB_HIP(hipMemcpyAsync(sums, c->lev_buf, sizeof(double) * c->nlev[term], hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    return HB_OK;
+}
+
+int hb_ctx_level_axpy(hb_ctx *c, int32_t term, const double *delta)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_level_axpy");
+    if (rc) return rc;
+    if (term < 0 || term >= c->nr) return hb_fail(HB_ERR_INVALID, "hb_ctx_level_axpy: bad term");
+    HB_HIP(hipMemcpyAsync(c->lev_buf, delta, sizeof(double) * c->nlev[term], hipMemcpyHostToDevice, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream)); // delta may be a pageable host temporary
+    return hbk_level_axpy(c, term, c->lev_buf);
+}
+
+int hb_ctx_sweep(hb_ctx *c, const hb_sweep_in *in, hb_sweep_out *out)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_sweep");
+    if (rc) return rc;
+    if (!in || !out) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep: null argument");
+    if (in->model_index < 1 || in->model_index > 6) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep: bad model_index");
+    if (in->n_fold < 2 || in->n_fold > HB_MAX_FOLD) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep: bad n_fold");
+    if (in->model_index == 6)
+        for (int k = 2; k < in->n_fold; k++)
+            if (!(in->fold[k] > in->fold[k - 1]))
+                return hb_fail(HB_ERR_UNSUPPORTED, "BayesR on the GPU path needs 'fold' in strictly increasing order");
+    if (!c->stats_ready) {
+        rc = hbk_stats(c);
+        if (rc) return rc;
+    }
+    if (!c->gram_ready) {
+        rc = hb_ctx_build_gram(c, nullptr);
+        if (rc) return rc;
+    }
+    rc = hb_sweep_enqueue(c, in, c->profiling);
+    if (rc) return rc;
+    if (in->count_pip && c->nw) {
+        rc = hbk_windows(c);
+        if (rc) return rc;
+    }
+    rc = fetch_acc(c);
+    if (rc) return rc;
+    const double *a = c->h_acc;
+    out->sum_g2 = a[HB_ACC_SUMG2];
+    for (int k = 0; k < HB_MAX_FOLD; k++) out->class_count[k] = a[HB_ACC_COUNT0 + k];
+    out->sum_vargL = a[HB_ACC_SUMVARGL];
+    out->sum_r = a[HB_ACC_SUMR];
+    out->sum_r2 = a[HB_ACC_SUMR2];
+    out->var_u = a[HB_ACC_VARU];
+    out->n_events = a[HB_ACC_EVENTS];
+    return HB_OK;
+}
+
+int hb_ctx_get_counters(hb_ctx *c, double *nzrate, double *alpha_sum, double *alpha_sq)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_get_counters");
+    if (rc) return rc;
+    HB_HIP(hipStreamSynchronize(c->stream));
+    if (nzrate) {
+        std::vector<uint32_t> t(c->m);
+        HB_HIP(hipMemcpy(t.data(), c->nzrate, sizeof(uint32_t) * c->m, hipMemcpyDeviceToHost));
+        for (int i = 0; i < c->m; i++) nzrate[i] = (double)t[i];
+    }
+    if (alpha_sum) HB_HIP(hipMemcpy(alpha_sum, c->alpha_sum, sizeof(double) * c->m, hipMemcpyDeviceToHost));
+    if (alpha_sq) HB_HIP(hipMemcpy(alpha_sq, c->alpha_sq, sizeof(double) * c->m, hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
+int hb_ctx_set_windows(hb_ctx *c, const uint32_t *windindx, int32_t nw)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_set_windows");
+    if (rc) return rc;
+    if (c->wind) { (void)hipFree(c->wind); c->wind = nullptr; }
+    if (c->wflag) { (void)hipFree(c->wflag); c->wflag = nullptr; }
+    if (c->wppa) { (void)hipFree(c->wppa); c->wppa = nullptr; }
+    c->nw = 0;
+    c->graph_model = -1; // the captured graph holds the old pointers
+    if (!windindx || nw <= 0) return HB_OK;
+    for (int i = 0; i < c->m; i++)
+        if (windindx[i] < 1 || (int)windindx[i] > nw) return hb_fail(HB_ERR_INVALID, "hb_ctx_set_windows: window id out of range");
+    std::vector<uint32_t> w(c->m_pad, 1u);
+    std::memcpy(w.data(), windindx, sizeof(uint32_t) * c->m);
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->wind), sizeof(uint32_t) * c->m_pad));
+    HB_HIP(hipMemcpy(c->wind, w.data(), sizeof(uint32_t) * c->m_pad, hipMemcpyHostToDevice));
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->wflag), (size_t)nw));
+    HB_HIP(hipMemset(c->wflag, 0, (size_t)nw));
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->wppa), sizeof(double) * nw));
+    HB_HIP(hipMemset(c->wppa, 0, sizeof(double) * nw));
+    c->nw = nw;
+    return HB_OK;
+}
+
+int hb_ctx_get_windows(hb_ctx *c, double *wppa)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_get_windows");
+    if (rc) return rc;
+    if (!c->nw) return hb_fail(HB_ERR_INVALID, "hb_ctx_get_windows: no windows set");
+    HB_HIP(hipStreamSynchronize(c->stream));
+    HB_HIP(hipMemcpy(wppa, c->wppa, sizeof(double) * c->nw, hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
+int hb_ctx_last_timing(hb_ctx *c, hb_sweep_timing *t)
+{
+    if (!c || !t) return hb_fail(HB_ERR_INVALID, "hb_ctx_last_timing: null argument");
+    *t = c->timing;
+    return HB_OK;
+}
+
+int hb_ctx_set_profiling(hb_ctx *c, int32_t on)
+{
+    if (!c) return hb_fail(HB_ERR_INVALID, "hb_ctx_set_profiling: null context");
+    c->profiling = on != 0;
+    return HB_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,90 @@
+// hb_internal.hpp — private declarations shared by the engine translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/hibayes_gpu.h"
+
+// thread-local last error (hb_last_error)
+void hb_set_error(const std::string &msg);
+int hb_fail(int status, const std::string &msg);
+
+#define HB_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return hb_fail(HB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+    } while (0)
+
+// layout of the per-sweep scalar block the kernels accumulate into / the host reads back
+enum {
+    HB_ACC_SUMG2 = 0,
+    HB_ACC_COUNT0 = 1, // .. +HB_MAX_FOLD
+    HB_ACC_EVENTS = 9,
+    HB_ACC_SUMVARGL = 10,
+    HB_ACC_SUMR = 11,
+    HB_ACC_SUMR2 = 12,
+    HB_ACC_VARU = 13,
+    HB_ACC_N = 16
+};
+
+struct hb_ctx {
+    int device = 0;
+    int n = 0, m = 0, P = 0, npanels = 0, m_pad = 0;
+    int64_t ld = 0; // bytes per genotype column on device (multiple of 256)
+    int precise = 0;
+    int64_t m_offset = 0;
+    uint64_t seed = 0;
+    hipStream_t stream = nullptr;
+
+    int8_t *X = nullptr;
+    double *xpx = nullptr, *vx = nullptr, *g = nullptr, *vargL = nullptr;
+    double *alpha_sum = nullptr, *alpha_sq = nullptr;
+    uint8_t *tracker = nullptr;
+    uint32_t *nzrate = nullptr;
+    double *r = nullptr, *u = nullptr;
+    float *r32 = nullptr;
+    int32_t *gram = nullptr;
+    bool gram_ready = false, stats_ready = false;
+    int *xinfo = nullptr; // device: [0]=min value, [1]=max value over X
+    int xmin = 0, xmax = 0;
+
+    double *thr = nullptr, *invv = nullptr, *sdz = nullptr; // (HB_MAX_FOLD-1) x m_pad each
+    double *partial = nullptr;                              // nsplit x m_pad
+    double *dots = nullptr;                                 // m_pad (hb_ctx_dot)
+    int nchunks = 0, nsplit = 0;
+    int32_t *ev_count = nullptr, *ev_idx = nullptr;
+    double *ev_delta = nullptr;
+    double *acc = nullptr;        // HB_ACC_N device scalars
+    double *h_acc = nullptr;      // pinned mirror
+    hb_sweep_in *d_in = nullptr;  // device copy of the sweep parameters
+    hb_sweep_in *h_in = nullptr;  // pinned staging
+
+    double *Cmat = nullptr;
+    int nc = 0;
+    int32_t *zid = nullptr;
+    int nr = 0;
+    std::vector<int> nlev, lev_first;
+    double *lev_buf = nullptr;
+    int lev_total = 0;
+    double *scratch = nullptr; // small device scratch (>= 4096 doubles)
+
+    uint32_t *wind = nullptr;
+    uint8_t *wflag = nullptr;
+    double *wppa = nullptr;
+    int nw = 0;
+
+    // captured sweep graph, keyed by (model_index, n_fold)
+    hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph = nullptr;
+    int graph_model = -1, graph_fold = -1;
+    bool use_graph = true;
+
+    bool profiling = false;
+    hb_sweep_timing timing{};
+    std::vector<hipEvent_t> ev_pool;
+};
+
+int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed);
+int hb_build_gram_impl(hb_ctx *c);

@@ -1,0 +1,1068 @@
+// hb_kernels.hip — gfx950 kernels of the block-Gibbs marker sweep.
+//
+// One sweep (reference src/Bayes.cpp:586-816) is executed panel by panel; a panel is P
+// consecutive markers.  For each panel:
+//   k_dot      d = X_p' yadj                  bandwidth-bound int8 mat-vec (the dominant kernel)
+//   k_chain    the serial conditional updates of the panel's markers, made exact by the panel
+//              Gram matrix G = X_p' X_p:  after marker k moves by D_k, rhs_j -= G[k][j] D_k
+//              for every later marker j of the panel  (== what the reference gets by updating
+//              yadj with daxpy before the next ddot)
+//   k_update   yadj -= X_p[:, changed] D,  u += X_p[:, changed] D
+// Per-marker quantities that do not depend on the running rhs (the uniform and normal deviates,
+// 1/v, sd*z, and the inclusion test rewritten as thresholds on rhs^2) are produced once per
+// sweep by k_pre, so the serial part is a handful of fp64 operations per marker.
+#include "hb_internal.hpp"
+#include "hb_rng.hpp"
+#include <type_traits>
+#include <algorithm>
+
+#define HB_INF __builtin_huge_val()
+
+// ---------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum, result valid in every thread; red must hold blockDim.x/64 entries
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T *red)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    T s = 0;
+    for (int i = 0; i < nw; i++) s += red[i];
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// marker statistics, reference src/Bayes.cpp:310-317 — integer-exact
+// one workgroup per column
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stats(const int8_t *__restrict__ X, int64_t ld, int n, int m,
+                                               double *__restrict__ xpx, double *__restrict__ vx,
+                                               int *__restrict__ xinfo)
+{
+    __shared__ long long red[4];
+    const int j = blockIdx.x;
+    const int8_t *col = X + (int64_t)j * ld;
+    long long s1 = 0, s2 = 0;
+    int mn = 127, mx = -128;
+    for (int64_t r0 = (int64_t)threadIdx.x * 16; r0 < ld; r0 += 256 * 16) {
+        const int4 v = *reinterpret_cast<const int4 *>(col + r0);
+        const int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int x = (int)(int8_t)(w[q] >> (8 * b));
+                if (r0 + q * 4 + b < n) {
+                    s1 += x;
+                    s2 += x * x;
+                    mn = min(mn, x);
+                    mx = max(mx, x);
+                }
+            }
+        }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (j < m) {
+        atomicMin(&xinfo[0], mn);
+        atomicMax(&xinfo[1], mx);
+    }
+    if (threadIdx.x == 0) {
+        if (j < m) {
+            xpx[j] = (double)s2;
+            const long long num = (long long)n * s2 - s1 * s1; // n*S2 - S1^2, exact
+            vx[j] = (num == 0 || n < 2) ? 0.0 : (double)num / ((double)n * (double)(n - 1));
+        } else {
+            xpx[j] = 0.0;
+            vx[j] = 0.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dot: partial[split][col] = sum over the split's rows of x[row][col] * yadj[row]
+// tile = 8 columns x (256 threads x 16 rows); grid = (ncols/8, nsplit)
+// ---------------------------------------------------------------------------------------------
+template <bool SIGNED>
+__device__ __forceinline__ float b2f(unsigned w, int b)
+{
+    if (SIGNED) return (float)(int)(int8_t)(w >> (8 * b));
+    return (float)((w >> (8 * b)) & 0xffu);
+}
+
+template <bool PRECISE, bool SIGNED>
+__global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64_t ld,
+                                             const float *__restrict__ r32,
+                                             const double *__restrict__ r64, int nchunks,
+                                             int chunks_per_split, double *__restrict__ partial,
+                                             int pstride)
+{
+    using acc_t = typename std::conditional<PRECISE, double, float>::type;
+    __shared__ acc_t red[4][8];
+    const int ct = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
+    const int8_t *xc = X + (int64_t)ct * 8 * ld;
+    acc_t acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[c] = 0;
+    const int ch1 = min(nchunks, (sp + 1) * chunks_per_split);
+    for (int ch = sp * chunks_per_split; ch < ch1; ++ch) {
+        const int64_t row0 = ((int64_t)ch * 256 + tid) * 16;
+        if (row0 < ld) {
+            uint4 xv[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) xv[c] = *reinterpret_cast<const uint4 *>(xc + (int64_t)c * ld + row0);
+            acc_t rv[16];
+            if (PRECISE) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const double2 t = *reinterpret_cast<const double2 *>(r64 + row0 + 2 * q);
+                    rv[2 * q] = (acc_t)t.x;
+                    rv[2 * q + 1] = (acc_t)t.y;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4 t = *reinterpret_cast<const float4 *>(r32 + row0 + 4 * q);
+                    rv[4 * q] = (acc_t)t.x;
+                    rv[4 * q + 1] = (acc_t)t.y;
+                    rv[4 * q + 2] = (acc_t)t.z;
+                    rv[4 * q + 3] = (acc_t)t.w;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const unsigned w[4] = {xv[c].x, xv[c].y, xv[c].z, xv[c].w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        acc[c] = fma((acc_t)b2f<SIGNED>(w[q], b), rv[q * 4 + b], acc[c]);
+                }
+            }
+        }
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const acc_t s = wave_sum(acc[c]);
+        if (lane == 0) red[wv][c] = s;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        const acc_t s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        partial[(int64_t)sp * pstride + ct * 8 + tid] = (double)s;
+    }
+}
+
+__global__ void k_sum_partials(const double *__restrict__ partial, int pstride, int nsplit, int ncols,
+                               double *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    double s = 0;
+    for (int sp = 0; sp < nsplit; sp++) s += partial[(int64_t)sp * pstride + j];
+    out[j] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pre: everything per marker that does not depend on the running rhs.
+// Conditional posteriors restated as thresholds on q = rhs^2:
+//   B/C (src/Bayes.cpp:640-645 / :683-688): included  <=>  U >= 1/(1+exp(s1-s0))
+//        <=>  s1-s0 >= log((1-U)/U)  <=>  q >= 2 v vare (log((1-U)/U) + ldV/2 - logpi1 + logpi0)
+//   R   (:759-781): class > c  <=>  U >= P(class <= c | q); with fold ascending that cumulative
+//        probability decreases in q, so the K-1 boundaries are thresholds thr_0 <= thr_1 <= ...
+//        found here by safeguarded Newton on  log B(q) - log A(q) = log((1-U)/U).
+// ---------------------------------------------------------------------------------------------
+struct pre_view {
+    int m, m_pad;
+    int64_t m_offset;
+    uint64_t seed;
+    const double *xpx, *vx, *g, *vargL;
+    double *thr, *invv, *sdz;
+    int kpad; // thresholds written per marker (1, 3 or 7)
+};
+
+__device__ double bayesr_threshold(int K, int c, const double *a, const double *b, double logT)
+{
+    // h(q) = logsumexp_{i>c}(a_i + b_i q) - logsumexp_{i<=c}(a_i + b_i q) - logT, increasing in q
+    auto h = [&](double q, double &dh) {
+        double mA = -HB_INF, mB = -HB_INF;
+        for (int i = 0; i < K; i++) {
+            const double s = a[i] + b[i] * q;
+            if (i <= c) mA = fmax(mA, s); else mB = fmax(mB, s);
+        }
+        double sA = 0, sB = 0, dA = 0, dB = 0;
+        for (int i = 0; i < K; i++) {
+            const double s = a[i] + b[i] * q;
+            if (i <= c) { const double w = exp(s - mA); sA += w; dA += b[i] * w; }
+            else        { const double w = exp(s - mB); sB += w; dB += b[i] * w; }
+        }
+        dh = dB / sB - dA / sA;
+        return (mB + log(sB)) - (mA + log(sA)) - logT;
+    };
+    double dh;
+    double h0 = h(0.0, dh);
+    if (!(h0 < 0.0)) return 0.0;         // already above the boundary at q = 0
+    if (!(dh > 0.0)) return HB_INF;      // flat: the boundary is never crossed
+    // bracket
+    double lo = 0.0, hi = -h0 / dh;
+    if (!(hi > 0.0)) hi = 1.0;
+    double hh = h(hi, dh);
+    int guard = 0;
+    while (hh < 0.0 && guard++ < 200) {
+        lo = hi;
+        hi *= 2.0;
+        hh = h(hi, dh);
+    }
+    if (hh < 0.0) return HB_INF;
+    double q = hi;
+    for (int it = 0; it < 100; it++) {
+        double d;
+        const double hv = h(q, d);
+        if (hv < 0.0) lo = q; else hi = q;
+        double qn = q - hv / d;
+        if (!(qn > lo && qn < hi)) qn = 0.5 * (lo + hi);
+        if (fabs(qn - q) <= 4e-16 * fabs(qn) || hi - lo <= 4e-16 * hi) { q = qn; break; }
+        q = qn;
+    }
+    return q;
+}
+
+__global__ __launch_bounds__(256) void k_pre(const hb_sweep_in *__restrict__ pin, pre_view v)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= v.m_pad) return;
+    const int kp = v.kpad;
+    const bool active = (j < v.m) && (v.vx[j] != 0.0);
+    if (!active) {
+        for (int c = 0; c < kp; c++) {
+            v.thr[(int64_t)c * v.m_pad + j] = HB_INF;
+            v.invv[(int64_t)c * v.m_pad + j] = 0.0;
+            v.sdz[(int64_t)c * v.m_pad + j] = 0.0;
+        }
+        return;
+    }
+    const int model = pin->model_index;
+    const double vare = pin->vare;
+    const uint64_t sub = hb_sub(HB_PURPOSE_MARKER, (uint64_t)pin->iter);
+    const uint64_t base = (uint64_t)(v.m_offset + j) * HB_BLK_PER_MARKER;
+    const double xx = v.xpx[j];
+    const double gold = v.g[j];
+    const double z = hb_normal_blk(v.seed, sub, base + 1);
+
+    if (model == 6) {
+        const int K = pin->n_fold;
+        const double U = hb_uniform_blk(v.seed, sub, base + 0);
+        const double logT = log((1.0 - U) / U);
+        double a[HB_MAX_FOLD], b[HB_MAX_FOLD];
+        a[0] = pin->logpi[0];
+        b[0] = 0.0;
+        const double lhs = xx / vare;
+        for (int c = 1; c < K; c++) {
+            const double vf = pin->vara_fold[c];
+            const double vv = xx + vare / vf; // :761, :784
+            a[c] = -0.5 * log(vf * lhs + 1.0) + pin->logpi[c];
+            b[c] = 0.5 / (vv * vare);
+            v.invv[(int64_t)(c - 1) * v.m_pad + j] = 1.0 / vv;
+            v.sdz[(int64_t)(c - 1) * v.m_pad + j] = sqrt(vare / vv) * z;
+        }
+        double prev = 0.0;
+        for (int c = 0; c < K - 1; c++) { // boundaries are nested: thr_0 <= thr_1 <= ...
+            prev = fmax(prev, bayesr_threshold(K, c, a, b, logT));
+            v.thr[(int64_t)c * v.m_pad + j] = prev;
+        }
+        for (int c = K - 1; c < kp; c++) {
+            v.thr[(int64_t)c * v.m_pad + j] = HB_INF;
+            v.invv[(int64_t)c * v.m_pad + j] = 0.0;
+            v.sdz[(int64_t)c * v.m_pad + j] = 0.0;
+        }
+        return;
+    }
+
+    double varg = pin->varg;
+    if (model == 2 || model == 3) { // per-marker variance, :613 / :636 — drawn from g of the previous sweep
+        hb_stream st(v.seed, sub, base + 4);
+        varg = (gold * gold + pin->s2varg_df) / st.chisq(pin->dfvara + 1.0);
+    }
+    double vv;
+    if (model == 5) vv = xx + 1.0 / v.vargL[j]; // :726
+    else vv = xx + vare / varg;                 // :595, :617, :648, :691
+    double thr = -HB_INF;
+    if (model == 3 || model == 4) {
+        const double U = hb_uniform_blk(v.seed, sub, base + 0);
+        const double logdetV = log(varg * (xx / vare) + 1.0);
+        thr = 2.0 * vv * vare * (log((1.0 - U) / U) + 0.5 * logdetV - pin->logpi[1] + pin->logpi[0]);
+        if (thr != thr) thr = HB_INF; // inf - inf when both log(pi) are -inf: never include
+    }
+    v.thr[j] = thr;
+    v.invv[j] = 1.0 / vv;
+    v.sdz[j] = sqrt(vare / vv) * z;
+    for (int c = 1; c < kp; c++) {
+        v.thr[(int64_t)c * v.m_pad + j] = HB_INF;
+        v.invv[(int64_t)c * v.m_pad + j] = 0.0;
+        v.sdz[(int64_t)c * v.m_pad + j] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_chain: one workgroup of P threads (thread = marker of the panel, wave = 64-marker sub-block).
+// ---------------------------------------------------------------------------------------------
+struct chain_view {
+    int m_pad, P, nsplit;
+    const double *xpx, *vx;
+    double *g;
+    uint8_t *tracker;
+    uint32_t *nzrate;
+    double *alpha_sum, *alpha_sq;
+    const double *thr, *invv, *sdz;
+    const int32_t *gram;
+    const double *partial;
+    int32_t *ev_count, *ev_idx;
+    double *ev_delta;
+    double *acc;
+    const uint32_t *wind;
+    uint8_t *wflag;
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int k)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K1>
+__global__ __launch_bounds__(1024) void k_chain(const hb_sweep_in *__restrict__ pin, chain_view v, int p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int P = v.P, S = P >> 6;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    int32_t *Gd = reinterpret_cast<int32_t *>(smem);                            // S x 64 x 64
+    double *ev_del = reinterpret_cast<double *>(smem + (size_t)S * 16384);      // P
+    int *ev_ix = reinterpret_cast<int *>(smem + (size_t)S * 16384 + (size_t)P * 8); // P
+    double *red = reinterpret_cast<double *>(smem + (size_t)S * 16384 + (size_t)P * 12); // 16
+    int *cnts = reinterpret_cast<int *>(smem + (size_t)S * 16384 + (size_t)P * 12 + 128); // ev_cnt, class counts
+
+    const int j = p * P + t;
+    const int32_t *gp = v.gram + (size_t)p * P * P;
+
+    // stage this wave's 64x64 diagonal Gram block
+    {
+        int32_t *mine = Gd + wave * 4096;
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+            const int k = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+            const int4 val = *reinterpret_cast<const int4 *>(gp + (size_t)(64 * wave + k) * P + 64 * wave + c4);
+            *reinterpret_cast<int4 *>(mine + k * 64 + c4) = val;
+        }
+    }
+    if (t < 1 + HB_MAX_FOLD) cnts[t] = 0;
+
+    const int model = pin->model_index;
+    const bool active = v.vx[j] != 0.0;
+    const double gold = v.g[j];
+    double rhs = 0.0;
+    for (int sp = 0; sp < v.nsplit; sp++) rhs += v.partial[(size_t)sp * v.m_pad + j];
+    // :594/:616/:725 add xx*oldgi always, :639/:682/:757 only when oldgi != 0 — identical values
+    if (gold != 0.0) rhs = fma(v.xpx[j], gold, rhs);
+    double thr[K1], invv[K1], sdz[K1];
+#pragma unroll
+    for (int c = 0; c < K1; c++) {
+        thr[c] = v.thr[(size_t)c * v.m_pad + j];
+        invv[c] = v.invv[(size_t)c * v.m_pad + j];
+        sdz[c] = v.sdz[(size_t)c * v.m_pad + j];
+    }
+    int cls_f = 0;
+    double g_f = 0.0;
+    __syncthreads();
+
+    int ev_prev = 0;
+    for (int s = 0; s < S; s++) {
+        if (wave == s) {
+            const int32_t *mine = Gd + wave * 4096;
+            int cnt = cnts[0];
+            int lo = 0;
+            for (;;) {
+                const double q = rhs * rhs;
+                int cls = 0;
+                double iv = 0.0, sz = 0.0;
+#pragma unroll
+                for (int c = 0; c < K1; c++) {
+                    const bool ge = q >= thr[c];
+                    cls += ge ? 1 : 0;
+                    iv = ge ? invv[c] : iv;
+                    sz = ge ? sdz[c] : sz;
+                }
+                double gn = (cls > 0) ? fma(rhs, iv, sz) : 0.0;
+                if (model == 5 && fabs(gn) < 1e-6) gn = 1e-6; // :728
+                const double delta = gn - gold;
+                const bool live = lane >= lo;
+                if (live) { cls_f = cls; g_f = gn; }
+                const unsigned long long mask = __ballot(active && live && (delta != 0.0));
+                if (mask == 0ull) break;
+                const int k = __ffsll((long long)mask) - 1;
+                const double dk = readlane_f64(delta, k);
+                if (lane > k) rhs = fma(-(double)mine[k * 64 + lane], dk, rhs);
+                if (lane == k) { ev_ix[cnt] = t; ev_del[cnt] = dk; }
+                cnt++;
+                lo = k + 1;
+                if (lo >= 64) break;
+            }
+            if (lane == 0) cnts[0] = cnt;
+        }
+        __syncthreads();
+        const int ev_now = cnts[0];
+        if (wave > s) {
+            for (int e = ev_prev; e < ev_now; e++) {
+                const int k = ev_ix[e];
+                rhs = fma(-(double)gp[(size_t)k * P + t], ev_del[e], rhs);
+            }
+        }
+        ev_prev = ev_now;
+    }
+
+    // ---- write back ----
+    if (!active) { cls_f = 0; g_f = 0.0; }
+    v.g[j] = g_f;
+    v.tracker[j] = (uint8_t)cls_f;
+    if (pin->count_pip && cls_f != 0) {
+        v.nzrate[j] += 1u;
+        if (v.wind) v.wflag[v.wind[j] - 1u] = 1;
+    }
+    if (pin->store) {
+        v.alpha_sum[j] += g_f;
+        v.alpha_sq[j] += g_f * g_f;
+    }
+    // sums the hyper-parameter draws need: :603 g.g (RR), :698 sum g^2 of included (C),
+    // :791 sum g^2/fold[class] (R); class counts exclude monomorphic markers
+    double w = 0.0;
+    if (cls_f > 0) w = (model == 6) ? g_f * g_f / pin->fold[cls_f] : g_f * g_f;
+    const double wsum = block_sum(w, red);
+    if (active) atomicAdd(&cnts[1 + cls_f], 1);
+    __syncthreads();
+    const int nev = cnts[0];
+    for (int e = t; e < nev; e += P) {
+        v.ev_idx[(size_t)p * P + e] = ev_ix[e];
+        v.ev_delta[(size_t)p * P + e] = ev_del[e];
+    }
+    if (t == 0) {
+        v.ev_count[p] = nev;
+        v.acc[HB_ACC_SUMG2] += wsum;
+        v.acc[HB_ACC_EVENTS] += (double)nev;
+        for (int c = 0; c < HB_MAX_FOLD; c++) v.acc[HB_ACC_COUNT0 + c] += (double)cnts[1 + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_update: yadj -= sum_e x_e D_e, u += the same, r32 = (float)yadj, for the panel's changed markers
+// thread = 4 consecutive rows
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update(const int8_t *__restrict__ X, int64_t ld, int P, int p,
+                                                const int32_t *__restrict__ ev_count,
+                                                const int32_t *__restrict__ ev_idx,
+                                                const double *__restrict__ ev_delta,
+                                                double *__restrict__ r, double *__restrict__ u,
+                                                float *__restrict__ r32)
+{
+    const int nev = ev_count[p];
+    if (nev == 0) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (row0 >= ld) return;
+    const int8_t *xp = X + (int64_t)p * P * ld + row0;
+    const int32_t *ix = ev_idx + (size_t)p * P;
+    const double *dl = ev_delta + (size_t)p * P;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int e = 0;
+    for (; e + 4 <= nev; e += 4) {
+        int w[4];
+        double d[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            w[q] = *reinterpret_cast<const int *>(xp + (int64_t)ix[e + q] * ld);
+            d[q] = dl[e + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            a0 = fma((double)(int8_t)(w[q]), d[q], a0);
+            a1 = fma((double)(int8_t)(w[q] >> 8), d[q], a1);
+            a2 = fma((double)(int8_t)(w[q] >> 16), d[q], a2);
+            a3 = fma((double)(int8_t)(w[q] >> 24), d[q], a3);
+        }
+    }
+    for (; e < nev; e++) {
+        const int w = *reinterpret_cast<const int *>(xp + (int64_t)ix[e] * ld);
+        const double d = dl[e];
+        a0 = fma((double)(int8_t)(w), d, a0);
+        a1 = fma((double)(int8_t)(w >> 8), d, a1);
+        a2 = fma((double)(int8_t)(w >> 16), d, a2);
+        a3 = fma((double)(int8_t)(w >> 24), d, a3);
+    }
+    double2 r01 = *reinterpret_cast<double2 *>(r + row0), r23 = *reinterpret_cast<double2 *>(r + row0 + 2);
+    double2 u01 = *reinterpret_cast<double2 *>(u + row0), u23 = *reinterpret_cast<double2 *>(u + row0 + 2);
+    r01.x -= a0; r01.y -= a1; r23.x -= a2; r23.y -= a3;
+    u01.x += a0; u01.y += a1; u23.x += a2; u23.y += a3;
+    *reinterpret_cast<double2 *>(r + row0) = r01;
+    *reinterpret_cast<double2 *>(r + row0 + 2) = r23;
+    *reinterpret_cast<double2 *>(u + row0) = u01;
+    *reinterpret_cast<double2 *>(u + row0 + 2) = u23;
+    *reinterpret_cast<float4 *>(r32 + row0) = make_float4((float)r01.x, (float)r01.y, (float)r23.x, (float)r23.y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// end-of-sweep reductions behind src/Bayes.cpp:819 (var(u), N-1, two-pass like arma::var) and
+// :823 (yadj.yadj); also sum(yadj) for the next intercept draw (:480). One workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_reduce_ru(const double *__restrict__ r, const double *__restrict__ u,
+                                                    int n, double *__restrict__ acc)
+{
+    __shared__ double red[16];
+    double sr = 0, sr2 = 0, su = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double a = r[i];
+        sr += a;
+        sr2 = fma(a, a, sr2);
+        su += u[i];
+    }
+    sr = block_sum(sr, red);
+    sr2 = block_sum(sr2, red);
+    su = block_sum(su, red);
+    const double mean = su / n;
+    double a2 = 0, a3 = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double d = mean - u[i];
+        a2 = fma(d, d, a2);
+        a3 += d;
+    }
+    a2 = block_sum(a2, red);
+    a3 = block_sum(a3, red);
+    if (threadIdx.x == 0) {
+        acc[HB_ACC_SUMR] = sr;
+        acc[HB_ACC_SUMR2] = sr2;
+        acc[HB_ACC_VARU] = n > 1 ? (a2 - a3 * a3 / n) / (n - 1) : 0.0;
+    }
+}
+
+// BayesL: vargL_j <- 1 / InvGauss(sqrt(vare) lambda / |g_j|, lambda^2), src/Bayes.cpp:729-730
+__global__ __launch_bounds__(256) void k_bayesl_post(const hb_sweep_in *__restrict__ pin, int m, int64_t m_offset,
+                                                     uint64_t seed, const double *__restrict__ vx,
+                                                     const double *__restrict__ g, double *__restrict__ vargL)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m || vx[j] == 0.0) return;
+    const uint64_t sub = hb_sub(HB_PURPOSE_MARKER, (uint64_t)pin->iter);
+    hb_stream st(seed, sub, (uint64_t)(m_offset + j) * HB_BLK_PER_MARKER + 2);
+    const double vargi = 1.0 / st.invgauss(sqrt(pin->vare) * pin->lambda / fabs(g[j]), pin->lambda2);
+    if (vargi >= 0.0) vargL[j] = vargi;
+}
+
+__global__ __launch_bounds__(1024) void k_sum_vec(const double *__restrict__ x, int n, double *__restrict__ out)
+{
+    __shared__ double red[16];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out = s;
+}
+
+__global__ void k_windows(uint8_t *__restrict__ wflag, double *__restrict__ wppa, int nw)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    wppa[w] += (double)wflag[w];
+    wflag[w] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers for the host blocks sharing yadj (reference src/Bayes.cpp:479-516)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_shift(double *__restrict__ r, float *__restrict__ r32, int n, double a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = r[i] + a;
+    r[i] = v;
+    r32[i] = (float)v;
+}
+
+__global__ void k_axpy(double *__restrict__ r, float *__restrict__ r32, const double *__restrict__ x, int n, double a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = fma(a, x[i], r[i]);
+    r[i] = v;
+    r32[i] = (float)v;
+}
+
+__global__ __launch_bounds__(1024) void k_dot_vec(const double *__restrict__ x, const double *__restrict__ y, int n,
+                                                  double *__restrict__ out)
+{
+    __shared__ double red[16];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s = fma(x[i], y[i], s);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out = s;
+}
+
+// Z_t' yadj: per-level sums; one workgroup, LDS-free atomics on a zeroed buffer
+__global__ void k_level_sums(const double *__restrict__ r, const int32_t *__restrict__ zid, int n,
+                             double *__restrict__ sums)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    atomicAdd(&sums[zid[i]], r[i]);
+}
+
+__global__ void k_level_axpy(double *__restrict__ r, float *__restrict__ r32, const int32_t *__restrict__ zid, int n,
+                             const double *__restrict__ delta)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = r[i] + delta[zid[i]];
+    r[i] = v;
+    r32[i] = (float)v;
+}
+
+__global__ void k_to_f32(const double *__restrict__ r, float *__restrict__ r32, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) r32[i] = (float)r[i];
+}
+
+// multi-GPU exchange: pack (yadj - yadj_start, u - u_start) and unpack the summed deltas
+__global__ void k_delta_pack(const double *__restrict__ r, const double *__restrict__ u,
+                             const double *__restrict__ r0, const double *__restrict__ u0, int n,
+                             double *__restrict__ buf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    buf[i] = r[i] - r0[i];
+    buf[n + i] = u[i] - u0[i];
+}
+
+__global__ void k_delta_unpack(double *__restrict__ r, double *__restrict__ u, float *__restrict__ r32,
+                               const double *__restrict__ r0, const double *__restrict__ u0, int n,
+                               const double *__restrict__ buf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = r0[i] + buf[i];
+    r[i] = a;
+    r32[i] = (float)a;
+    u[i] = u0[i] + buf[n + i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// data paths upstream of X: f64 -> int8 check, .bed decode, synthetic generator
+// ---------------------------------------------------------------------------------------------
+__global__ void k_f64_to_i8(const double *__restrict__ src, int64_t lds, int n, int ncols,
+                            int8_t *__restrict__ dst, int64_t ldd, int *__restrict__ bad)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n * ncols) return;
+    const int c = (int)(idx / n), i = (int)(idx % n);
+    const double v = src[(int64_t)c * lds + i];
+    const double rv = rint(v);
+    if (!(rv == v) || rv < -127.0 || rv > 127.0) { atomicExch(bad, 1); return; }
+    dst[(int64_t)c * ldd + i] = (int8_t)rv;
+}
+
+// PLINK .bed SNP-major: byte (i>>2) of SNP j, bits 2*(i&3); map 00->2, 01->NA, 10->1, 11->0
+// (reference src/read_bed.cpp:116-120).  One workgroup per SNP: count genotypes over ALL nind
+// individuals (the reference imputes before ibrm() subsets rows, :182-230), then write the
+// selected rows.
+__global__ __launch_bounds__(256) void k_bed_decode(const uint8_t *__restrict__ bed, int64_t bpc, int nind,
+                                                    const int32_t *__restrict__ rows, int n, int8_t *__restrict__ dst,
+                                                    int64_t ldd)
+{
+    __shared__ long long red[4];
+    const int j = blockIdx.x;
+    const uint8_t *p = bed + (int64_t)j * bpc;
+    long long c0 = 0, c1 = 0, c2 = 0, cm = 0;
+    for (int i = threadIdx.x; i < nind; i += blockDim.x) {
+        const int code = (p[i >> 2] >> (2 * (i & 3))) & 3;
+        c2 += (code == 0);
+        cm += (code == 1);
+        c1 += (code == 2);
+        c0 += (code == 3);
+    }
+    c0 = block_sum(c0, red);
+    c1 = block_sum(c1, red);
+    c2 = block_sum(c2, red);
+    cm = block_sum(cm, red);
+    int8_t major = 0;
+    long long best = 0;
+    if (c0 > best) { best = c0; major = 0; }
+    if (c1 > best) { best = c1; major = 1; }
+    if (c2 > best) { best = c2; major = 2; }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int src = rows ? rows[i] : i;
+        const int code = (p[src >> 2] >> (2 * (src & 3))) & 3;
+        const int8_t gg = code == 0 ? 2 : code == 2 ? 1 : code == 3 ? 0 : major;
+        dst[(int64_t)j * ldd + i] = gg;
+    }
+    (void)cm;
+}
+
+// out[row] = sum_j x[row][j] alpha[j]  (e -= X*alpha, reference src/Bayes.cpp:971); block = 1024 rows x 256 columns
+__global__ __launch_bounds__(256) void k_xalpha(const int8_t *__restrict__ X, int64_t ld, int m_pad,
+                                                const double *__restrict__ alpha, double *__restrict__ out)
+{
+    const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (row0 >= ld) return;
+    const int j0 = blockIdx.y * 256, j1 = min(m_pad, j0 + 256);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int j = j0; j < j1; j++) {
+        const double al = alpha[j];
+        if (al == 0.0) continue;
+        const int w = *reinterpret_cast<const int *>(X + (int64_t)j * ld + row0);
+        a0 = fma((double)(int8_t)(w), al, a0);
+        a1 = fma((double)(int8_t)(w >> 8), al, a1);
+        a2 = fma((double)(int8_t)(w >> 16), al, a2);
+        a3 = fma((double)(int8_t)(w >> 24), al, a3);
+    }
+    if (a0 != 0.0) atomicAdd(out + row0, a0);
+    if (a1 != 0.0) atomicAdd(out + row0 + 1, a1);
+    if (a2 != 0.0) atomicAdd(out + row0 + 2, a2);
+    if (a3 != 0.0) atomicAdd(out + row0 + 3, a3);
+}
+
+// synthetic genotypes, SURVEY §8(d): p_j ~ U(0.05, 0.5), x ~ Binomial(2, p_j); thread = 4 rows
+__global__ __launch_bounds__(256) void k_generate(int8_t *__restrict__ X, int64_t ld, int n, int m, int64_t m_offset,
+                                                  uint64_t seed, int mono_every)
+{
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= ld) return;
+    for (int j = blockIdx.y; j < m; j += gridDim.y) {
+    const uint64_t gj = (uint64_t)(m_offset + j);
+    const uint64_t sub = hb_sub(HB_PURPOSE_DATA, gj);
+    const double pj = 0.05 + 0.45 * hb_uniform_blk(seed, sub, 0xFFFFFFFFFFull);
+    const unsigned thr16 = (unsigned)(pj * 65536.0);
+    const bool mono = mono_every > 0 && (gj % (uint64_t)mono_every) == (uint64_t)(mono_every - 1);
+    const uint4 w = hb_block(seed, sub, (uint64_t)i4);
+    const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+    unsigned out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        unsigned x = ((ws[k] & 0xffffu) < thr16) + ((ws[k] >> 16) < thr16);
+        if (mono || i4 * 4 + k >= n) x = 0;
+        out |= x << (8 * k);
+    }
+    *reinterpret_cast<unsigned *>(X + (int64_t)j * ld + i4 * 4) = out;
+    }
+}
+
+// =============================================================================================
+// host side: launchers
+// =============================================================================================
+static inline int kpad_for(int model, int n_fold)
+{
+    if (model != 6) return 1;
+    const int k1 = n_fold - 1;
+    return k1 <= 1 ? 1 : (k1 <= 3 ? 3 : 7);
+}
+
+static size_t chain_smem(int P) { return (size_t)(P / 64) * 16384 + (size_t)P * 12 + 128 + 64; }
+
+int hbk_init_attrs()
+{
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return HB_OK;
+}
+
+template <int K1>
+static hipError_t launch_chain(hb_ctx *c, const chain_view &cv, int p)
+{
+    const size_t smem = chain_smem(c->P);
+    hipLaunchKernelGGL(k_chain<K1>, dim3(1), dim3(c->P), smem, c->stream, c->d_in, cv, p);
+    return hipGetLastError();
+}
+
+static void launch_dot(hb_ctx *c, int col0, int ncols)
+{
+    const dim3 grid(ncols / 8, c->nsplit), block(256);
+    const int8_t *Xp = c->X + (int64_t)col0 * c->ld;
+    double *part = c->partial + col0;
+    const bool sgn = c->xmin < 0;
+    if (c->precise) {
+        if (sgn) hipLaunchKernelGGL((k_dot<true, true>), grid, block, 0, c->stream, Xp, c->ld, c->r32, c->r, c->nchunks, 1, part, c->m_pad);
+        else     hipLaunchKernelGGL((k_dot<true, false>), grid, block, 0, c->stream, Xp, c->ld, c->r32, c->r, c->nchunks, 1, part, c->m_pad);
+    } else {
+        if (sgn) hipLaunchKernelGGL((k_dot<false, true>), grid, block, 0, c->stream, Xp, c->ld, c->r32, c->r, c->nchunks, 1, part, c->m_pad);
+        else     hipLaunchKernelGGL((k_dot<false, false>), grid, block, 0, c->stream, Xp, c->ld, c->r32, c->r, c->nchunks, 1, part, c->m_pad);
+    }
+}
+
+struct phase_timer {
+    hb_ctx *c;
+    bool on;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> spans;
+    size_t next = 0;
+    phase_timer(hb_ctx *ctx, bool enable) : c(ctx), on(enable) {}
+    hipEvent_t get()
+    {
+        if (next == c->ev_pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            c->ev_pool.push_back(e);
+        }
+        return c->ev_pool[next++];
+    }
+    hipEvent_t begin()
+    {
+        if (!on) return nullptr;
+        hipEvent_t e = get();
+        (void)hipEventRecord(e, c->stream);
+        return e;
+    }
+    void end(int phase, hipEvent_t b)
+    {
+        if (!on) return;
+        hipEvent_t e = get();
+        (void)hipEventRecord(e, c->stream);
+        spans.push_back({phase, {b, e}});
+    }
+};
+
+// enqueue one whole sweep on c->stream (parameters already in c->d_in)
+static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
+{
+    phase_timer tm(c, timed);
+    const int kp = kpad_for(model, n_fold);
+    HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, c->stream));
+    hipEvent_t t_all = tm.begin();
+    {
+        hipEvent_t b = tm.begin();
+        pre_view pv{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
+        hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, c->stream, c->d_in, pv);
+        tm.end(3, b);
+    }
+    chain_view cv{c->m_pad, c->P, c->nsplit, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
+                  c->thr, c->invv, c->sdz, c->gram, c->partial, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
+                  c->wind, c->wflag};
+    const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
+    for (int p = 0; p < c->npanels; p++) {
+        hipEvent_t b = tm.begin();
+        launch_dot(c, p * c->P, c->P);
+        tm.end(0, b);
+        b = tm.begin();
+        hipError_t e = kp == 1 ? launch_chain<1>(c, cv, p) : kp == 3 ? launch_chain<3>(c, cv, p) : launch_chain<7>(c, cv, p);
+        if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain launch: ") + hipGetErrorString(e));
+        tm.end(1, b);
+        b = tm.begin();
+        hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, c->stream, c->X, c->ld, c->P, p, c->ev_count,
+                           c->ev_idx, c->ev_delta, c->r, c->u, c->r32);
+        tm.end(2, b);
+    }
+    {
+        hipEvent_t b = tm.begin();
+        if (model == 5) {
+            hipLaunchKernelGGL(k_bayesl_post, dim3((c->m + 255) / 256), dim3(256), 0, c->stream, c->d_in, c->m,
+                               c->m_offset, c->seed, c->vx, c->g, c->vargL);
+            hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(1024), 0, c->stream, c->vargL, c->m, c->acc + HB_ACC_SUMVARGL);
+        }
+        hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(1024), 0, c->stream, c->r, c->u, c->n, c->acc);
+        tm.end(3, b);
+    }
+    tm.end(4, t_all);
+    HB_HIP(hipGetLastError());
+    if (timed) {
+        HB_HIP(hipStreamSynchronize(c->stream));
+        hb_sweep_timing T{};
+        for (auto &sp : tm.spans) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, sp.second.first, sp.second.second);
+            switch (sp.first) {
+            case 0: T.dot_ms += ms; T.dot_launches++; break;
+            case 1: T.chain_ms += ms; break;
+            case 2: T.update_ms += ms; break;
+            case 3: T.other_ms += ms; break;
+            case 4: T.total_ms += ms; break;
+            }
+        }
+        c->timing = T;
+    }
+    return HB_OK;
+}
+
+int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
+{
+    *c->h_in = *in;
+    HB_HIP(hipMemcpyAsync(c->d_in, c->h_in, sizeof(hb_sweep_in), hipMemcpyHostToDevice, c->stream));
+    if (timed || !c->use_graph) return enqueue_sweep_kernels(c, in->model_index, in->n_fold, timed);
+    if (!c->gexec || c->graph_model != in->model_index || c->graph_fold != in->n_fold) {
+        if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+        HB_HIP(hipStreamSynchronize(c->stream));
+        HB_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
+        hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+        if (rc) return rc;
+        if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        HB_HIP(hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
+        c->graph_model = in->model_index;
+        c->graph_fold = in->n_fold;
+    }
+    HB_HIP(hipGraphLaunch(c->gexec, c->stream));
+    return HB_OK;
+}
+
+// ---- thin launch wrappers used by hb_ctx.cpp ----
+int hbk_stats(hb_ctx *c)
+{
+    int init[2] = {127, -128};
+    HB_HIP(hipMemcpyAsync(c->xinfo, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_stats, dim3(c->m_pad), dim3(256), 0, c->stream, c->X, c->ld, c->n, c->m, c->xpx, c->vx, c->xinfo);
+    HB_HIP(hipGetLastError());
+    int info[2];
+    HB_HIP(hipMemcpyAsync(info, c->xinfo, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    c->xmin = info[0];
+    c->xmax = info[1];
+    c->stats_ready = true;
+    return HB_OK;
+}
+
+int hbk_dot_all(hb_ctx *c)
+{
+    for (int p = 0; p < c->npanels; p++) launch_dot(c, p * c->P, c->P);
+    hipLaunchKernelGGL(k_sum_partials, dim3((c->m_pad + 255) / 256), dim3(256), 0, c->stream, c->partial, c->m_pad,
+                       c->nsplit, c->m_pad, c->dots);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_dot_panels(hb_ctx *c, int reps)
+{
+    for (int r = 0; r < reps; r++)
+        for (int p = 0; p < c->npanels; p++) launch_dot(c, p * c->P, c->P);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_reduce_ru(hb_ctx *c)
+{
+    hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(1024), 0, c->stream, c->r, c->u, c->n, c->acc);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_shift(hb_ctx *c, double a)
+{
+    hipLaunchKernelGGL(k_shift, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->r, c->r32, c->n, a);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_to_f32(hb_ctx *c)
+{
+    hipLaunchKernelGGL(k_to_f32, dim3((int)((c->ld + 255) / 256)), dim3(256), 0, c->stream, c->r, c->r32, (int)c->ld);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_cov_dot(hb_ctx *c, int i, double *dev_out)
+{
+    hipLaunchKernelGGL(k_dot_vec, dim3(1), dim3(1024), 0, c->stream, c->Cmat + (size_t)i * c->n, c->r, c->n, dev_out);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_cov_axpy(hb_ctx *c, int i, double a)
+{
+    hipLaunchKernelGGL(k_axpy, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->r, c->r32, c->Cmat + (size_t)i * c->n, c->n, a);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_level_sums(hb_ctx *c, int term, double *dev_sums, int nlev)
+{
+    HB_HIP(hipMemsetAsync(dev_sums, 0, sizeof(double) * nlev, c->stream));
+    hipLaunchKernelGGL(k_level_sums, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->r, c->zid + (size_t)term * c->n, c->n, dev_sums);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_level_axpy(hb_ctx *c, int term, const double *dev_delta)
+{
+    hipLaunchKernelGGL(k_level_axpy, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->r, c->r32, c->zid + (size_t)term * c->n, c->n, dev_delta);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_windows(hb_ctx *c)
+{
+    if (c->nw) hipLaunchKernelGGL(k_windows, dim3((c->nw + 255) / 256), dim3(256), 0, c->stream, c->wflag, c->wppa, c->nw);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_f64_to_i8(hb_ctx *c, const double *dsrc, int64_t lds, int ncols, int8_t *dst, int *dbad)
+{
+    const int64_t tot = (int64_t)c->n * ncols;
+    hipLaunchKernelGGL(k_f64_to_i8, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, dsrc, lds, c->n, ncols, dst, c->ld, dbad);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_bed_decode(hb_ctx *c, const uint8_t *dbed, int64_t bpc, int nind, const int32_t *drows, int col0, int ncols)
+{
+    hipLaunchKernelGGL(k_bed_decode, dim3(ncols), dim3(256), 0, c->stream, dbed, bpc, nind, drows, c->n, c->X + (int64_t)col0 * c->ld, c->ld);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_generate(hb_ctx *c, uint64_t seed, int mono_every)
+{
+    const dim3 grid((unsigned)((c->ld / 4 + 255) / 256), (unsigned)std::min(c->m, 32768));
+    hipLaunchKernelGGL(k_generate, grid, dim3(256), 0, c->stream, c->X, c->ld, c->n, c->m, c->m_offset, seed, mono_every);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_delta_pack(hb_ctx *c, const double *r0, const double *u0, double *buf)
+{
+    hipLaunchKernelGGL(k_delta_pack, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->r, c->u, r0, u0, c->n, buf);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_delta_unpack(hb_ctx *c, const double *r0, const double *u0, const double *buf)
+{
+    hipLaunchKernelGGL(k_delta_unpack, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->r, c->u, c->r32, r0, u0, c->n, buf);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out)
+{
+    HB_HIP(hipMemsetAsync(dev_out, 0, sizeof(double) * (size_t)c->ld, c->stream));
+    const dim3 grid((unsigned)((c->ld / 4 + 255) / 256), (unsigned)((c->m_pad + 255) / 256));
+    hipLaunchKernelGGL(k_xalpha, grid, dim3(256), 0, c->stream, c->X, c->ld, c->m_pad, dev_alpha, dev_out);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}

@@ -1,0 +1,277 @@
+/*
+ * hibayes_gpu.h — C ABI of libhibayes_gpu.so, the MI355X (gfx950) engine for hibayes'
+ * individual-level per-SNP Gibbs sampler.
+ *
+ * Drop-in boundary.  The reference reaches this path through ONE symbol:
+ *     SEXP _hibayes_Bayes(SEXP x 27)          reference src/RcppExports.cpp:16-50
+ * generated from `Rcpp::List Bayes(arma::vec& y, arma::mat& X, std::string model, ...)`
+ * at reference src/Bayes.cpp:60-88 and called from R/RcppExports.R:4-6 by ibrm()
+ * (R/bayes.r:293-296).  hb_bayes_run() below takes that argument list one-for-one
+ * (plain pointers and sizes; Nullable<T> -> pointer-or-NULL / has_* flags) and returns
+ * the fields of the Rcpp::List built at src/Bayes.cpp:919-1040.  The Rcpp shim a
+ * maintainer adds on the reference side is shown in INTEGRATION.md.
+ *
+ * All functions return 0 on success and a non-zero hb_status otherwise; the message for
+ * the calling thread's last failure is hb_last_error().  Validation failures carry the
+ * reference's own exception texts (src/Bayes.cpp:92-117, :293, :325, :357).  Nothing in
+ * this library aborts the process, and nothing here falls back to a CPU implementation:
+ * without a HIP device every compute entry point fails with HB_ERR_NO_DEVICE.
+ */
+#ifndef HIBAYES_GPU_H
+#define HIBAYES_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HB_ABI_VERSION 1
+#define HB_MAX_FOLD 8
+
+typedef enum {
+    HB_OK = 0,
+    HB_ERR_INVALID = 1,     /* argument validation (reference exception text in hb_last_error) */
+    HB_ERR_NO_DEVICE = 2,   /* no usable HIP device / runtime */
+    HB_ERR_HIP = 3,         /* a HIP call or kernel failed */
+    HB_ERR_UNSUPPORTED = 4, /* argument outside the GPU path (BSLMM, epsilon block, non-integer X) */
+    HB_ERR_COMM = 5,        /* the multi-GPU all-reduce callback failed */
+    HB_ERR_INTERRUPT = 6    /* interrupt callback asked to stop */
+} hb_status;
+
+int hb_abi_version(void);
+const char *hb_version(void);
+const char *hb_last_error(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int hb_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-GPU exchange.  Markers are sharded over `world` processes (one per GPU); once per
+ * sweep every rank contributes a vector of `count` doubles living in DEVICE memory and
+ * needs the element-wise sum over ranks back in place.  The host process supplies the
+ * collective (torch.distributed / RCCL all_reduce in hibayes_amd/dist.py); the library
+ * enqueues its kernels on `hip_stream` and calls this with that stream quiesced.
+ * Return 0 on success.
+ * ------------------------------------------------------------------------------------ */
+typedef int (*hb_allreduce_fn)(void *device_buf, size_t count, void *user);
+/* called once per iteration from the calling thread; non-zero return stops the run
+ * (the shim wires it to R_CheckUserInterrupt; the reference cannot be interrupted) */
+typedef int (*hb_interrupt_fn)(void *user);
+/* console lines the reference prints through Rcpp::Rcout (src/Bayes.cpp:393-461, :884-914,
+ * :1042-1091); NULL = print to stdout when verbose */
+typedef void (*hb_log_fn)(const char *line, void *user);
+
+/* ------------------------------------------------------------------------------------
+ * Arguments of Bayes(), reference src/Bayes.cpp:60-88, same order.
+ * ------------------------------------------------------------------------------------ */
+typedef struct hb_bayes_args {
+    int32_t n;               /* y.n_elem == X.n_rows                                       */
+    int32_t m;               /* X.n_cols (LOCAL columns when sharded)                      */
+    const double *y;         /* arma::vec& y                                        (:61) */
+    /* arma::mat& X (:62).  Exactly one of the two must be non-NULL.  X_f64 is the
+     * reference's layout (column-major doubles) and must hold integers in [-127,127]
+     * (0/1/2 or -1/0/1 genotype codes); X_i8 is the fast path that skips the double
+     * blow-up (e.g. the bigmemory .bin mapping, R/read_plink.r:57-65).                     */
+    const double *X_f64;
+    int64_t ld_f64;          /* leading dimension in elements (>= n)                       */
+    const int8_t *X_i8;
+    int64_t ld_i8;
+    const char *model;       /* std::string model                                    (:63) */
+    const double *Pi;        /* arma::vec Pi                                         (:64) */
+    int32_t n_pi;
+    const double *Kival;     /* BSLMM only (:65) — must be NULL (HB_ERR_UNSUPPORTED)        */
+    const double *Ki;        /* BSLMM only (:66) — must be NULL                             */
+    const double *C;         /* Nullable<arma::mat> C, n x nc column-major           (:67) */
+    int32_t nc;
+    const char *const *R;    /* Nullable<CharacterMatrix> R, n x nr column-major      (:68) */
+    int32_t nr;
+    const double *fold;      /* Nullable<arma::vec> fold                             (:69) */
+    int32_t n_fold;
+    int32_t niter;           /* (:70) default 50000 */
+    int32_t nburn;           /* (:71) default 20000 */
+    int32_t thin;            /* (:72) default 5     */
+    const double *epsl_y_J;  /* single-step epsilon block (:73-75) — must be NULL           */
+    const void *epsl_Gi;
+    const uint32_t *epsl_index;
+    /* Nullable<double> dfvr..s2ve (:76-83): value used only when the has_ flag is set      */
+    int32_t has_dfvr, has_s2vr, has_vg, has_dfvg, has_s2vg, has_ve, has_dfve, has_s2ve;
+    double dfvr, s2vr, vg, dfvg, s2vg, ve, dfve, s2ve;
+    const uint32_t *windindx; /* Nullable<arma::uvec> windindx, m, 1-based           (:84) */
+    int32_t outfreq;          /* (:85) */
+    int32_t threads;          /* (:86) accepted and ignored: there is no OpenMP region     */
+    int32_t verbose;          /* (:87) */
+
+    /* ---- additions that have no reference counterpart ---- */
+    uint64_t seed;            /* replaces R's global RNG state (set.seed(), R/bayes.r:151)  */
+    int32_t device;           /* HIP device ordinal                                         */
+    int32_t panel;            /* markers per block-Gibbs panel: 0 = auto, else 64..1024     */
+    int32_t precise;          /* 1: fp64 accumulation in the panel mat-vec                  */
+    int32_t store_alpha;      /* keep MCMCsamples$alpha (m x n_records) — see hb_bayes_out  */
+    /* marker sharding: this process owns global columns [m_offset, m_offset + m)           */
+    int32_t rank, world;
+    int64_t m_global, m_offset;
+    hb_allreduce_fn allreduce;
+    void *allreduce_user;
+    void *exchange_buf;       /* optional caller-owned DEVICE buffer the collective runs on,
+                                 >= hb_exchange_count(n) doubles (a torch tensor)            */
+    hb_interrupt_fn interrupt;
+    void *interrupt_user;
+    hb_log_fn log;
+    void *log_user;
+} hb_bayes_args;
+
+/* number of doubles exchanged per sweep for n individuals */
+size_t hb_exchange_count(int32_t n);
+
+/* ------------------------------------------------------------------------------------
+ * Result, reference src/Bayes.cpp:919-1040.  Arrays are caller-allocated; a NULL pointer
+ * means "not wanted".  R = n_records = (niter - nburn) / thin.
+ * ------------------------------------------------------------------------------------ */
+typedef struct hb_bayes_out {
+    double Vg, Ve, h2, mu;   /* results["Vg"], ["Ve"], ["h2"], ["mu"]          (:934-944) */
+    int32_t n_records;
+    int32_t nzct;
+    int32_t nw;              /* number of GWAS windows = max(windindx)                     */
+    int32_t n_levels;        /* total random-effect levels                                 */
+    double *beta;            /* nc                                              (:951)    */
+    double *alpha;           /* m                                               (:972)    */
+    double *pi;              /* n_pi                                            (:984)    */
+    double *Vr;              /* nr                                              (:925)    */
+    double *r_est;           /* n_levels, results["r"]$Estimation              (:1020)    */
+    int32_t *r_term_nlevels; /* nr: levels per term; level names are the sorted unique
+                                strings of each R column (makeZ, :36-37)                   */
+    double *g;               /* n: FINAL-iteration u, not a mean               (:1023)    */
+    double *e;               /* n                                              (:1024)    */
+    double *pip;             /* m                                              (:1032)    */
+    double *gwas;            /* nw                                             (:1037)    */
+    /* MCMCsamples: */
+    double *s_Vg, *s_Ve, *s_h2, *s_mu;   /* 1 x R each                         (:937-945) */
+    double *s_beta;          /* nc x R col-major                                (:952)    */
+    double *s_alpha;         /* m x R col-major, only when args.store_alpha     (:973)    */
+    double *s_pi;            /* n_pi x R                                        (:985)    */
+    double *s_Vr;            /* nr x R                                          (:926)    */
+    double *s_r;             /* n_levels x R                                    (:1021)   */
+    /* extras: posterior SD of alpha from the running second moment (m), timings */
+    double *alpha_sd;
+    double setup_seconds;    /* upload + marker statistics + Gram precompute              */
+    double loop_seconds;     /* the MCMC loop only                                        */
+    int32_t iters_done;
+    double mean_events;      /* mean number of markers whose effect changed per sweep     */
+} hb_bayes_out;
+
+/* The whole sampler: replaces Bayes() (reference src/Bayes.cpp:60-1094). */
+int hb_bayes_run(const hb_bayes_args *args, hb_bayes_out *out);
+
+/* ====================================================================================
+ * Fine-grained engine API.  hb_bayes_run() is built on it; the parity tests and bench.py
+ * drive the device pieces through it one at a time.  A context owns all device state of
+ * one genotype shard; calls on one context must be serialised by the caller.
+ * ==================================================================================== */
+typedef struct hb_ctx hb_ctx;
+
+typedef struct hb_ctx_params {
+    int32_t device;
+    int32_t n, m;            /* individuals, local markers */
+    int32_t panel;           /* 0 = auto */
+    int32_t precise;
+    int64_t m_offset;        /* global index of local marker 0 (RNG addressing) */
+    uint64_t seed;
+} hb_ctx_params;
+
+int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out);
+void hb_ctx_destroy(hb_ctx *c);
+int hb_ctx_panel(const hb_ctx *c);
+int64_t hb_ctx_ld(const hb_ctx *c);     /* device leading dimension of X in bytes */
+
+/* Genotypes -> device int8, column-major. ncols columns starting at col0. */
+int hb_ctx_upload_genotype_i8(hb_ctx *c, const int8_t *X, int64_t ld, int32_t col0, int32_t ncols);
+/* doubles are checked for integrality and range, never rounded silently */
+int hb_ctx_upload_genotype_f64(hb_ctx *c, const double *X, int64_t ld, int32_t col0, int32_t ncols);
+/* PLINK .bed (SNP-major, 2 bits/genotype) decoded ON DEVICE with the code map of reference
+ * src/read_bed.cpp:116-120 and its major-genotype imputation (:182-230); `rows` (n long,
+ * indices into the .bed's nind individuals) selects/reorders individuals as ibrm() does
+ * (R/bayes.r:165, :286-291); NULL = first n individuals. bed excludes no header: pass the
+ * whole file image including the 3 magic bytes. */
+int hb_ctx_upload_bed(hb_ctx *c, const uint8_t *bed, int64_t nbytes, int32_t nind,
+                      const int32_t *rows, int32_t col0, int32_t ncols);
+/* synthetic genotypes generated on device (SURVEY §8 d): p_j ~ U(0.05,0.5),
+ * x ~ Binomial(2,p_j), every mono_every-th column forced monomorphic (0 = never) */
+int hb_ctx_generate_genotype(hb_ctx *c, uint64_t seed, int32_t mono_every);
+int hb_ctx_download_genotype(hb_ctx *c, int8_t *X, int64_t ld, int32_t col0, int32_t ncols);
+
+/* xpx_i = sum x^2, vx_i = var(x_i) (N-1), reference src/Bayes.cpp:310-317; integer-exact */
+int hb_ctx_marker_stats(hb_ctx *c, double *xpx, double *vx, double *sumvx, int32_t *nvar0);
+/* per-panel Gram blocks G = X_p' X_p (int32, exact); also reports seconds spent */
+int hb_ctx_build_gram(hb_ctx *c, double *seconds);
+/* rows x cols window of panel p's Gram (row-major int32, P x P) for exactness tests */
+int hb_ctx_download_gram(hb_ctx *c, int32_t panel_index, int32_t *G);
+
+/* residual yadj and u = Xg (n each) */
+int hb_ctx_set_residual(hb_ctx *c, const double *yadj, const double *u);
+int hb_ctx_get_residual(hb_ctx *c, double *yadj, double *u);
+int hb_ctx_set_effects(hb_ctx *c, const double *g, const uint8_t *tracker, const double *vargL);
+int hb_ctx_get_effects(hb_ctx *c, double *g, uint8_t *tracker, double *vargL);
+/* d[j] = x_j . yadj for ncols columns from col0 — the panel mat-vec kernel on its own */
+int hb_ctx_dot(hb_ctx *c, int32_t col0, int32_t ncols, double *d);
+
+/* helpers for the host blocks that share yadj (reference src/Bayes.cpp:479-516) */
+int hb_ctx_residual_sums(hb_ctx *c, double *sum_r, double *sum_r2);
+int hb_ctx_residual_shift(hb_ctx *c, double a);                       /* yadj += a        */
+int hb_ctx_set_covariates(hb_ctx *c, const double *Cmat, int32_t nc); /* n x nc, col-major */
+int hb_ctx_cov_dot(hb_ctx *c, int32_t i, double *out);                /* C_i . yadj        */
+int hb_ctx_cov_axpy(hb_ctx *c, int32_t i, double a);                  /* yadj += a C_i     */
+int hb_ctx_set_levels(hb_ctx *c, const int32_t *zid, int32_t nr, const int32_t *nlev);
+int hb_ctx_level_sums(hb_ctx *c, int32_t term, double *sums);         /* Z_t' yadj         */
+int hb_ctx_level_axpy(hb_ctx *c, int32_t term, const double *delta);  /* yadj += Z_t delta */
+
+/* One marker sweep (reference src/Bayes.cpp:586-816) plus the two reductions behind
+ * :819 and :823.  Hyper-parameters come from the host, per-SNP draws happen on device. */
+typedef struct hb_sweep_in {
+    int32_t model_index;     /* 1 RR, 2 A, 3 B/Bpi, 4 C/Cpi, 5 L, 6 R   (:97)              */
+    int32_t n_fold;
+    int64_t iter;            /* addresses the marker RNG stream                             */
+    double vare;
+    double varg;             /* shared marker variance (RR, C, R)                           */
+    double s2varg_df;        /* s2varg_ * dfvara_ (A, B)                                    */
+    double dfvara;           /* (A, B)                                                      */
+    double logpi[HB_MAX_FOLD];
+    double fold[HB_MAX_FOLD];
+    double vara_fold[HB_MAX_FOLD];
+    double lambda, lambda2;  /* (L)                                                         */
+    int32_t count_pip;       /* iter >= nburn: accumulate nzrate / window flags             */
+    int32_t store;           /* thinned record: accumulate alpha moments                    */
+} hb_sweep_in;
+
+typedef struct hb_sweep_out {
+    double sum_g2;            /* g.g (RR) | sum g^2 of included (C) | sum g^2/fold (R)      */
+    double class_count[HB_MAX_FOLD]; /* markers per class among polymorphic ones, class 0
+                                        EXCLUDES monomorphic markers                         */
+    double sum_vargL;         /* (L) sum over markers incl. untouched monomorphic ones      */
+    double sum_r, sum_r2;     /* over yadj after the sweep                                   */
+    double var_u;             /* var(u), N-1                                                 */
+    double n_events;          /* markers whose effect changed                                */
+} hb_sweep_out;
+
+int hb_ctx_sweep(hb_ctx *c, const hb_sweep_in *in, hb_sweep_out *out);
+/* nzrate counters (m, as doubles), alpha sum / sum of squares over stored records */
+int hb_ctx_get_counters(hb_ctx *c, double *nzrate, double *alpha_sum, double *alpha_sq);
+int hb_ctx_set_windows(hb_ctx *c, const uint32_t *windindx, int32_t nw);
+int hb_ctx_get_windows(hb_ctx *c, double *wppa);
+
+/* device timing of the last hb_ctx_sweep: milliseconds by phase, averaged per launch */
+typedef struct hb_sweep_timing {
+    double total_ms;
+    double dot_ms;       /* summed over panel launches */
+    int32_t dot_launches;
+    double chain_ms;
+    double update_ms;
+    double other_ms;
+} hb_sweep_timing;
+int hb_ctx_last_timing(hb_ctx *c, hb_sweep_timing *t);
+int hb_ctx_set_profiling(hb_ctx *c, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
