@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""bench.py — Gibbs sweeps/sec of the individual-level marker sweep on MI355X.
+
+Metric (BASELINE.json): "Gibbs sweeps/sec (full m-marker pass) + achieved HBM GB/s, n=50k m=500k".
+One step = one iteration of the reference's MCMC loop (src/Bayes.cpp:477-917): intercept draw,
+the full m-marker sweep on the device, the end-of-sweep reductions and the host hyper-parameter
+draws — on synthetic int8 genotypes already resident in HBM (SURVEY.md §8 d).
+
+  python bench.py --gpus 1 --steps K --warmup W            single GPU
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   marker-sharded
+
+Weak scaling: every rank holds --m markers (m_global = N * m); `value` counts passes over m markers
+by all ranks per second, i.e. N * (global sweeps/s).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as ct
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=50000)
+    ap.add_argument("--m", type=int, default=500000)
+    ap.add_argument("--model", default="BayesR")
+    ap.add_argument("--panel", type=int, default=0)
+    ap.add_argument("--precise", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=20240901)
+    ap.add_argument("--profile-sweeps", type=int, default=3, help="extra sweeps timed kernel by kernel with HIP events")
+    ap.add_argument("--cpu-m", type=int, default=8000, help="markers of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sweeps", type=int, default=4)
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def synth_phenotype(ctx, n, m, m_offset, m_global, seed, comm, model):
+    """y = X beta + e with h2 = 0.5 and 0.1% causal markers (SURVEY.md §8 d); BayesR: the three
+    non-null classes in ratio 2:2:1 with variances 1e-4 : 1e-3 : 1e-2."""
+    rng = np.random.default_rng(seed + 17)  # identical on every rank
+    n_causal = max(1, int(round(0.001 * m_global)))
+    idx = np.sort(rng.choice(m_global, n_causal, replace=False))
+    eff = rng.normal(0.0, 1.0, n_causal)
+    if model == "BayesR":
+        cls = rng.choice(3, n_causal, p=[0.4, 0.4, 0.2])
+        eff *= np.sqrt(np.array([1e-4, 1e-3, 1e-2])[cls])
+    beta = np.zeros(m)
+    loc = (idx >= m_offset) & (idx < m_offset + m)
+    beta[idx[loc] - m_offset] = eff[loc]
+    xb = np.zeros(n)
+    from hibayes_amd._lib import check
+    check(ctx.L.hb_ctx_matvec(ctx.h, beta.ctypes.data, xb.ctypes.data))
+    if comm is not None:
+        t = comm.torch.tensor(xb, device=comm.device)
+        comm.dist.all_reduce(t)
+        xb = t.cpu().numpy()
+    xb -= xb.mean()
+    xb *= np.sqrt(0.5 / xb.var())
+    return xb + rng.normal(0.0, np.sqrt(0.5), n)
+
+
+def cpu_baseline(ctx, y, args, Pi, fold):
+    """Times oracle/hb_oracle.c (the faithful port of src/Bayes.cpp: double column-major X, serial
+    marker loop, BLAS-1 shaped dot/axpy) on the first --cpu-m markers of the same data, then scales
+    to m markers (cost per sweep is exactly linear in m: one independent column per marker)."""
+    from oracle import oracle as O
+    mc = min(args.cpu_m, args.m)
+    X8 = ctx.download(0, mc)
+    Xd = np.asfortranarray(X8, dtype=np.float64)  # the reference's layout: 8 bytes per genotype
+    del X8
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    out = {}
+    it = 1 + args.cpu_sweeps
+    # nburn = niter - 1: sweeps run exactly as in the reference loop, one stored record
+    r = O.bayes(y, Xd, args.model, Pi, fold=fold, niter=it, nburn=it - 1, thin=1, threads=1,
+                rng=O.RNG_PHILOX, seed=args.seed)
+    out[1] = r["iters_done"] / r["loop_seconds"] * (mc / float(args.m))
+    one_thread_s = r["loop_seconds"]
+    # threaded dot/axpy (what a threaded BLAS would give the reference, README.md:18). BLAS-1 on
+    # n-long vectors rarely scales; bounded by a wall-clock guard in a child process.
+    thr = min(cores, 16)
+    if thr > 1:
+        import multiprocessing as mp
+
+        def _child(q):
+            os.environ["OMP_WAIT_POLICY"] = "passive"
+            rr = O.bayes(y, Xd, args.model, Pi, fold=fold, niter=it, nburn=it - 1, thin=1, threads=thr,
+                         rng=O.RNG_PHILOX, seed=args.seed)
+            q.put(rr["iters_done"] / rr["loop_seconds"])
+
+        q = mp.get_context("fork").Queue()
+        p = mp.get_context("fork").Process(target=_child, args=(q,))
+        p.start()
+        p.join(timeout=max(30.0, 4.0 * one_thread_s))
+        if p.is_alive():
+            p.terminate()
+            p.join()
+        elif not q.empty():
+            out[thr] = q.get() * (mc / float(args.m))
+    best_thr = max(out, key=lambda k: out[k])
+    return {"value": out[best_thr], "unit": "sweeps/s", "cores": best_thr, "kind": "port",
+            "sample": "oracle/hb_oracle.c (double col-major X, serial marker loop) on the first %d of %d markers, "
+                      "n=%d, %d sweeps, scaled by m_sample/m" % (mc, args.m, args.n, 1 + args.cpu_sweeps),
+            "value_1thread": out[1], "host_cores": cores}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    comm = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        from hibayes_amd.dist import TorchComm
+        comm = TorchComm(device=torch.device("cuda", local_rank))
+    import hibayes_amd as H
+    from hibayes_amd import _lib
+    from hibayes_amd._lib import BayesArgs, BayesOut, RunInfo, check
+    L = H.lib()
+
+    n, m = args.n, args.m
+    m_global, m_offset = m * world, m * rank
+    if args.model == "BayesR":
+        Pi, fold = [0.95, 0.02, 0.02, 0.01], [0.0, 1e-4, 1e-3, 1e-2]  # R/bayes.r:273-275
+    else:
+        Pi, fold = [0.95, 0.05], None
+
+    def note(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
+
+    t_start = t0 = time.time()
+    ctx = H.Context(n, m, device=local_rank, panel=args.panel, precise=bool(args.precise), m_offset=m_offset,
+                    seed=args.seed)
+    ctx.generate(args.seed, mono_every=1000)
+    gen_s = time.time() - t0
+    note("genotypes generated on device (%.2fs)" % gen_s)
+    y = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, args.model)
+    note("phenotype built")
+    gram_s = ctx.build_gram()
+    note("Gram blocks built (%.2fs)" % gram_s)
+
+    K, W, PS = args.steps, args.warmup, args.profile_sweeps
+    a = BayesArgs()
+    a.n, a.m = n, m
+    yv = np.ascontiguousarray(y)
+    a.y = yv.ctypes.data
+    a.model = args.model.encode()
+    pv = np.array(Pi)
+    a.Pi, a.n_pi = pv.ctypes.data, pv.size
+    if fold is not None:
+        fv = np.array(fold)
+        a.fold, a.n_fold = fv.ctypes.data, fv.size
+    a.niter, a.nburn, a.thin = W + K + PS + 5, 0, 5  # every sweep counts PIP, every 5th is a stored record
+    a.outfreq, a.verbose = 0, 0
+    a.seed, a.device, a.precise, a.store_alpha = args.seed, local_rank, args.precise, 0
+    a.ctx = ctx.h
+    keep = []
+    if comm is not None:
+        a.rank, a.world, a.m_global, a.m_offset = rank, world, m_global, m_offset
+        cb, ptr = comm.make_callback(L.hb_exchange_count(n))
+        a.allreduce, a.exchange_buf = cb, ptr
+        keep.append(cb)
+    run = ct.c_void_p()
+    check(L.hb_run_create(ct.byref(a), ct.byref(run)))
+    fin = ct.c_int32()
+
+    def sync():
+        torch.cuda.synchronize(local_rank)
+        if comm is not None:
+            comm.barrier()
+            torch.cuda.synchronize(local_rank)
+
+    note("run created")
+    check(L.hb_run_step(run, W, ct.byref(fin)))
+    sync()
+    note("warm-up done")
+    t1 = time.perf_counter()
+    check(L.hb_run_step(run, K, ct.byref(fin)))
+    sync()
+    elapsed = time.perf_counter() - t1
+    note("timed region done: %.3fs for %d steps" % (elapsed, K))
+    if comm is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm.device)
+        comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    info = RunInfo()
+    check(L.hb_run_state(run, ct.byref(info)))
+
+    # kernel-by-kernel pass: HIP events on the stream the kernels run on
+    roof = None
+    if PS > 0:
+        ctx.set_profiling(True)
+        dot_ms, launches, tot, chain, upd = 0.0, 0, 0.0, 0.0, 0.0
+        for _ in range(PS):
+            check(L.hb_run_step(run, 1, ct.byref(fin)))
+            tm = ctx.last_timing()
+            dot_ms += tm["dot_ms"]; launches += tm["dot_launches"]; tot += tm["total_ms"]
+            chain += tm["chain_ms"]; upd += tm["update_ms"]
+        ctx.set_profiling(False)
+        P = ctx.panel
+        avg_ms = dot_ms / max(launches, 1)
+        alg_bytes = float(n) * P  # one read of the panel's int8 genotypes (SURVEY §8 d: n*m per sweep)
+        ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": alg_bytes,
+                "avg_launch_ms": avg_ms, "launches_per_sweep": launches // PS,
+                "sweep_phase_ms": {"total": tot / PS, "dot": dot_ms / PS, "chain": chain / PS, "update": upd / PS}}
+
+    note("profiling pass done")
+    value = world * K / elapsed
+    res = {
+        "metric": "Gibbs sweeps/sec (full m-marker pass), n=50k m=500k",
+        "value": value, "unit": "sweeps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64" if args.precise else "f32", "data": "synthetic",
+        "config": {"workload": "%s marker sweep, n=%d individuals x m=%d int8 markers per GPU (m_global=%d), "
+                               "panel=%d" % (args.model, n, m, m_global, ctx.panel),
+                   "model": args.model, "n": n, "m_per_gpu": m, "m_global": m_global, "panel": ctx.panel,
+                   "sharding": "markers, contiguous ranges, one residual all-reduce per sweep" if world > 1 else "none",
+                   "mean_changed_markers_per_sweep": info.mean_events, "NumNZSnp_last": info.nnz,
+                   "setup_seconds": {"generate": gen_s, "gram": gram_s}},
+        "achieved_GBps": value * n * m / 1e9, "achieved_frac_of_hbm_peak": value * n * m / 1e9 / (HBM_PEAK_GBPS * world),
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        try:
+            res["cpu_baseline"] = cpu_baseline(ctx, y, args, Pi, fold)
+        except Exception as e:  # the baseline is a reported side number, never the measured path
+            res["cpu_baseline"] = {"error": repr(e)}
+    L.hb_run_destroy(run)
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(res))
+    if comm is not None:
+        comm.dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

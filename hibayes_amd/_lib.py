@@ -54,6 +54,7 @@ class BayesArgs(C.Structure):
         ("exchange_buf", C.c_void_p),
         ("interrupt", INTERRUPT_FN), ("interrupt_user", C.c_void_p),
         ("log", LOG_FN), ("log_user", C.c_void_p),
+        ("ctx", C.c_void_p),
     ]
 
 
@@ -71,6 +72,15 @@ class BayesOut(C.Structure):
         ("setup_seconds", C.c_double), ("loop_seconds", C.c_double),
         ("iters_done", C.c_int32),
         ("mean_events", C.c_double),
+    ]
+
+
+class RunInfo(C.Structure):
+    _fields_ = [
+        ("iter", C.c_int32), ("records", C.c_int32), ("nnz", C.c_double),
+        ("vara", C.c_double), ("vare", C.c_double), ("varg", C.c_double), ("mu", C.c_double),
+        ("pi", C.c_double * HB_MAX_FOLD), ("mean_events", C.c_double),
+        ("loop_seconds", C.c_double), ("setup_seconds", C.c_double), ("gram_seconds", C.c_double),
     ]
 
 
@@ -115,7 +125,8 @@ SYMBOLS = [
     "hb_ctx_get_residual", "hb_ctx_set_effects", "hb_ctx_get_effects", "hb_ctx_dot", "hb_ctx_residual_sums",
     "hb_ctx_residual_shift", "hb_ctx_set_covariates", "hb_ctx_cov_dot", "hb_ctx_cov_axpy", "hb_ctx_set_levels",
     "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_sweep", "hb_ctx_get_counters", "hb_ctx_set_windows",
-    "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling",
+    "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec",
+    "hb_run_create", "hb_run_step", "hb_run_state", "hb_run_ctx", "hb_run_finish", "hb_run_destroy",
 ]
 
 
@@ -168,6 +179,15 @@ def lib():
     L.hb_ctx_get_windows.argtypes = [vp, vp]
     L.hb_ctx_last_timing.argtypes = [vp, C.POINTER(SweepTiming)]
     L.hb_ctx_set_profiling.argtypes = [vp, i32]
+    L.hb_ctx_matvec.argtypes = [vp, vp, vp]
+    L.hb_run_create.argtypes = [C.POINTER(BayesArgs), C.POINTER(vp)]
+    L.hb_run_step.argtypes = [vp, i32, C.POINTER(i32)]
+    L.hb_run_state.argtypes = [vp, C.POINTER(RunInfo)]
+    L.hb_run_ctx.argtypes = [vp]
+    L.hb_run_ctx.restype = vp
+    L.hb_run_finish.argtypes = [vp, C.POINTER(BayesOut)]
+    L.hb_run_destroy.argtypes = [vp]
+    L.hb_run_destroy.restype = None
     _lib = L
     return L
 

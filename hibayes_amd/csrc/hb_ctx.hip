@@ -21,6 +21,7 @@ int hbk_windows(hb_ctx *c);
 int hbk_f64_to_i8(hb_ctx *c, const double *dsrc, int64_t lds, int ncols, int8_t *dst, int *dbad);
 int hbk_bed_decode(hb_ctx *c, const uint8_t *dbed, int64_t bpc, int nind, const int32_t *drows, int col0, int ncols);
 int hbk_generate(hb_ctx *c, uint64_t seed, int mono_every);
+int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out);
 
 static thread_local std::string g_err;
 
@@ -156,7 +157,7 @@ void hb_ctx_destroy(hb_ctx *c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     void *ptrs[] = {c->X, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dots, c->ev_count, c->ev_idx,
-                    c->ev_delta, c->acc, c->d_in, c->scratch, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
+                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -401,6 +402,28 @@ int hb_ctx_dot(hb_ctx *c, int32_t col0, int32_t ncols, double *d)
     return HB_OK;
 }
 
+int hb_ctx_matvec(hb_ctx *c, const double *alpha, double *out)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_matvec");
+    if (rc) return rc;
+    if (!alpha || !out) return hb_fail(HB_ERR_INVALID, "hb_ctx_matvec: null argument");
+    double *da = nullptr, *dout = nullptr;
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&da), sizeof(double) * (size_t)c->m_pad));
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&dout), sizeof(double) * (size_t)c->ld));
+    hipError_t e = hipMemset(da, 0, sizeof(double) * (size_t)c->m_pad);
+    if (e == hipSuccess) e = hipMemcpy(da, alpha, sizeof(double) * c->m, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = hbk_xalpha(c, da, dout);
+        if (rc == HB_OK) e = hipStreamSynchronize(c->stream);
+        if (rc == HB_OK && e == hipSuccess) e = hipMemcpy(out, dout, sizeof(double) * c->n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(da);
+    (void)hipFree(dout);
+    if (rc) return rc;
+    if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("hb_ctx_matvec: ") + hipGetErrorString(e));
+    return HB_OK;
+}
+
 static int fetch_acc(hb_ctx *c)
 {
     HB_HIP(hipMemcpyAsync(c->h_acc, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToHost, c->stream));
@@ -610,7 +633,20 @@ int hb_ctx_last_timing(hb_ctx *c, hb_sweep_timing *t)
 int hb_ctx_set_profiling(hb_ctx *c, int32_t on)
 {
     if (!c) return hb_fail(HB_ERR_INVALID, "hb_ctx_set_profiling: null context");
-    c->profiling = on != 0;
+    c->profiling = (on & 1) != 0;
+    if ((on & 2) && !c->dbg) { // bit 1: cycle stamps inside k_chain (development aid)
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->dbg), sizeof(long long) * 32 * (size_t)c->npanels));
+        HB_HIP(hipMemset(c->dbg, 0, sizeof(long long) * 32 * (size_t)c->npanels));
+        c->graph_model = -1;
+    }
+    return HB_OK;
+}
+
+int hb_ctx_debug_stamps(hb_ctx *c, long long *out)
+{
+    if (!c || !c->dbg) return hb_fail(HB_ERR_INVALID, "hb_ctx_debug_stamps: stamps not enabled");
+    HB_HIP(hipStreamSynchronize(c->stream));
+    HB_HIP(hipMemcpy(out, c->dbg, sizeof(long long) * 32 * (size_t)c->npanels, hipMemcpyDeviceToHost));
     return HB_OK;
 }
 

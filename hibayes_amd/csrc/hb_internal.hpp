@@ -69,6 +69,7 @@ struct hb_ctx {
     double *lev_buf = nullptr;
     int lev_total = 0;
     double *scratch = nullptr; // small device scratch (>= 4096 doubles)
+    long long *dbg = nullptr;  // optional chain-kernel cycle stamps, 32 per panel
 
     uint32_t *wind = nullptr;
     uint8_t *wflag = nullptr;

@@ -345,7 +345,10 @@ struct chain_view {
     double *acc;
     const uint32_t *wind;
     uint8_t *wflag;
+    long long *dbg; // optional: 32 cycle stamps per panel (tools/chain_timeline.py)
 };
+
+#define HB_STAMP(i) do { if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + (i)] = clock64(); } while (0)
 
 __device__ __forceinline__ double readlane_f64(double v, int k)
 {
@@ -354,40 +357,35 @@ __device__ __forceinline__ double readlane_f64(double v, int k)
     return __hiloint2double(hi, lo);
 }
 
+// LDS plan (dynamic, one object): [row cache: nslot x P int32][ev_del: P f64][ev_ix: P i32][slot_of: P i32]
+// [red: 16 f64][cnts: 16 i32][wcnt: 16 i32].
+// The row cache holds the full Gram rows G[k][0..P) of the markers that are certain to move this sweep
+// (g_old != 0): both the in-wave corrections and the cross-wave ones are then LDS reads.  A marker that
+// enters the model from zero (a "surprise") falls back to reading its row from global memory.
 template <int K1>
-__global__ __launch_bounds__(1024) void k_chain(const hb_sweep_in *__restrict__ pin, chain_view v, int p)
+__global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ pin, chain_view v, int p, int nslot)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int P = v.P, S = P >> 6;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    int32_t *Gd = reinterpret_cast<int32_t *>(smem);                            // S x 64 x 64
-    double *ev_del = reinterpret_cast<double *>(smem + (size_t)S * 16384);      // P
-    int *ev_ix = reinterpret_cast<int *>(smem + (size_t)S * 16384 + (size_t)P * 8); // P
-    double *red = reinterpret_cast<double *>(smem + (size_t)S * 16384 + (size_t)P * 12); // 16
-    int *cnts = reinterpret_cast<int *>(smem + (size_t)S * 16384 + (size_t)P * 12 + 128); // ev_cnt, class counts
+    int32_t *rowc = reinterpret_cast<int32_t *>(smem);
+    char *base = smem + (size_t)nslot * P * 4;
+    double *ev_del = reinterpret_cast<double *>(base);
+    int *ev_ix = reinterpret_cast<int *>(base + (size_t)P * 8);
+    int *slot_of = reinterpret_cast<int *>(base + (size_t)P * 12);
+    double *red = reinterpret_cast<double *>(base + (size_t)P * 16);
+    int *cnts = reinterpret_cast<int *>(base + (size_t)P * 16 + 128);
+    int *wcnt = cnts + 16;
 
     const int j = p * P + t;
     const int32_t *gp = v.gram + (size_t)p * P * P;
+    HB_STAMP(0);
 
-    // stage this wave's 64x64 diagonal Gram block
-    {
-        int32_t *mine = Gd + wave * 4096;
-#pragma unroll 4
-        for (int it = 0; it < 16; it++) {
-            const int k = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-            const int4 val = *reinterpret_cast<const int4 *>(gp + (size_t)(64 * wave + k) * P + 64 * wave + c4);
-            *reinterpret_cast<int4 *>(mine + k * 64 + c4) = val;
-        }
-    }
-    if (t < 1 + HB_MAX_FOLD) cnts[t] = 0;
-
+    // ---- issue every per-marker load up front (one memory latency for all of them) ----
     const int model = pin->model_index;
-    const bool active = v.vx[j] != 0.0;
+    const double vxj = v.vx[j];
     const double gold = v.g[j];
-    double rhs = 0.0;
-    for (int sp = 0; sp < v.nsplit; sp++) rhs += v.partial[(size_t)sp * v.m_pad + j];
-    // :594/:616/:725 add xx*oldgi always, :639/:682/:757 only when oldgi != 0 — identical values
-    if (gold != 0.0) rhs = fma(v.xpx[j], gold, rhs);
+    const double xx = v.xpx[j];
     double thr[K1], invv[K1], sdz[K1];
 #pragma unroll
     for (int c = 0; c < K1; c++) {
@@ -395,18 +393,87 @@ __global__ __launch_bounds__(1024) void k_chain(const hb_sweep_in *__restrict__ 
         invv[c] = v.invv[(size_t)c * v.m_pad + j];
         sdz[c] = v.sdz[(size_t)c * v.m_pad + j];
     }
+    double ps[16];
+    {
+        const int last = v.nsplit - 1;
+#pragma unroll
+        for (int sp = 0; sp < 16; sp++) ps[sp] = v.partial[(size_t)min(sp, last) * v.m_pad + j]; // clamped: no branches
+    }
+    const bool active = vxj != 0.0;
+    const bool hot = active && gold != 0.0;
+
+    // ---- slots for the hot markers, in marker order ----
+    const unsigned long long hmask = __ballot(hot);
+    if (lane == 0) wcnt[wave] = __popcll(hmask);
+    if (t < 16) cnts[t] = 0;
+    __syncthreads();
+    int sbase = 0, nhot = 0;
+    for (int w = 0; w < S; w++) {
+        const int c = wcnt[w];
+        sbase += (w < wave) ? c : 0;
+        nhot += c;
+    }
+    const int myslot_raw = sbase + __popcll(hmask & ((1ull << lane) - 1ull));
+    const int myslot = (hot && myslot_raw < nslot) ? myslot_raw : -1; // lane-resident: slot of marker t
+    slot_of[t] = myslot;
+    if (myslot >= 0) ev_ix[myslot] = t; // borrowed as the slot -> marker list until the chain starts
+    __syncthreads();
+    // ---- stream the hot rows into LDS. One item = 256 consecutive ints of the row cache; four items per
+    // wave in flight. Indices are clamped instead of predicated so that the loads stay branch-free. ----
+    {
+        const int ncached = min(nhot, nslot);
+        if (ncached > 0) {
+            const int lgP = 31 - __clz(P);
+            const int total = ncached << lgP;          // ints in the cache image
+            const int items = (total + 255) >> 8;
+            for (int it0 = wave; it0 < items; it0 += 4 * S) {
+                int4 val0, val1, val2, val3;
+                int lin[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) lin[q] = min(((it0 + q * S) << 8) + lane * 4, total - 4);
+                val0 = *reinterpret_cast<const int4 *>(gp + ((size_t)ev_ix[lin[0] >> lgP] << lgP) + (lin[0] & (P - 1)));
+                val1 = *reinterpret_cast<const int4 *>(gp + ((size_t)ev_ix[lin[1] >> lgP] << lgP) + (lin[1] & (P - 1)));
+                val2 = *reinterpret_cast<const int4 *>(gp + ((size_t)ev_ix[lin[2] >> lgP] << lgP) + (lin[2] & (P - 1)));
+                val3 = *reinterpret_cast<const int4 *>(gp + ((size_t)ev_ix[lin[3] >> lgP] << lgP) + (lin[3] & (P - 1)));
+                *reinterpret_cast<int4 *>(rowc + lin[0]) = val0; // clamped duplicates rewrite identical data
+                *reinterpret_cast<int4 *>(rowc + lin[1]) = val1;
+                *reinterpret_cast<int4 *>(rowc + lin[2]) = val2;
+                *reinterpret_cast<int4 *>(rowc + lin[3]) = val3;
+            }
+        }
+    }
+    double rhs = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < 16; sp++) rhs += (sp < v.nsplit) ? ps[sp] : 0.0;
+    for (int sp = 16; sp < v.nsplit; sp++) rhs += v.partial[(size_t)sp * v.m_pad + j];
+    // :594/:616/:725 add xx*oldgi always, :639/:682/:757 only when oldgi != 0 — identical values
+    if (gold != 0.0) rhs = fma(xx, gold, rhs);
     int cls_f = 0;
     double g_f = 0.0;
     __syncthreads();
+    HB_STAMP(1);
 
     int ev_prev = 0;
+    int *ev_sl = slot_of; // after the hot rows are cached, slot_of is only needed through ev_sl/myslot
+    (void)ev_sl;
     for (int s = 0; s < S; s++) {
         if (wave == s) {
-            const int32_t *mine = Gd + wave * 4096;
             int cnt = cnts[0];
             int lo = 0;
+            unsigned long long hleft = hmask;                   // hot lanes not yet passed
+            const unsigned long long amask = __ballot(active);  // polymorphic lanes
             for (;;) {
+                // the next certain event is the next hot lane: fetch its Gram entry while deciding
+                const int knext = hleft ? (__ffsll((long long)hleft) - 1) : 0;
+                const int snext = __builtin_amdgcn_readlane(myslot, knext);
+                int gnext = 0;
+                if (hleft && snext >= 0) gnext = rowc[(size_t)snext * P + t];
                 const double q = rhs * rhs;
+                // a marker at zero moves only if it enters the model (q >= thr[0]); a hot one always moves
+                const unsigned long long live = ~0ull << lo;
+                const unsigned long long mask = ((__ballot(q >= thr[0]) & amask) | hleft) & live;
+                if (mask == 0ull) break;
+                const int k = __ffsll((long long)mask) - 1;
                 int cls = 0;
                 double iv = 0.0, sz = 0.0;
 #pragma unroll
@@ -419,30 +486,57 @@ __global__ __launch_bounds__(1024) void k_chain(const hb_sweep_in *__restrict__ 
                 double gn = (cls > 0) ? fma(rhs, iv, sz) : 0.0;
                 if (model == 5 && fabs(gn) < 1e-6) gn = 1e-6; // :728
                 const double delta = gn - gold;
-                const bool live = lane >= lo;
-                if (live) { cls_f = cls; g_f = gn; }
-                const unsigned long long mask = __ballot(active && live && (delta != 0.0));
-                if (mask == 0ull) break;
-                const int k = __ffsll((long long)mask) - 1;
+                if (lane == k) { cls_f = cls; g_f = gn; }
                 const double dk = readlane_f64(delta, k);
-                if (lane > k) rhs = fma(-(double)mine[k * 64 + lane], dk, rhs);
-                if (lane == k) { ev_ix[cnt] = t; ev_del[cnt] = dk; }
-                cnt++;
+                const int tk = 64 * s + k;
+                if (dk != 0.0) { // (a hot marker redrawing exactly its old value would be a no-op)
+                    int gv;
+                    int slot = snext;
+                    if (!(hleft && k == knext)) slot = __builtin_amdgcn_readlane(myslot, k);
+                    if (hleft && k == knext && snext >= 0) {
+                        gv = gnext;
+                    } else if (slot >= 0) {
+                        gv = rowc[(size_t)slot * P + t];
+                    } else { // a marker entering the model from zero: its Gram row is still in global memory
+                        gv = gp[(size_t)tk * P + t];
+                    }
+                    if (lane > k) rhs = fma(-(double)gv, dk, rhs);
+                    if (lane == k) { ev_ix[cnt] = (slot << 16) | tk; ev_del[cnt] = dk; }
+                    cnt++;
+                }
                 lo = k + 1;
                 if (lo >= 64) break;
+                hleft &= ~((2ull << k) - 1ull);
             }
             if (lane == 0) cnts[0] = cnt;
         }
         __syncthreads();
         const int ev_now = cnts[0];
-        if (wave > s) {
-            for (int e = ev_prev; e < ev_now; e++) {
-                const int k = ev_ix[e];
-                rhs = fma(-(double)gp[(size_t)k * P + t], ev_del[e], rhs);
+        if (wave > s) { // later sub-blocks take the new events; event records first, Gram entries second
+            for (int e0 = ev_prev; e0 < ev_now; e0 += 8) {
+                int rec[8], gv[8];
+                double dl[8];
+#pragma unroll
+                for (int q8 = 0; q8 < 8; q8++) {
+                    const int e = min(e0 + q8, ev_now - 1);
+                    rec[q8] = ev_ix[e];
+                    dl[q8] = (e0 + q8 < ev_now) ? ev_del[e] : 0.0;
+                }
+#pragma unroll
+                for (int q8 = 0; q8 < 8; q8++) {
+                    const int slot = __builtin_amdgcn_readfirstlane(rec[q8] >> 16);
+                    const int k = __builtin_amdgcn_readfirstlane(rec[q8] & 0xffff);
+                    if (slot >= 0) gv[q8] = rowc[(size_t)slot * P + t];
+                    else gv[q8] = gp[(size_t)k * P + t];
+                }
+#pragma unroll
+                for (int q8 = 0; q8 < 8; q8++) rhs = fma(-(double)gv[q8], dl[q8], rhs);
             }
         }
         ev_prev = ev_now;
+        if (s < 24) HB_STAMP(2 + s);
     }
+    HB_STAMP(26);
 
     // ---- write back ----
     if (!active) { cls_f = 0; g_f = 0.0; }
@@ -460,25 +554,31 @@ __global__ __launch_bounds__(1024) void k_chain(const hb_sweep_in *__restrict__ 
     // :791 sum g^2/fold[class] (R); class counts exclude monomorphic markers
     double w = 0.0;
     if (cls_f > 0) w = (model == 6) ? g_f * g_f / pin->fold[cls_f] : g_f * g_f;
-    const double wsum = block_sum(w, red);
-    if (active) atomicAdd(&cnts[1 + cls_f], 1);
-    __syncthreads();
     const int nev = cnts[0];
+#pragma unroll
+    for (int c = 0; c <= K1; c++) {
+        const unsigned long long mk = __ballot(active && cls_f == c);
+        if (lane == 0 && mk) atomicAdd(&cnts[1 + c], __popcll(mk));
+    }
+    const double wsum = block_sum(w, red); // two barriers: also publishes the class counts
     for (int e = t; e < nev; e += P) {
-        v.ev_idx[(size_t)p * P + e] = ev_ix[e];
+        v.ev_idx[(size_t)p * P + e] = ev_ix[e] & 0xffff;
         v.ev_delta[(size_t)p * P + e] = ev_del[e];
     }
     if (t == 0) {
         v.ev_count[p] = nev;
-        v.acc[HB_ACC_SUMG2] += wsum;
-        v.acc[HB_ACC_EVENTS] += (double)nev;
-        for (int c = 0; c < HB_MAX_FOLD; c++) v.acc[HB_ACC_COUNT0 + c] += (double)cnts[1 + c];
+        atomicAdd(&v.acc[HB_ACC_SUMG2], wsum);
+        atomicAdd(&v.acc[HB_ACC_EVENTS], (double)nev);
     }
+    if (t >= 64 && t < 64 + HB_MAX_FOLD && t - 64 <= K1 && cnts[1 + t - 64])
+        atomicAdd(&v.acc[HB_ACC_COUNT0 + t - 64], (double)cnts[1 + t - 64]);
+    HB_STAMP(27);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_update: yadj -= sum_e x_e D_e, u += the same, r32 = (float)yadj, for the panel's changed markers
-// thread = 4 consecutive rows
+// k_update: yadj -= sum_e x_e D_e, u += the same, r32 = (float)yadj, for the panel's changed markers.
+// thread = 4 consecutive rows; the event list is staged in LDS once, then the column loads of 8
+// events are in flight together.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_update(const int8_t *__restrict__ X, int64_t ld, int P, int p,
                                                 const int32_t *__restrict__ ev_count,
@@ -487,38 +587,45 @@ __global__ __launch_bounds__(256) void k_update(const int8_t *__restrict__ X, in
                                                 double *__restrict__ r, double *__restrict__ u,
                                                 float *__restrict__ r32)
 {
+    __shared__ int s_ix[512];
+    __shared__ double s_dl[512];
     const int nev = ev_count[p];
     if (nev == 0) return;
+    for (int e = threadIdx.x; e < nev; e += blockDim.x) {
+        s_ix[e] = ev_idx[(size_t)p * P + e];
+        s_dl[e] = ev_delta[(size_t)p * P + e];
+    }
+    __syncthreads();
     const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (row0 >= ld) return;
     const int8_t *xp = X + (int64_t)p * P * ld + row0;
-    const int32_t *ix = ev_idx + (size_t)p * P;
-    const double *dl = ev_delta + (size_t)p * P;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int e = 0;
-    for (; e + 4 <= nev; e += 4) {
-        int w[4];
-        double d[4];
+    for (; e + 16 <= nev; e += 16) {
+        int w[16];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            w[q] = *reinterpret_cast<const int *>(xp + (int64_t)ix[e + q] * ld);
-            d[q] = dl[e + q];
-        }
+        for (int q = 0; q < 16; q++) w[q] = *reinterpret_cast<const int *>(xp + (int64_t)s_ix[e + q] * ld);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            a0 = fma((double)(int8_t)(w[q]), d[q], a0);
-            a1 = fma((double)(int8_t)(w[q] >> 8), d[q], a1);
-            a2 = fma((double)(int8_t)(w[q] >> 16), d[q], a2);
-            a3 = fma((double)(int8_t)(w[q] >> 24), d[q], a3);
+        for (int q = 0; q < 16; q++) {
+            const double d = s_dl[e + q];
+            a0 = fma((double)(int8_t)(w[q]), d, a0);
+            a1 = fma((double)(int8_t)(w[q] >> 8), d, a1);
+            a2 = fma((double)(int8_t)(w[q] >> 16), d, a2);
+            a3 = fma((double)(int8_t)(w[q] >> 24), d, a3);
         }
     }
-    for (; e < nev; e++) {
-        const int w = *reinterpret_cast<const int *>(xp + (int64_t)ix[e] * ld);
-        const double d = dl[e];
-        a0 = fma((double)(int8_t)(w), d, a0);
-        a1 = fma((double)(int8_t)(w >> 8), d, a1);
-        a2 = fma((double)(int8_t)(w >> 16), d, a2);
-        a3 = fma((double)(int8_t)(w >> 24), d, a3);
+    if (e < nev) {
+        int w[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) w[q] = *reinterpret_cast<const int *>(xp + (int64_t)s_ix[min(e + q, nev - 1)] * ld);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const double d = (e + q < nev) ? s_dl[e + q] : 0.0;
+            a0 = fma((double)(int8_t)(w[q]), d, a0);
+            a1 = fma((double)(int8_t)(w[q] >> 8), d, a1);
+            a2 = fma((double)(int8_t)(w[q] >> 16), d, a2);
+            a3 = fma((double)(int8_t)(w[q] >> 24), d, a3);
+        }
     }
     double2 r01 = *reinterpret_cast<double2 *>(r + row0), r23 = *reinterpret_cast<double2 *>(r + row0 + 2);
     double2 u01 = *reinterpret_cast<double2 *>(u + row0), u23 = *reinterpret_cast<double2 *>(u + row0 + 2);
@@ -784,7 +891,9 @@ static inline int kpad_for(int model, int n_fold)
     return k1 <= 1 ? 1 : (k1 <= 3 ? 3 : 7);
 }
 
-static size_t chain_smem(int P) { return (size_t)(P / 64) * 16384 + (size_t)P * 12 + 128 + 64; }
+// LDS budget of k_chain: as many Gram rows as fit beside the event lists
+static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128 + 128)) / ((size_t)P * 4)); }
+static size_t chain_smem(int P) { return (size_t)chain_nslot(P) * P * 4 + (size_t)P * 16 + 128 + 128; }
 
 int hbk_init_attrs()
 {
@@ -798,7 +907,7 @@ template <int K1>
 static hipError_t launch_chain(hb_ctx *c, const chain_view &cv, int p)
 {
     const size_t smem = chain_smem(c->P);
-    hipLaunchKernelGGL(k_chain<K1>, dim3(1), dim3(c->P), smem, c->stream, c->d_in, cv, p);
+    hipLaunchKernelGGL(k_chain<K1>, dim3(1), dim3(c->P), smem, c->stream, c->d_in, cv, p, chain_nslot(c->P));
     return hipGetLastError();
 }
 
@@ -863,7 +972,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
     }
     chain_view cv{c->m_pad, c->P, c->nsplit, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
-                  c->wind, c->wflag};
+                  c->wind, c->wflag, c->dbg};
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
     for (int p = 0; p < c->npanels; p++) {
         hipEvent_t b = tm.begin();

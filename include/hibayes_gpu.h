@@ -55,6 +55,7 @@ int hb_device_count(void);
  * Return 0 on success.
  * ------------------------------------------------------------------------------------ */
 typedef int (*hb_allreduce_fn)(void *device_buf, size_t count, void *user);
+typedef struct hb_ctx hb_ctx; /* device context of one genotype shard, see the engine API below */
 /* called once per iteration from the calling thread; non-zero return stops the run
  * (the shim wires it to R_CheckUserInterrupt; the reference cannot be interrupted) */
 typedef int (*hb_interrupt_fn)(void *user);
@@ -119,6 +120,9 @@ typedef struct hb_bayes_args {
     void *interrupt_user;
     hb_log_fn log;
     void *log_user;
+    /* optional pre-loaded context: genotypes already resident on the device (then X_f64 and X_i8
+     * must be NULL and n, m must match). Lets one upload serve several model fits.            */
+    hb_ctx *ctx;
 } hb_bayes_args;
 
 /* number of doubles exchanged per sweep for n individuals */
@@ -163,13 +167,32 @@ typedef struct hb_bayes_out {
 /* The whole sampler: replaces Bayes() (reference src/Bayes.cpp:60-1094). */
 int hb_bayes_run(const hb_bayes_args *args, hb_bayes_out *out);
 
+/* The same sampler, stepwise: create (validation, upload, marker statistics, Gram, priors) ->
+ * step (iterations of the loop at src/Bayes.cpp:477) -> finish (posterior assembly, :919-1040).
+ * hb_bayes_run() is exactly create + step-until-finished + finish. The caller's arrays are copied
+ * at create time. */
+typedef struct hb_run hb_run;
+typedef struct hb_run_info {
+    int32_t iter;            /* iterations done */
+    int32_t records;         /* thinned records stored */
+    double nnz;              /* NumNZSnp of the last sweep */
+    double vara, vare, varg, mu;
+    double pi[HB_MAX_FOLD];
+    double mean_events;      /* mean markers changed per sweep so far */
+    double loop_seconds, setup_seconds, gram_seconds;
+} hb_run_info;
+int hb_run_create(const hb_bayes_args *args, hb_run **out);
+int hb_run_step(hb_run *r, int32_t nsteps, int32_t *finished);
+int hb_run_state(hb_run *r, hb_run_info *info);
+hb_ctx *hb_run_ctx(hb_run *r);
+int hb_run_finish(hb_run *r, hb_bayes_out *out);
+void hb_run_destroy(hb_run *r);
+
 /* ====================================================================================
  * Fine-grained engine API.  hb_bayes_run() is built on it; the parity tests and bench.py
  * drive the device pieces through it one at a time.  A context owns all device state of
  * one genotype shard; calls on one context must be serialised by the caller.
  * ==================================================================================== */
-typedef struct hb_ctx hb_ctx;
-
 typedef struct hb_ctx_params {
     int32_t device;
     int32_t n, m;            /* individuals, local markers */
@@ -214,6 +237,9 @@ int hb_ctx_set_effects(hb_ctx *c, const double *g, const uint8_t *tracker, const
 int hb_ctx_get_effects(hb_ctx *c, double *g, uint8_t *tracker, double *vargL);
 /* d[j] = x_j . yadj for ncols columns from col0 — the panel mat-vec kernel on its own */
 int hb_ctx_dot(hb_ctx *c, int32_t col0, int32_t ncols, double *d);
+
+/* out (n) = X * alpha (m): the product behind e = y - ... - X*alpha, reference src/Bayes.cpp:971 */
+int hb_ctx_matvec(hb_ctx *c, const double *alpha, double *out);
 
 /* helpers for the host blocks that share yadj (reference src/Bayes.cpp:479-516) */
 int hb_ctx_residual_sums(hb_ctx *c, double *sum_r, double *sum_r2);

@@ -44,7 +44,7 @@ for model, Pi, fold in [("BayesCpi", [0.95, 0.05], None), ("BayesC", [0.9, 0.1],
     kw = dict(model=model, Pi=Pi, fold=fold, niter=12, nburn=4, thin=2, seed=99)
     t0 = time.time()
     try:
-        got = H.Bayes(y, X, verbose=False, precise=True, panel=256, **kw)
+        got = H.Bayes(y, X, verbose=False, precise=True, **kw)
     except Exception as e:
         print(model, "FAILED", e); continue
     t1 = time.time()
