@@ -570,8 +570,7 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
         atomicAdd(&v.acc[HB_ACC_SUMG2], wsum);
         atomicAdd(&v.acc[HB_ACC_EVENTS], (double)nev);
     }
-    if (t >= 64 && t < 64 + HB_MAX_FOLD && t - 64 <= K1 && cnts[1 + t - 64])
-        atomicAdd(&v.acc[HB_ACC_COUNT0 + t - 64], (double)cnts[1 + t - 64]);
+    if (t <= K1 && t < HB_MAX_FOLD && cnts[1 + t]) atomicAdd(&v.acc[HB_ACC_COUNT0 + t], (double)cnts[1 + t]);
     HB_STAMP(27);
 }
 

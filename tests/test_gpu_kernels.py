@@ -1,0 +1,164 @@
+"""Kernel-level parity on the MI355X, through the C ABI (hb_ctx_*): integer-exact pieces must match
+bit for bit, floating-point pieces within the stated tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+import hibayes_amd as H
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_geno(rng, n, m, signed=False):
+    p = rng.uniform(0.05, 0.5, m)
+    X = (rng.random((n, m)) < p).astype(np.int8) + (rng.random((n, m)) < p).astype(np.int8)
+    if signed:
+        X = X - 1
+    return np.asfortranarray(X.astype(np.int8))
+
+
+@pytest.mark.parametrize("n,m,panel", [(300, 1000, 0), (1000, 777, 64), (4097, 130, 128), (257, 2049, 512)])
+def test_marker_stats_exact(n, m, panel):
+    rng = np.random.default_rng(n + m)
+    X = rand_geno(rng, n, m)
+    X[:, 5] = 1
+    X[:, m - 1] = 0
+    with H.Context(n, m, panel=panel) as c:
+        c.upload(X)
+        assert np.array_equal(c.download(), X)
+        xpx, vx, sumvx, nvar0 = c.marker_stats()
+    Xd = X.astype(np.float64)
+    assert np.array_equal(xpx, (Xd ** 2).sum(0))              # integer-exact
+    np.testing.assert_allclose(vx, Xd.var(0, ddof=1), rtol=1e-13, atol=0)
+    assert vx[5] == 0 and vx[m - 1] == 0 and nvar0 == int((Xd.var(0) == 0).sum())
+    assert sumvx == pytest.approx(vx.sum(), rel=1e-13)
+
+
+def test_marker_stats_on_demo_match_reference_facts(demo):
+    with H.Context(300, 1000) as c:
+        c.upload(demo["M"])
+        xpx, vx, sumvx, nvar0 = c.marker_stats()
+    assert xpx[:5].tolist() == [483, 101, 209, 464, 65] and nvar0 == 50
+    assert sumvx == pytest.approx(294.93311036789305, rel=1e-13)
+
+
+@pytest.mark.parametrize("panel", [64, 128, 256, 512])
+def test_gram_blocks_exact(panel):
+    rng = np.random.default_rng(panel)
+    n, m = 1111, 3 * panel + 17
+    X = rand_geno(rng, n, m, signed=(panel == 128))
+    with H.Context(n, m, panel=panel) as c:
+        c.upload(X)
+        c.build_gram()
+        for p in range((m + panel - 1) // panel):
+            cols = X[:, p * panel:(p + 1) * panel].astype(np.int64)
+            G = c.gram(p)
+            k = cols.shape[1]
+            assert np.array_equal(G[:k, :k], cols.T @ cols)      # int32, exact; asymmetric off-diagonal tiles
+            assert not G[k:, :].any() and not G[:, k:].any()      # zero padding
+
+
+@pytest.mark.parametrize("signed", [False, True])
+def test_panel_matvec_against_fp64(signed):
+    rng = np.random.default_rng(3)
+    n, m = 5000, 1300
+    X = rand_geno(rng, n, m, signed=signed)
+    r = rng.normal(0, 2.0, n)
+    ref = X.astype(np.float64).T @ r
+    scale = np.sqrt((X.astype(np.float64) ** 2).sum(0) * r.var()) + 1e-9   # natural scale of x_j . r
+    with H.Context(n, m, precise=True) as c:
+        c.upload(X)
+        c.set_residual(r, np.zeros(n))
+        d = c.dot()
+    assert np.max(np.abs(d - ref) / scale) < 1e-13                      # fp64 accumulation
+    with H.Context(n, m, precise=False) as c:
+        c.upload(X)
+        c.set_residual(r, np.zeros(n))
+        d = c.dot()
+    assert np.max(np.abs(d - ref) / scale) < 2e-6                       # fp32 accumulation: stated tolerance
+
+
+def test_matvec_and_residual_helpers():
+    rng = np.random.default_rng(4)
+    n, m = 2000, 900
+    X = rand_geno(rng, n, m)
+    a = np.zeros(m)
+    a[rng.choice(m, 40, replace=False)] = rng.normal(size=40)
+    out = np.zeros(n)
+    with H.Context(n, m) as c:
+        c.upload(X)
+        H._lib.check(c.L.hb_ctx_matvec(c.h, a.ctypes.data, out.ctypes.data))
+        np.testing.assert_allclose(out, X.astype(float) @ a, rtol=1e-12, atol=1e-12)
+        r = rng.normal(size=n)
+        c.set_residual(r, np.zeros(n))
+        s1, s2 = c.residual_sums()
+        assert s1 == pytest.approx(r.sum(), abs=1e-9) and s2 == pytest.approx((r * r).sum(), rel=1e-12)
+        c.residual_shift(0.25)
+        Cm = rng.normal(size=(n, 2))
+        c.set_covariates(Cm)
+        assert c.cov_dot(1) == pytest.approx(Cm[:, 1] @ (r + 0.25), rel=1e-12)
+        c.cov_axpy(0, -0.5)
+        zid = rng.integers(0, 7, size=(n, 1))
+        c.set_levels(zid, [7])
+        cur = r + 0.25 - 0.5 * Cm[:, 0]
+        np.testing.assert_allclose(c.level_sums(0), np.bincount(zid[:, 0], weights=cur, minlength=7), rtol=1e-11)
+        delta = rng.normal(size=7)
+        c.level_axpy(0, delta)
+        got, _ = c.get_residual()
+        np.testing.assert_allclose(got, cur + delta[zid[:, 0]], rtol=1e-13, atol=1e-13)
+
+
+def test_bed_decode_on_device_matches_golden(demo):
+    raw = open(demo["prefix"] + ".bed", "rb").read()
+    with H.Context(300, 1000) as c:
+        c.upload_bed(raw, 600, rows=demo["rows"])
+        assert np.array_equal(c.download(), demo["M"])
+    with H.Context(600, 1000) as c:
+        c.upload_bed(raw, 600)
+        g = c.download()
+    assert g[:4, :5].tolist() == [[2, 1, 1, 1, 0], [1, 0, 1, 1, 0], [0, 2, 0, 0, 0], [1, 1, 1, 1, 0]]  # README.md:81-86
+    # ragged individuals + missing calls + imputation from the counts over ALL individuals
+    rng = np.random.default_rng(8)
+    nind, nsnp = 1003, 60
+    body = rng.integers(0, 256, size=nsnp * ((nind + 3) // 4), dtype=np.uint8)
+    img = bytes([0x6C, 0x1B, 0x01]) + body.tobytes()
+    ref = O.decode_bed(img, nind, nsnp, impute=True)
+    rows = rng.permutation(nind)[:400]
+    with H.Context(400, nsnp) as c:
+        c.upload_bed(img, nind, rows=rows)
+        assert np.array_equal(c.download(), ref[rows, :])
+    with pytest.raises(H.HibayesError):
+        with H.Context(400, nsnp) as c:
+            c.upload_bed(b"\x00\x01\x02" + body.tobytes(), nind, rows=rows)
+
+
+def test_f64_upload_checks_integrality():
+    n, m = 64, 70
+    X = np.random.default_rng(1).integers(0, 3, size=(n, m)).astype(np.float64)
+    with H.Context(n, m) as c:
+        c.upload(X)
+        assert np.array_equal(c.download(), X.astype(np.int8))
+        X[5, 9] = 0.5   # an imputed fractional genotype (ssbrm) must be refused, never rounded
+        with pytest.raises(H.HibayesError) as ei:
+            c.upload(X)
+        assert ei.value.status == 4
+
+
+def test_synthetic_generator_is_the_documented_philox_stream():
+    n, m, seed = 101, 9, 20240901
+    with H.Context(n, m, m_offset=1000) as c:
+        c.generate(seed, mono_every=4)
+        X = c.download()
+    for j in range(m):
+        gj = 1000 + j
+        sub = (3 << 56) | gj
+        pj = 0.05 + 0.45 * O.lib().hbo_philox_uniform(seed, sub, 0xFFFFFFFFFF)
+        thr = int(pj * 65536.0)
+        for i in range(n):
+            w = int(O.philox_block(seed, sub, i // 4)[i % 4])
+            x = int((w & 0xFFFF) < thr) + int((w >> 16) < thr)
+            if gj % 4 == 3:
+                x = 0
+            assert X[i, j] == x

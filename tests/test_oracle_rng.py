@@ -1,0 +1,68 @@
+"""Pins of the oracle's RNG layer (oracle/hbo_rng.c) against published third-party outputs."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def test_r_set_seed_runif_known_values():
+    # R: set.seed(1); runif(3)  ->  0.2655087 0.3721239 0.5728534   (R documentation examples, any R >= 1.7)
+    mt = O.MT(1)
+    assert [round(mt.unif(), 7) for _ in range(3)] == [0.2655087, 0.3721239, 0.5728534]
+    # R: set.seed(42); runif(1) -> 0.914806
+    assert round(O.MT(42).unif(), 6) == 0.914806
+
+
+def test_r_inversion_rnorm_known_values():
+    # R: set.seed(123); rnorm(5)
+    mt = O.MT(123)
+    got = [round(mt.norm(), 8) for _ in range(5)]
+    assert got == [-0.56047565, -0.23017749, 1.55870831, 0.07050839, 0.12928774]
+    # R: set.seed(1); rnorm(1) -> -0.6264538
+    assert round(O.MT(1).norm(), 7) == -0.6264538
+
+
+def test_qnorm_as241_against_scipy():
+    from scipy.special import ndtri
+    p = np.concatenate([np.linspace(1e-12, 1 - 1e-12, 4001), 10.0 ** -np.arange(1, 300, 11.0)])
+    q = np.array([O.lib().hbo_qnorm(float(x)) for x in p])
+    r = ndtri(p)
+    assert np.max(np.abs(q - r) / np.maximum(np.abs(r), 1e-300)) < 5e-15
+
+
+def test_philox4x32_10_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds (Salmon et al., SC'11)
+    assert [hex(x) for x in O.philox([0, 0, 0, 0], [0, 0])] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])] == \
+        ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    assert [hex(x) for x in O.philox([0xffffffff] * 4, [0xffffffff] * 2)] == \
+        ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+def test_philox_block_addressing_matches_rocrand_layout():
+    # rocrand_init(seed, subsequence, offset = 4*blk): counter = {blk_lo, blk_hi, sub_lo, sub_hi}, key = seed
+    seed, sub, blk = 0x299f31d0a4093822, 0x0370734413198a2e, 0x85a308d3243f6a88
+    assert np.array_equal(O.philox_block(seed, sub, blk),
+                          O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]))
+
+
+def test_u53_is_open_interval_and_uniform():
+    u = np.array([O.lib().hbo_philox_uniform(7, 1 << 56, b) for b in range(20000)])
+    assert u.min() > 0 and u.max() < 1
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+    z = np.array([O.lib().hbo_philox_normal(7, 1 << 56, b) for b in range(20000)])
+    assert abs(z.mean()) < 0.03 and abs(z.var() - 1) < 0.05
+
+
+@pytest.mark.parametrize("kind", [O.RNG_R, O.RNG_PHILOX])
+def test_gamma_chisq_invgauss_moments(kind):
+    s = O.Stream(kind, 12345, sub=2 << 56)
+    for shape in (0.5, 2.5, 40.0):
+        x = np.array([s.gamma(shape, 2.0) for _ in range(20000)])
+        assert abs(x.mean() / (2 * shape) - 1) < 0.04
+        assert abs(x.var() / (4 * shape) - 1) < 0.12
+    c = np.array([s.chisq(7.0) for _ in range(20000)])
+    assert abs(c.mean() - 7) < 0.15
+    ig = np.array([s.invgauss(1.5, 4.0) for _ in range(20000)])
+    assert abs(ig.mean() - 1.5) < 0.05  # E = mu, Var = mu^3/lambda
+    assert abs(ig.var() / (1.5 ** 3 / 4.0) - 1) < 0.15
