@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 // launch wrappers implemented in hb_kernels.hip
 int hbk_init_attrs();
@@ -91,6 +92,9 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     c->seed = p->seed;
     c->nchunks = (int)((c->ld + 4095) / 4096);
     c->nsplit = c->nchunks;
+    c->L = 0; // look-ahead pays only once the chain is off the critical path; see DESIGN.md
+    if (const char *e = getenv("HB_LOOKAHEAD")) c->L = std::max(0, std::min(3, atoi(e)));
+    c->NB = c->L + 1;
     int rc = HB_OK;
 #define TRY(x)                   \
     do {                         \
@@ -106,6 +110,22 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
             delete c;
             return hb_fail(HB_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         }
+        if (hipStreamCreateWithFlags(&c->s_chain, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->s_upd, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) {
+            hb_ctx_destroy(c);
+            return hb_fail(HB_ERR_HIP, "hipStreamCreate failed");
+        }
+        c->ev_dot.resize(c->npanels);
+        c->ev_chain.resize(c->npanels);
+        c->ev_upd.resize(c->npanels);
+        for (int p = 0; p < c->npanels; p++)
+            if (hipEventCreateWithFlags(&c->ev_dot[p], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_chain[p], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_upd[p], hipEventDisableTiming) != hipSuccess) {
+                hb_ctx_destroy(c);
+                return hb_fail(HB_ERR_HIP, "hipEventCreate failed");
+            }
     }
     TRY(hbk_init_attrs());
     const size_t mp = (size_t)c->m_pad;
@@ -118,10 +138,10 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->alpha_sq, mp));
     TRY(dev_alloc(&c->tracker, mp));
     TRY(dev_alloc(&c->nzrate, mp));
-    TRY(dev_alloc(&c->r, (size_t)c->ld));
+    TRY(dev_alloc(&c->r, (size_t)c->ld * c->NB));      // NB versions; slot 0 is the residual between sweeps
     TRY(dev_alloc(&c->u, (size_t)c->ld));
-    TRY(dev_alloc(&c->r32, (size_t)c->ld));
-    TRY(dev_alloc(&c->gram, mp * (size_t)P));
+    TRY(dev_alloc(&c->r32, (size_t)c->ld * c->NB));
+    TRY(dev_alloc(&c->gram, mp * (size_t)P * (c->L + 1)));
     TRY(dev_alloc(&c->xinfo, 2));
     TRY(dev_alloc(&c->thr, mp * (HB_MAX_FOLD - 1)));
     TRY(dev_alloc(&c->invv, mp * (HB_MAX_FOLD - 1)));
@@ -155,6 +175,12 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : c->ev_dot) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev_chain) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev_upd) if (e) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
+    if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
     void *ptrs[] = {c->X, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dots, c->ev_count, c->ev_idx,
                     c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
@@ -338,7 +364,7 @@ int hb_ctx_download_gram(hb_ctx *c, int32_t panel_index, int32_t *G)
     if (rc) return rc;
     if (!c->gram_ready) return hb_fail(HB_ERR_INVALID, "hb_ctx_download_gram: call hb_ctx_build_gram first");
     if (panel_index < 0 || panel_index >= c->npanels) return hb_fail(HB_ERR_INVALID, "hb_ctx_download_gram: bad panel");
-    HB_HIP(hipMemcpy(G, c->gram + (size_t)panel_index * c->P * c->P, sizeof(int32_t) * c->P * c->P, hipMemcpyDeviceToHost));
+    HB_HIP(hipMemcpy(G, c->gram + (size_t)panel_index * (c->L + 1) * c->P * c->P, sizeof(int32_t) * c->P * c->P, hipMemcpyDeviceToHost));
     return HB_OK;
 }
 

@@ -11,15 +11,20 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(64) void k_gram(const int8_t *__restrict__ X, int64_t ld, int P,
+// Band layout: gram[(p * (L+1) + l) * P*P + row * P + col] = x_{(p-l)P + row} . x_{pP + col}, l = 0..L
+// (l = 0: the panel's own Gram; l >= 1: the panels the look-ahead pipeline has not yet folded into
+// the residual when panel p's mat-vec runs).
+__global__ __launch_bounds__(64) void k_gram(const int8_t *__restrict__ X, int64_t ld, int P, int L,
                                              int32_t *__restrict__ gram)
 {
     const int nb = P >> 6;                   // 64-blocks per panel side
-    const int p = blockIdx.x / (nb * nb);
+    const int pl = blockIdx.x / (nb * nb);
+    const int p = pl / (L + 1), l = pl % (L + 1);
+    if (p - l < 0) return;
     const int rem = blockIdx.x % (nb * nb);
     const int bi = rem / nb, bj = rem % nb;
     const int lane = threadIdx.x;
-    const int8_t *xa = X + ((int64_t)p * P + bi * 64 + (lane & 31)) * ld + 16 * (lane >> 5);
+    const int8_t *xa = X + ((int64_t)(p - l) * P + bi * 64 + (lane & 31)) * ld + 16 * (lane >> 5);
     const int8_t *xb = X + ((int64_t)p * P + bj * 64 + (lane & 31)) * ld + 16 * (lane >> 5);
     v16i acc[2][2];
 #pragma unroll
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(64) void k_gram(const int8_t *__restrict__ X, int64
         acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    int32_t *gp = gram + (size_t)p * P * P;
+    int32_t *gp = gram + (size_t)pl * P * P;
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -55,7 +60,8 @@ __global__ __launch_bounds__(64) void k_gram(const int8_t *__restrict__ X, int64
 int hb_build_gram_impl(hb_ctx *c)
 {
     const int nb = c->P / 64;
-    hipLaunchKernelGGL(k_gram, dim3((unsigned)(c->npanels * nb * nb)), dim3(64), 0, c->stream, c->X, c->ld, c->P, c->gram);
+    hipLaunchKernelGGL(k_gram, dim3((unsigned)(c->npanels * (c->L + 1) * nb * nb)), dim3(64), 0, c->stream, c->X, c->ld, c->P,
+                       c->L, c->gram);
     HB_HIP(hipGetLastError());
     return HB_OK;
 }

@@ -32,11 +32,17 @@ enum {
 struct hb_ctx {
     int device = 0;
     int n = 0, m = 0, P = 0, npanels = 0, m_pad = 0;
+    int L = 2;  // look-ahead in panels: the mat-vec of panel p sees the residual with panels <= p-L-1 applied
+    int NB = 3; // residual versions kept = L + 1
     int64_t ld = 0; // bytes per genotype column on device (multiple of 256)
     int precise = 0;
     int64_t m_offset = 0;
     uint64_t seed = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // mat-vec stream (and everything outside the sweep)
+    hipStream_t s_chain = nullptr;     // serial chain kernels
+    hipStream_t s_upd = nullptr;       // residual updates
+    std::vector<hipEvent_t> ev_dot, ev_chain, ev_upd; // cross-stream dependencies of one sweep
+    hipEvent_t ev_fork = nullptr;
 
     int8_t *X = nullptr;
     double *xpx = nullptr, *vx = nullptr, *g = nullptr, *vargL = nullptr;

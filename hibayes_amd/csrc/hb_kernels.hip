@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_pre(const hb_sweep_in *__restrict__ pin
 // k_chain: one workgroup of P threads (thread = marker of the panel, wave = 64-marker sub-block).
 // ---------------------------------------------------------------------------------------------
 struct chain_view {
-    int m_pad, P, nsplit;
+    int m_pad, P, nsplit, L;
     const double *xpx, *vx;
     double *g;
     uint8_t *tracker;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
     int *wcnt = cnts + 16;
 
     const int j = p * P + t;
-    const int32_t *gp = v.gram + (size_t)p * P * P;
+    const int32_t *gp = v.gram + (size_t)p * (v.L + 1) * P * P; // l = 0: this panel's own Gram block
     HB_STAMP(0);
 
     // ---- issue every per-marker load up front (one memory latency for all of them) ----
@@ -448,6 +448,28 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
     for (int sp = 16; sp < v.nsplit; sp++) rhs += v.partial[(size_t)sp * v.m_pad + j];
     // :594/:616/:725 add xx*oldgi always, :639/:682/:757 only when oldgi != 0 — identical values
     if (gold != 0.0) rhs = fma(xx, gold, rhs);
+    // Look-ahead: this panel's mat-vec ran against the residual without the moves of the previous L panels.
+    // Fold them in with the band Gram blocks  G_l[k][t] = x_{(p-l)P+k} . x_{pP+t}:  rhs_t -= G_l[k][t] D_k.
+    for (int l = 1; l <= v.L; l++) {
+        const int bp = p - l;
+        if (bp < 0) break;
+        const int nevp = v.ev_count[bp];
+        const int32_t *gx = gp + (size_t)l * P * P;
+        const int32_t *eix = v.ev_idx + (size_t)bp * P;
+        const double *edl = v.ev_delta + (size_t)bp * P;
+        for (int e0 = 0; e0 < nevp; e0 += 8) {
+            int gv[8];
+            double dl[8];
+#pragma unroll
+            for (int q8 = 0; q8 < 8; q8++) {
+                const int e = min(e0 + q8, nevp - 1);
+                gv[q8] = gx[(size_t)eix[e] * P + t];
+                dl[q8] = (e0 + q8 < nevp) ? edl[e] : 0.0;
+            }
+#pragma unroll
+            for (int q8 = 0; q8 < 8; q8++) rhs = fma(-(double)gv[q8], dl[q8], rhs);
+        }
+    }
     int cls_f = 0;
     double g_f = 0.0;
     __syncthreads();
@@ -583,13 +605,25 @@ __global__ __launch_bounds__(256) void k_update(const int8_t *__restrict__ X, in
                                                 const int32_t *__restrict__ ev_count,
                                                 const int32_t *__restrict__ ev_idx,
                                                 const double *__restrict__ ev_delta,
-                                                double *__restrict__ r, double *__restrict__ u,
-                                                float *__restrict__ r32)
+                                                const double *__restrict__ r_in, double *__restrict__ r,
+                                                double *__restrict__ u, float *__restrict__ r32)
 {
+    // r_in -> r: version p-1 -> version p of the residual (distinct buffers under look-ahead)
     __shared__ int s_ix[512];
     __shared__ double s_dl[512];
     const int nev = ev_count[p];
-    if (nev == 0) return;
+    if (nev == 0) {
+        if (r_in != r) { // nothing moved: the new version is a copy
+            const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+            if (row0 < ld) {
+                const double2 a = *reinterpret_cast<const double2 *>(r_in + row0), b = *reinterpret_cast<const double2 *>(r_in + row0 + 2);
+                *reinterpret_cast<double2 *>(r + row0) = a;
+                *reinterpret_cast<double2 *>(r + row0 + 2) = b;
+                *reinterpret_cast<float4 *>(r32 + row0) = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < nev; e += blockDim.x) {
         s_ix[e] = ev_idx[(size_t)p * P + e];
         s_dl[e] = ev_delta[(size_t)p * P + e];
@@ -626,7 +660,7 @@ __global__ __launch_bounds__(256) void k_update(const int8_t *__restrict__ X, in
             a3 = fma((double)(int8_t)(w[q] >> 24), d, a3);
         }
     }
-    double2 r01 = *reinterpret_cast<double2 *>(r + row0), r23 = *reinterpret_cast<double2 *>(r + row0 + 2);
+    double2 r01 = *reinterpret_cast<const double2 *>(r_in + row0), r23 = *reinterpret_cast<const double2 *>(r_in + row0 + 2);
     double2 u01 = *reinterpret_cast<double2 *>(u + row0), u23 = *reinterpret_cast<double2 *>(u + row0 + 2);
     r01.x -= a0; r01.y -= a1; r23.x -= a2; r23.y -= a3;
     u01.x += a0; u01.y += a1; u23.x += a2; u23.y += a3;
@@ -903,25 +937,31 @@ int hbk_init_attrs()
 }
 
 template <int K1>
-static hipError_t launch_chain(hb_ctx *c, const chain_view &cv, int p)
+static hipError_t launch_chain(hb_ctx *c, const chain_view &cv, int p, hipStream_t st)
 {
     const size_t smem = chain_smem(c->P);
-    hipLaunchKernelGGL(k_chain<K1>, dim3(1), dim3(c->P), smem, c->stream, c->d_in, cv, p, chain_nslot(c->P));
+    hipLaunchKernelGGL(k_chain<K1>, dim3(1), dim3(c->P), smem, st, c->d_in, cv, p, chain_nslot(c->P));
     return hipGetLastError();
 }
 
-static void launch_dot(hb_ctx *c, int col0, int ncols)
+// residual version v (moves of panels <= v applied; v = -1: start of the sweep) lives in slot (v+1) mod NB
+static inline int ver_slot(const hb_ctx *c, int v) { return (v + 1) % c->NB; }
+
+static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr)
 {
+    if (!st) st = c->stream;
     const dim3 grid(ncols / 8, c->nsplit), block(256);
     const int8_t *Xp = c->X + (int64_t)col0 * c->ld;
     double *part = c->partial + col0;
+    const float *r32 = c->r32 + (size_t)slot * c->ld;
+    const double *r64 = c->r + (size_t)slot * c->ld;
     const bool sgn = c->xmin < 0;
     if (c->precise) {
-        if (sgn) hipLaunchKernelGGL((k_dot<true, true>), grid, block, 0, c->stream, Xp, c->ld, c->r32, c->r, c->nchunks, 1, part, c->m_pad);
-        else     hipLaunchKernelGGL((k_dot<true, false>), grid, block, 0, c->stream, Xp, c->ld, c->r32, c->r, c->nchunks, 1, part, c->m_pad);
+        if (sgn) hipLaunchKernelGGL((k_dot<true, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad);
+        else     hipLaunchKernelGGL((k_dot<true, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad);
     } else {
-        if (sgn) hipLaunchKernelGGL((k_dot<false, true>), grid, block, 0, c->stream, Xp, c->ld, c->r32, c->r, c->nchunks, 1, part, c->m_pad);
-        else     hipLaunchKernelGGL((k_dot<false, false>), grid, block, 0, c->stream, Xp, c->ld, c->r32, c->r, c->nchunks, 1, part, c->m_pad);
+        if (sgn) hipLaunchKernelGGL((k_dot<false, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad);
+        else     hipLaunchKernelGGL((k_dot<false, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad);
     }
 }
 
@@ -956,44 +996,85 @@ struct phase_timer {
     }
 };
 
-// enqueue one whole sweep on c->stream (parameters already in c->d_in)
+// Enqueue one whole sweep (parameters already in c->d_in).
+//
+// Pipeline (look-ahead L panels).  Three streams; panel p's kernels and their dependencies:
+//   A  mat-vec(p)   reads residual version p-L-1                 after update(p-L-1)
+//   B  chain(p)     folds in the moves of panels p-L..p-1        after mat-vec(p) and chain(p-1)
+//   C  update(p)    residual version p-1 -> p                     after chain(p) and update(p-1)
+// so the serial chain of panel p runs while the mat-vecs of the next panels stream from HBM.  Version v
+// of the residual lives in slot (v+1) mod (L+1); update(p) overwrites the slot mat-vec(p) has just read.
+// `timed` serialises everything on stream A with HIP events around each kernel (same kernels, same results).
 static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
 {
     phase_timer tm(c, timed);
     const int kp = kpad_for(model, n_fold);
-    HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, c->stream));
+    const int L = c->L, np = c->npanels;
+    hipStream_t sA = c->stream, sB = timed ? c->stream : c->s_chain, sC = timed ? c->stream : c->s_upd;
+    HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, sA));
     hipEvent_t t_all = tm.begin();
     {
         hipEvent_t b = tm.begin();
         pre_view pv{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
-        hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, c->stream, c->d_in, pv);
+        hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pv);
         tm.end(3, b);
     }
-    chain_view cv{c->m_pad, c->P, c->nsplit, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
+    if (!timed) { // fork the chain and update streams off stream A
+        HB_HIP(hipEventRecord(c->ev_fork, sA));
+        HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
+        HB_HIP(hipStreamWaitEvent(sC, c->ev_fork, 0));
+    }
+    chain_view cv{c->m_pad, c->P, c->nsplit, L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg};
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
-    for (int p = 0; p < c->npanels; p++) {
-        hipEvent_t b = tm.begin();
-        launch_dot(c, p * c->P, c->P);
-        tm.end(0, b);
-        b = tm.begin();
-        hipError_t e = kp == 1 ? launch_chain<1>(c, cv, p) : kp == 3 ? launch_chain<3>(c, cv, p) : launch_chain<7>(c, cv, p);
-        if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain launch: ") + hipGetErrorString(e));
-        tm.end(1, b);
-        b = tm.begin();
-        hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, c->stream, c->X, c->ld, c->P, p, c->ev_count,
-                           c->ev_idx, c->ev_delta, c->r, c->u, c->r32);
-        tm.end(2, b);
+    // software pipeline in issue order: mat-vec runs L panels ahead of chain/update in program order too,
+    // so that a plain in-order replay of the captured graph is still dependency-correct
+    for (int step = 0; step < np + L; step++) {
+        const int pd = step;     // panel whose mat-vec is issued now
+        const int pc = step - L; // panel whose chain + update are issued now
+        if (pd < np) {
+            hipEvent_t b = tm.begin();
+            const int vread = pd - L - 1;
+            if (!timed && vread >= 0) HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[vread], 0));
+            launch_dot(c, pd * c->P, c->P, ver_slot(c, vread < -1 ? -1 : vread), sA);
+            if (!timed) HB_HIP(hipEventRecord(c->ev_dot[pd], sA));
+            tm.end(0, b);
+        }
+        if (pc >= 0) {
+            hipEvent_t b = tm.begin();
+            if (!timed) HB_HIP(hipStreamWaitEvent(sB, c->ev_dot[pc], 0));
+            hipError_t e = kp == 1 ? launch_chain<1>(c, cv, pc, sB) : kp == 3 ? launch_chain<3>(c, cv, pc, sB) : launch_chain<7>(c, cv, pc, sB);
+            if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain launch: ") + hipGetErrorString(e));
+            if (!timed) HB_HIP(hipEventRecord(c->ev_chain[pc], sB));
+            tm.end(1, b);
+            b = tm.begin();
+            if (!timed) HB_HIP(hipStreamWaitEvent(sC, c->ev_chain[pc], 0));
+            const int sin = ver_slot(c, pc - 1), sout = ver_slot(c, pc);
+            hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sC, c->X, c->ld, c->P, pc, c->ev_count, c->ev_idx,
+                               c->ev_delta, c->r + (size_t)sin * c->ld, c->r + (size_t)sout * c->ld, c->u,
+                               c->r32 + (size_t)sout * c->ld);
+            if (!timed) HB_HIP(hipEventRecord(c->ev_upd[pc], sC));
+            tm.end(2, b);
+        }
+    }
+    if (!timed) { // join
+        HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[np - 1], 0));
+        HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[np - 1], 0));
     }
     {
         hipEvent_t b = tm.begin();
-        if (model == 5) {
-            hipLaunchKernelGGL(k_bayesl_post, dim3((c->m + 255) / 256), dim3(256), 0, c->stream, c->d_in, c->m,
-                               c->m_offset, c->seed, c->vx, c->g, c->vargL);
-            hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(1024), 0, c->stream, c->vargL, c->m, c->acc + HB_ACC_SUMVARGL);
+        const int sfin = ver_slot(c, np - 1);
+        if (sfin != 0) { // the residual between sweeps lives in slot 0
+            HB_HIP(hipMemcpyAsync(c->r, c->r + (size_t)sfin * c->ld, sizeof(double) * c->ld, hipMemcpyDeviceToDevice, sA));
+            HB_HIP(hipMemcpyAsync(c->r32, c->r32 + (size_t)sfin * c->ld, sizeof(float) * c->ld, hipMemcpyDeviceToDevice, sA));
         }
-        hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(1024), 0, c->stream, c->r, c->u, c->n, c->acc);
+        if (model == 5) {
+            hipLaunchKernelGGL(k_bayesl_post, dim3((c->m + 255) / 256), dim3(256), 0, sA, c->d_in, c->m,
+                               c->m_offset, c->seed, c->vx, c->g, c->vargL);
+            hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(1024), 0, sA, c->vargL, c->m, c->acc + HB_ACC_SUMVARGL);
+        }
+        hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(1024), 0, sA, c->r, c->u, c->n, c->acc);
         tm.end(3, b);
     }
     tm.end(4, t_all);
@@ -1026,7 +1107,7 @@ int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
         if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
         if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
         HB_HIP(hipStreamSynchronize(c->stream));
-        HB_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        HB_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
         int rc = enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
         hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
         if (rc) return rc;
