@@ -92,9 +92,19 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     c->seed = p->seed;
     c->nchunks = (int)((c->ld + 4095) / 4096);
     c->nsplit = c->nchunks;
-    c->L = 0; // look-ahead pays only once the chain is off the critical path; see DESIGN.md
-    if (const char *e = getenv("HB_LOOKAHEAD")) c->L = std::max(0, std::min(3, atoi(e)));
-    c->NB = c->L + 1;
+    // pipeline geometry: HB_PIPELINE=0 serial kernels, 1 persistent chain workgroup
+    c->pipeline = 1;
+    c->Lv = 2;
+    c->D = 1;
+    if (const char *e = getenv("HB_PIPELINE")) c->pipeline = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("HB_LOOKAHEAD")) c->Lv = std::max(0, std::min(6, atoi(e)));
+    if (const char *e = getenv("HB_DOTGROUP")) c->D = std::max(1, std::min(4, atoi(e)));
+    if (!c->pipeline && !getenv("HB_LOOKAHEAD")) c->Lv = 0;
+    if (!c->pipeline) c->D = 1;
+    // Lv counts mat-vec GROUPS of look-ahead; the Gram band then spans (Lv + 1) * D - 1 earlier panels
+    while ((c->Lv + 1) * c->D - 1 > 6) c->Lv--; // HB_LBMAX in hb_kernels.hip
+    c->L = std::max((c->Lv + 1) * c->D - 1, c->Lv);
+    c->NB = c->Lv + 1;
     int rc = HB_OK;
 #define TRY(x)                   \
     do {                         \
@@ -154,9 +164,14 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->acc, HB_ACC_N));
     TRY(dev_alloc(&c->d_in, 1));
     TRY(dev_alloc(&c->scratch, 8192));
+    TRY(dev_alloc(&c->flags, (size_t)4096));
+    TRY(dev_alloc(&c->hot_slot, mp));
+    TRY(dev_alloc(&c->hot_list, (size_t)c->npanels * 160));
+    TRY(dev_alloc(&c->hot_n, (size_t)c->npanels));
     {
         hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&c->h_acc), sizeof(double) * HB_ACC_N);
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_in), sizeof(hb_sweep_in));
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_flags), 64);
         if (e != hipSuccess) {
             hb_ctx_destroy(c);
             return hb_fail(HB_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
@@ -183,11 +198,12 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
     void *ptrs[] = {c->X, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dots, c->ev_count, c->ev_idx,
-                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
+                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_acc) (void)hipHostFree(c->h_acc);
     if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_flags) (void)hipHostFree(c->h_flags);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -453,7 +469,9 @@ int hb_ctx_matvec(hb_ctx *c, const double *alpha, double *out)
 static int fetch_acc(hb_ctx *c)
 {
     HB_HIP(hipMemcpyAsync(c->h_acc, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipMemcpyAsync(c->h_flags, c->flags, 16, hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
+    if (c->h_flags[1]) return hb_fail(HB_ERR_HIP, "device pipeline timed out waiting on a flag (sweep aborted)");
     return HB_OK;
 }
 

@@ -32,8 +32,14 @@ enum {
 struct hb_ctx {
     int device = 0;
     int n = 0, m = 0, P = 0, npanels = 0, m_pad = 0;
-    int L = 2;  // look-ahead in panels: the mat-vec of panel p sees the residual with panels <= p-L-1 applied
-    int NB = 3; // residual versions kept = L + 1
+    int L = 0;     // Gram band: blocks l = 0..L per panel (L = Lv + D - 1)
+    int Lv = 0;    // version lag: the mat-vec of group g reads the residual with panels <= g*D - Lv - 1 applied
+    int D = 1;     // panels per mat-vec launch
+    int NB = 1;    // residual versions kept = Lv + D
+    int pipeline = 0;              // 0: serial kernels per panel; 1: persistent chain workgroup + flags
+    unsigned int *flags = nullptr; // [0] chain_done, [1] abort, [2] spare, [4 + g] mat-vec tickets of group g
+    unsigned int *h_flags = nullptr;
+    int *hot_slot = nullptr, *hot_list = nullptr, *hot_n = nullptr; // per-sweep hot-lists (k_hotlist)
     int64_t ld = 0; // bytes per genotype column on device (multiple of 256)
     int precise = 0;
     int64_t m_offset = 0;

@@ -18,6 +18,64 @@
 
 #define HB_INF __builtin_huge_val()
 
+// ---- device-side flags of the persistent pipeline ----
+// Every shared word is accessed with relaxed agent-scope atomics (sc1); payloads are written with 4/8-byte
+// agent-scope atomic stores (write-through) and drained with s_waitcnt vmcnt(0) before the flag moves, so no
+// release fence is needed; consumers read the payload with agent-scope atomic loads (sc1), so no acquire
+// fence either (cdna_hip_programming.md §6 Guideline 16, forms R1 / "sc1 both sides").
+#define HB_FLAG_CHAIN_DONE 0
+#define HB_FLAG_ABORT 1
+#define HB_FLAG_TICKET0 64          /* 32 arrival counters, one per 256-byte line (64 words apart) */
+#define HB_NSUB 32
+#define HB_SUB_STRIDE 64
+#define HB_TIMEOUT_TICKS 300000000ull /* wall_clock64() runs at 100 MHz: 3 s */
+
+__device__ __forceinline__ unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_flag(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_sc1(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one lane waits until *word >= want; bounded; returns false when the run is being aborted
+__device__ __forceinline__ bool wait_ge(unsigned *flags, int word, unsigned want)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        if (ld_flag(flags + word) >= want) return true;
+        if (ld_flag(flags + HB_FLAG_ABORT)) return false;
+        if (wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
+            st_flag(flags + HB_FLAG_ABORT, 1u);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// lanes 0..31 of one wave wait until counter[lane] >= want[lane] for all of them; returns false on abort/timeout
+__device__ __forceinline__ bool wait_tickets(unsigned *flags, unsigned want)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned got = lane < HB_NSUB ? ld_flag(flags + HB_FLAG_TICKET0 + lane * HB_SUB_STRIDE) : 0xffffffffu;
+        if (__all(lane >= HB_NSUB || got >= want)) return true;
+        if (ld_flag(flags + HB_FLAG_ABORT)) return false;
+        if (wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
+            if (lane == 0) st_flag(flags + HB_FLAG_ABORT, 1u);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+// arrivals expected at sub-counter `lane` once mat-vec group g (0-based) has finished: groups complete in order
+__device__ __forceinline__ unsigned tickets_after_group(int g, int ngroups, unsigned total_full, unsigned total_last, int lane)
+{
+    const unsigned full = total_full / HB_NSUB + ((unsigned)lane < total_full % HB_NSUB ? 1u : 0u);
+    const unsigned last = total_last / HB_NSUB + ((unsigned)lane < total_last % HB_NSUB ? 1u : 0u);
+    return (g == ngroups - 1) ? (unsigned)(ngroups - 1) * full + last : (unsigned)(g + 1) * full;
+}
+
 // ---------------------------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------------------------
@@ -118,7 +176,7 @@ __global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64
                                              const float *__restrict__ r32,
                                              const double *__restrict__ r64, int nchunks,
                                              int chunks_per_split, double *__restrict__ partial,
-                                             int pstride)
+                                             int pstride, unsigned *__restrict__ ticket)
 {
     using acc_t = typename std::conditional<PRECISE, double, float>::type;
     __shared__ acc_t red[4][8];
@@ -173,7 +231,14 @@ __global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64
     __syncthreads();
     if (tid < 8) {
         const acc_t s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-        partial[(int64_t)sp * pstride + ct * 8 + tid] = (double)s;
+        st_sc1(&partial[(int64_t)sp * pstride + ct * 8 + tid], (double)s); // write-through: read by the chain workgroup
+    }
+    if (ticket && tid < 64) { // this wave made the stores: drain them, then count this workgroup in.
+        // A single arrival word would serialise ~12 ns per workgroup at its L2 channel (measured: it doubled the
+        // kernel time); 32 words on 32 different lines take the arrivals in parallel.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned id = blockIdx.x + blockIdx.y * gridDim.x;
+        if (tid == 0) __hip_atomic_fetch_add(ticket + (id % HB_NSUB) * HB_SUB_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -331,7 +396,7 @@ __global__ __launch_bounds__(256) void k_pre(const hb_sweep_in *__restrict__ pin
 // k_chain: one workgroup of P threads (thread = marker of the panel, wave = 64-marker sub-block).
 // ---------------------------------------------------------------------------------------------
 struct chain_view {
-    int m_pad, P, nsplit, L;
+    int m_pad, P, nsplit, L, Lb; // L: version lag of the serial pipeline; Lb: Gram band blocks per panel - 1
     const double *xpx, *vx;
     double *g;
     uint8_t *tracker;
@@ -378,7 +443,7 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
     int *wcnt = cnts + 16;
 
     const int j = p * P + t;
-    const int32_t *gp = v.gram + (size_t)p * (v.L + 1) * P * P; // l = 0: this panel's own Gram block
+    const int32_t *gp = v.gram + (size_t)p * (v.Lb + 1) * P * P; // l = 0: this panel's own Gram block
     HB_STAMP(0);
 
     // ---- issue every per-marker load up front (one memory latency for all of them) ----
@@ -597,78 +662,455 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_chain_persist: the same serial chain as k_chain, as ONE workgroup that lives for the whole sweep.
+// It walks the panels in order; panel p starts when the mat-vec group holding it has counted all its
+// workgroups into the ticket word, and ends by publishing the panel's moves (write-through) and
+// chain_done = p + 1, which the update kernel of panel p is waiting for.  Because the mat-vec of a later
+// panel q may have read a residual that does not contain panel p's moves yet (q's group read version
+// g(q) D - Lv - 1), each move is also folded forward into the per-thread correction registers corr[l]
+// of the next Lb panels through the band Gram blocks  G_l[q][k][t] = x_{pP+k} . x_{qP+t},  l = q - p.
+// ---------------------------------------------------------------------------------------------
+struct persist_view {
+    int npanels, D, Lv, Lb;
+    unsigned total_per_group; // mat-vec workgroups of a full group
+    unsigned total_last;      // ... of the last (possibly shorter) group
+    int ngroups;
+    unsigned *flags;
+    const int *slot_of, *hotlist, *nhot; // per-sweep hot-lists from k_hotlist
+};
+
+#define HB_LBMAX 6
+
+// hot-list of every panel (markers certain to move: polymorphic with g_old != 0), in marker order, capped at
+// nslot rows per panel; produced once per sweep, off the chain's critical path.  One workgroup per panel.
+__global__ __launch_bounds__(512) void k_hotlist(const double *__restrict__ vx, const double *__restrict__ g, int P, int nslot,
+                                                 int *__restrict__ slot_of, int *__restrict__ hotlist, int *__restrict__ nhot)
+{
+    __shared__ int wcnt[16];
+    const int p = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63, S = P >> 6;
+    const int j = p * P + t;
+    const bool hot = vx[j] != 0.0 && g[j] != 0.0;
+    const unsigned long long hmask = __ballot(hot);
+    if (lane == 0) wcnt[wave] = __popcll(hmask);
+    __syncthreads();
+    int sbase = 0, tot = 0;
+    for (int w = 0; w < S; w++) {
+        const int c = wcnt[w];
+        sbase += (w < wave) ? c : 0;
+        tot += c;
+    }
+    const int raw = sbase + __popcll(hmask & ((1ull << lane) - 1ull));
+    const int slot = (hot && raw < nslot) ? raw : -1;
+    slot_of[j] = slot;
+    if (slot >= 0) hotlist[(size_t)p * nslot + slot] = t;
+    if (t == 0) nhot[p] = min(tot, nslot);
+}
+
+// Software-pipelined version: everything panel p+1 needs that does not depend on panel p's outcome is fetched
+// while panel p's serial turns run — its per-marker coefficients, its mat-vec partials (if that mat-vec has
+// already finished) and the Gram rows of its hot markers (into the other half of a double-buffered LDS row
+// cache, two 1-KiB pieces per wave per turn boundary).
+template <int K1>
+__global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__restrict__ pin, chain_view v, persist_view pv,
+                                                       int nslot)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int P = v.P, S = P >> 6;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    int32_t *rowc0 = reinterpret_cast<int32_t *>(smem);                       // two row caches of nslot rows
+    char *base = smem + (size_t)2 * nslot * P * 4;
+    double *ev_del = reinterpret_cast<double *>(base);
+    int *ev_ix = reinterpret_cast<int *>(base + (size_t)P * 8);
+    int *hl = reinterpret_cast<int *>(base + (size_t)P * 12);                 // hot-list of the panel being prefetched
+    double *red = reinterpret_cast<double *>(base + (size_t)P * 16);
+    int *cnts = reinterpret_cast<int *>(base + (size_t)P * 16 + 128);
+    int *s_ok = cnts + 16;
+    int *s_tk = cnts + 17;
+
+    const int model = pin->model_index;
+    const int count_pip = pin->count_pip, store = pin->store;
+    const int lgP = 31 - __clz(P);
+    const int np = pv.npanels;
+    double corr[HB_LBMAX];
+#pragma unroll
+    for (int l = 0; l < HB_LBMAX; l++) corr[l] = 0.0;
+    double wacc = 0.0;
+    int cacc[K1 + 1];
+#pragma unroll
+    for (int c = 0; c <= K1; c++) cacc[c] = 0;
+    int evacc = 0;
+
+    // ---- "next" registers: filled one panel ahead ----
+    double n_vx, n_gold, n_xx, n_thr[K1], n_invv[K1], n_sdz[K1], n_ps[16];
+    int n_slot, n_nhot = 0;
+    int hl_reg = 0, nh_reg = 0; // hot-list entry / count two panels ahead (landed by the time they are stored)
+    bool n_have_ps = false;
+    auto issue_static = [&](int q) { // coefficients of panel q -> next registers (plain loads, fixed before the sweep)
+        const int jq = q * P + t;
+        n_vx = v.vx[jq];
+        n_gold = v.g[jq];
+        n_xx = v.xpx[jq];
+#pragma unroll
+        for (int c = 0; c < K1; c++) {
+            n_thr[c] = v.thr[(size_t)c * v.m_pad + jq];
+            n_invv[c] = v.invv[(size_t)c * v.m_pad + jq];
+            n_sdz[c] = v.sdz[(size_t)c * v.m_pad + jq];
+        }
+        n_slot = pv.slot_of[jq];
+    };
+    auto issue_partials = [&](int q) { // write-through by the mat-vec workgroups: read with sc1 loads
+        const int jq = q * P + t;
+        const int last = v.nsplit - 1;
+#pragma unroll
+        for (int sp = 0; sp < 16; sp++) n_ps[sp] = ld_sc1(&v.partial[(size_t)min(sp, last) * v.m_pad + jq]);
+    };
+    auto ticket_ready = [&](int q) -> bool { // wave 0, non-blocking
+        const unsigned want = tickets_after_group(q / pv.D, pv.ngroups, pv.total_per_group, pv.total_last, lane);
+        const unsigned got = lane < HB_NSUB ? ld_flag(pv.flags + HB_FLAG_TICKET0 + lane * HB_SUB_STRIDE) : 0xffffffffu;
+        return __all(lane >= HB_NSUB || got >= want);
+    };
+
+    // ---- prologue: panel 0 synchronously ----
+    issue_static(0);
+    if (wave == 0) {
+        const bool r = wait_tickets(pv.flags, tickets_after_group(0, pv.ngroups, pv.total_per_group, pv.total_last, lane));
+        if (lane == 0) *s_ok = r ? 1 : 0;
+    }
+    if (t < 16) cnts[t] = 0;
+    __syncthreads();
+    bool ok = *s_ok != 0;
+    if (ok) {
+        issue_partials(0);
+        n_have_ps = true;
+        // row cache 0 for panel 0
+        n_nhot = pv.nhot[0];
+        const int total = n_nhot << lgP, items = (total + 255) >> 8;
+        const int32_t *gp0 = v.gram;
+        for (int it = wave; it < items; it += S) {
+            const int lin = min((it << 8) + lane * 4, total - 4);
+            const int k = pv.hotlist[lin >> lgP];
+            *reinterpret_cast<int4 *>(rowc0 + lin) = *reinterpret_cast<const int4 *>(gp0 + ((size_t)k << lgP) + (lin & (P - 1)));
+        }
+    }
+    if (np > 1) {
+        if (t < nslot) hl_reg = pv.hotlist[(size_t)nslot + t];
+        nh_reg = pv.nhot[1];
+    }
+    __syncthreads();
+
+    for (int p = 0; ok && p < np; p++) {
+        const int j = p * P + t;
+        const int cur = p & 1;
+        int32_t *rowc = rowc0 + (size_t)cur * nslot * P;
+        int32_t *rown = rowc0 + (size_t)(cur ^ 1) * nslot * P;
+        const int32_t *gp = v.gram + (size_t)p * (pv.Lb + 1) * P * P;
+        HB_STAMP(0);
+        // ---- take over the prefetched panel ----
+        const double vxj = n_vx, gold = n_gold, xx = n_xx;
+        double thr[K1], invv[K1], sdz[K1];
+#pragma unroll
+        for (int c = 0; c < K1; c++) { thr[c] = n_thr[c]; invv[c] = n_invv[c]; sdz[c] = n_sdz[c]; }
+        const int myslot = n_slot;
+        if (!n_have_ps) { // the mat-vec was not finished when we looked: wait for it now
+            if (wave == 0) {
+                const bool r = wait_tickets(pv.flags, tickets_after_group(p / pv.D, pv.ngroups, pv.total_per_group, pv.total_last, lane));
+                if (lane == 0) *s_ok = r ? 1 : 0;
+            }
+            __syncthreads();
+            if (!*s_ok) { ok = false; break; }
+            issue_partials(p);
+        }
+        double rhs = 0.0;
+#pragma unroll
+        for (int sp = 0; sp < 16; sp++) rhs += (sp < v.nsplit) ? n_ps[sp] : 0.0;
+        for (int sp = 16; sp < v.nsplit; sp++) rhs += ld_sc1(&v.partial[(size_t)sp * v.m_pad + j]);
+        if (gold != 0.0) rhs = fma(xx, gold, rhs);
+        rhs -= corr[0];
+#pragma unroll
+        for (int l = 0; l + 1 < HB_LBMAX; l++) corr[l] = corr[l + 1];
+        corr[HB_LBMAX - 1] = 0.0;
+        const bool active = vxj != 0.0;
+        const bool hot = active && gold != 0.0;
+        const unsigned long long hmask = __ballot(hot);
+
+        HB_STAMP(1);
+        // ---- start fetching panel p+1 ----
+        const bool have_next = p + 1 < np;
+        n_have_ps = false;
+        const int32_t *gpn = gp + (size_t)(pv.Lb + 1) * P * P;
+        if (have_next) {
+            issue_static(p + 1);
+            if (t < nslot) hl[t] = hl_reg; // fetched one panel ago
+            n_nhot = nh_reg;
+            if (p + 2 < np) {
+                if (t < nslot) hl_reg = pv.hotlist[(size_t)(p + 2) * nslot + t];
+                nh_reg = pv.nhot[p + 2];
+            }
+        }
+        int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0; // row pieces in flight across a turn boundary
+        int plin0 = -1, plin1 = -1;
+
+        int cls_f = 0;
+        double g_f = 0.0;
+        int ev_prev = 0;
+        for (int s = 0; s < S; s++) {
+            if (wave == s) {
+                int cnt = cnts[0];
+                int lo = 0;
+                unsigned long long hleft = hmask;
+                const unsigned long long amask = __ballot(active);
+                for (;;) {
+                    const int knext = hleft ? (__ffsll((long long)hleft) - 1) : 0;
+                    const int snext = __builtin_amdgcn_readlane(myslot, knext);
+                    int gnext = 0;
+                    if (hleft && snext >= 0) gnext = rowc[(size_t)snext * P + t];
+                    const double q = rhs * rhs;
+                    const unsigned long long live = ~0ull << lo;
+                    const unsigned long long mask = ((__ballot(q >= thr[0]) & amask) | hleft) & live;
+                    if (mask == 0ull) break;
+                    const int k = __ffsll((long long)mask) - 1;
+                    int cls = 0;
+                    double iv = 0.0, sz = 0.0;
+#pragma unroll
+                    for (int c = 0; c < K1; c++) {
+                        const bool ge = q >= thr[c];
+                        cls += ge ? 1 : 0;
+                        iv = ge ? invv[c] : iv;
+                        sz = ge ? sdz[c] : sz;
+                    }
+                    double gn = (cls > 0) ? fma(rhs, iv, sz) : 0.0;
+                    if (model == 5 && fabs(gn) < 1e-6) gn = 1e-6;
+                    const double delta = gn - gold;
+                    if (lane == k) { cls_f = cls; g_f = gn; }
+                    const double dk = readlane_f64(delta, k);
+                    const int tk = 64 * s + k;
+                    if (dk != 0.0) {
+                        int gv;
+                        int slot = snext;
+                        if (!(hleft && k == knext)) slot = __builtin_amdgcn_readlane(myslot, k);
+                        if (hleft && k == knext && snext >= 0) gv = gnext;
+                        else if (slot >= 0) gv = rowc[(size_t)slot * P + t];
+                        else gv = gp[(size_t)tk * P + t];
+                        if (lane > k) rhs = fma(-(double)gv, dk, rhs);
+                        if (lane == k) { ev_ix[cnt] = (slot << 16) | tk; ev_del[cnt] = dk; }
+                        cnt++;
+                    }
+                    lo = k + 1;
+                    if (lo >= 64) break;
+                    hleft &= ~((2ull << k) - 1ull);
+                }
+                if (lane == 0) cnts[0] = cnt;
+            } else if (have_next) {
+                // ---- prefetch duty of the waiting waves: land the pieces issued at the previous boundary,
+                // issue the next two (piece index advances by 2 per boundary per wave)
+                const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
+                if (plin0 >= 0) *reinterpret_cast<int4 *>(rown + plin0) = pre0;
+                if (plin1 >= 0) *reinterpret_cast<int4 *>(rown + plin1) = pre1;
+                plin0 = plin1 = -1;
+                if (s >= 1) { // hl[] was written before the barrier of turn 0
+                    const int slotw = wave < s ? wave : wave - 1;              // rank among the S-1 waiting waves
+                    const int it = ((s - 1) * (S - 1) + slotw) * 2;
+                    if (it < n_items) {
+                        plin0 = min((it << 8) + lane * 4, n_total - 4);
+                        pre0 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin0 >> lgP] << lgP) + (plin0 & (P - 1)));
+                    }
+                    if (it + 1 < n_items) {
+                        plin1 = min(((it + 1) << 8) + lane * 4, n_total - 4);
+                        pre1 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin1 >> lgP] << lgP) + (plin1 & (P - 1)));
+                    }
+                }
+            }
+            __syncthreads();
+            const int ev_now = cnts[0];
+            if (wave > s) {
+                for (int e0 = ev_prev; e0 < ev_now; e0 += 8) {
+                    int rec[8], gv[8];
+                    double dl[8];
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; q8++) {
+                        const int e = min(e0 + q8, ev_now - 1);
+                        rec[q8] = ev_ix[e];
+                        dl[q8] = (e0 + q8 < ev_now) ? ev_del[e] : 0.0;
+                    }
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; q8++) {
+                        const int slot = __builtin_amdgcn_readfirstlane(rec[q8] >> 16);
+                        const int k = __builtin_amdgcn_readfirstlane(rec[q8] & 0xffff);
+                        if (slot >= 0) gv[q8] = rowc[(size_t)slot * P + t];
+                        else gv[q8] = gp[(size_t)k * P + t];
+                    }
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; q8++) rhs = fma(-(double)gv[q8], dl[q8], rhs);
+                }
+            }
+            ev_prev = ev_now;
+        }
+        HB_STAMP(2);
+        // pieces still in flight + whatever the turn schedule did not cover (many hot markers)
+        if (have_next) {
+            if (plin0 >= 0) *reinterpret_cast<int4 *>(rown + plin0) = pre0;
+            if (plin1 >= 0) *reinterpret_cast<int4 *>(rown + plin1) = pre1;
+            const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
+            const int covered = (S - 1) * (S - 1) * 2;
+            for (int it = covered + wave; it < n_items; it += S) {
+                const int lin = min((it << 8) + lane * 4, n_total - 4);
+                *reinterpret_cast<int4 *>(rown + lin) = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[lin >> lgP] << lgP) + (lin & (P - 1)));
+            }
+            if (wave == 0) {
+                const bool r = ticket_ready(p + 1);
+                if (lane == 0) *s_tk = r ? 1 : 0;
+            }
+        }
+
+        HB_STAMP(3);
+        // ---- publish the panel's moves: the update kernel of this group is waiting for them. The write-through
+        // stores travel while the per-marker results are written; one drain covers both. ----
+        const int nev = cnts[0];
+        for (int e = t; e < nev; e += P) {
+            st_sc1(&v.ev_idx[(size_t)p * P + e], ev_ix[e] & 0xffff);
+            st_sc1(&v.ev_delta[(size_t)p * P + e], ev_del[e]);
+        }
+        if (t == 0) st_sc1(&v.ev_count[p], nev);
+        HB_STAMP(4);
+        if (!active) { cls_f = 0; g_f = 0.0; }
+        if (g_f != gold) v.g[j] = g_f;
+        v.tracker[j] = (uint8_t)cls_f;
+        if (count_pip && cls_f != 0) {
+            v.nzrate[j] += 1u;
+            if (v.wind) v.wflag[v.wind[j] - 1u] = 1;
+        }
+        if (store && g_f != 0.0) {
+            v.alpha_sum[j] += g_f;
+            v.alpha_sq[j] += g_f * g_f;
+        }
+        if (cls_f > 0) wacc += (model == 6) ? g_f * g_f / pin->fold[cls_f] : g_f * g_f;
+#pragma unroll
+        for (int c = 0; c <= K1; c++) cacc[c] += (active && cls_f == c) ? 1 : 0;
+        evacc = nev + evacc;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)p + 1u);
+        if (have_next && *s_tk) { // next panel's mat-vec already done: its partials travel while we finish this one
+            issue_partials(p + 1);
+            n_have_ps = true;
+        }
+        HB_STAMP(5);
+        // ---- fold the moves forward into the corrections of the next Lb panels ----
+        if (nev > 0) {
+#pragma unroll
+            for (int l = 1; l <= HB_LBMAX; l++) {
+                const int q = p + l;
+                // panel q's mat-vec group g = q / D read the residual with every panel < (g - Lv) * D applied
+                const bool need = l <= pv.Lb && q < np && p >= (q / pv.D - pv.Lv) * pv.D;
+                if (need) {
+                    const int32_t *gx = v.gram + ((size_t)q * (pv.Lb + 1) + l) * P * P;
+                    double acc = 0.0;
+                    for (int e0 = 0; e0 < nev; e0 += 8) {
+                        int gv[8];
+                        double dl[8];
+#pragma unroll
+                        for (int q8 = 0; q8 < 8; q8++) {
+                            const int e = min(e0 + q8, nev - 1);
+                            gv[q8] = gx[(size_t)(ev_ix[e] & 0xffff) * P + t];
+                            dl[q8] = (e0 + q8 < nev) ? ev_del[e] : 0.0;
+                        }
+#pragma unroll
+                        for (int q8 = 0; q8 < 8; q8++) acc = fma((double)gv[q8], dl[q8], acc);
+                    }
+                    corr[l - 1] += acc;
+                }
+            }
+        }
+        HB_STAMP(6);
+        __syncthreads(); // LDS lists and the row cache half are free for the next panel
+        if (t == 0) cnts[0] = 0;
+    }
+
+    // ---- sweep totals for the hyper-parameter draws ----
+    __syncthreads();
+    const double wsum = block_sum(wacc, red);
+    if (t == 0) {
+        v.acc[HB_ACC_SUMG2] = wsum;
+        v.acc[HB_ACC_EVENTS] = (double)evacc;
+    }
+#pragma unroll
+    for (int c = 0; c <= K1; c++) {
+        const double cs = block_sum((double)cacc[c], red);
+        if (t == 0 && c < HB_MAX_FOLD) v.acc[HB_ACC_COUNT0 + c] = cs;
+    }
+    if (t == 0 && !ok) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, 0x7fffffffu); // aborted: release every waiter
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_update: yadj -= sum_e x_e D_e, u += the same, r32 = (float)yadj, for the panel's changed markers.
 // thread = 4 consecutive rows; the event list is staged in LDS once, then the column loads of 8
 // events are in flight together.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update(const int8_t *__restrict__ X, int64_t ld, int P, int p,
+__global__ __launch_bounds__(256) void k_update(const int8_t *__restrict__ X, int64_t ld, int P, int p0, int p1,
                                                 const int32_t *__restrict__ ev_count,
                                                 const int32_t *__restrict__ ev_idx,
                                                 const double *__restrict__ ev_delta,
                                                 const double *__restrict__ r_in, double *__restrict__ r,
-                                                double *__restrict__ u, float *__restrict__ r32)
+                                                double *__restrict__ u, float *__restrict__ r32,
+                                                unsigned *__restrict__ flags)
 {
-    // r_in -> r: version p-1 -> version p of the residual (distinct buffers under look-ahead)
+    // r_in -> r: the residual with the moves of panels [p0, p1) applied (distinct buffers under look-ahead)
     __shared__ int s_ix[512];
     __shared__ double s_dl[512];
-    const int nev = ev_count[p];
-    if (nev == 0) {
-        if (r_in != r) { // nothing moved: the new version is a copy
-            const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-            if (row0 < ld) {
-                const double2 a = *reinterpret_cast<const double2 *>(r_in + row0), b = *reinterpret_cast<const double2 *>(r_in + row0 + 2);
-                *reinterpret_cast<double2 *>(r + row0) = a;
-                *reinterpret_cast<double2 *>(r + row0 + 2) = b;
-                *reinterpret_cast<float4 *>(r32 + row0) = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+    __shared__ int s_ok;
+    const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const bool mine = row0 < ld;
+    // the residual rows do not depend on the chain: fetch them before waiting for it
+    double2 r01 = make_double2(0, 0), r23 = r01, u01 = r01, u23 = r01;
+    if (mine) {
+        r01 = *reinterpret_cast<const double2 *>(r_in + row0);
+        r23 = *reinterpret_cast<const double2 *>(r_in + row0 + 2);
+        u01 = *reinterpret_cast<const double2 *>(u + row0);
+        u23 = *reinterpret_cast<const double2 *>(u + row0 + 2);
+    }
+    if (flags) { // persistent pipeline: the chain workgroup publishes a panel's moves and then chain_done = panel + 1
+        if (threadIdx.x == 0) s_ok = wait_ge(flags, HB_FLAG_CHAIN_DONE, (unsigned)p1) ? 1 : 0;
+        __syncthreads();
+        if (!s_ok) return;
+    }
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int total = 0;
+    for (int p = p0; p < p1; p++) {
+        const int nev = ld_sc1(ev_count + p);
+        if (nev == 0) continue; // uniform
+        total += nev;
+        __syncthreads();
+        for (int e = threadIdx.x; e < nev; e += blockDim.x) {
+            s_ix[e] = ld_sc1(ev_idx + (size_t)p * P + e);
+            s_dl[e] = ld_sc1(ev_delta + (size_t)p * P + e);
+        }
+        __syncthreads();
+        if (!mine) continue;
+        const int8_t *xp = X + (int64_t)p * P * ld + row0;
+        for (int e = 0; e < nev; e += 16) {
+            int w[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) w[q] = *reinterpret_cast<const int *>(xp + (int64_t)s_ix[min(e + q, nev - 1)] * ld);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const double d = (e + q < nev) ? s_dl[e + q] : 0.0;
+                a0 = fma((double)(int8_t)(w[q]), d, a0);
+                a1 = fma((double)(int8_t)(w[q] >> 8), d, a1);
+                a2 = fma((double)(int8_t)(w[q] >> 16), d, a2);
+                a3 = fma((double)(int8_t)(w[q] >> 24), d, a3);
             }
         }
-        return;
     }
-    for (int e = threadIdx.x; e < nev; e += blockDim.x) {
-        s_ix[e] = ev_idx[(size_t)p * P + e];
-        s_dl[e] = ev_delta[(size_t)p * P + e];
-    }
-    __syncthreads();
-    const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (row0 >= ld) return;
-    const int8_t *xp = X + (int64_t)p * P * ld + row0;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int e = 0;
-    for (; e + 16 <= nev; e += 16) {
-        int w[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) w[q] = *reinterpret_cast<const int *>(xp + (int64_t)s_ix[e + q] * ld);
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const double d = s_dl[e + q];
-            a0 = fma((double)(int8_t)(w[q]), d, a0);
-            a1 = fma((double)(int8_t)(w[q] >> 8), d, a1);
-            a2 = fma((double)(int8_t)(w[q] >> 16), d, a2);
-            a3 = fma((double)(int8_t)(w[q] >> 24), d, a3);
-        }
-    }
-    if (e < nev) {
-        int w[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) w[q] = *reinterpret_cast<const int *>(xp + (int64_t)s_ix[min(e + q, nev - 1)] * ld);
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const double d = (e + q < nev) ? s_dl[e + q] : 0.0;
-            a0 = fma((double)(int8_t)(w[q]), d, a0);
-            a1 = fma((double)(int8_t)(w[q] >> 8), d, a1);
-            a2 = fma((double)(int8_t)(w[q] >> 16), d, a2);
-            a3 = fma((double)(int8_t)(w[q] >> 24), d, a3);
-        }
-    }
-    double2 r01 = *reinterpret_cast<const double2 *>(r_in + row0), r23 = *reinterpret_cast<const double2 *>(r_in + row0 + 2);
-    double2 u01 = *reinterpret_cast<double2 *>(u + row0), u23 = *reinterpret_cast<double2 *>(u + row0 + 2);
+    if (!mine || (total == 0 && r_in == r)) return;
     r01.x -= a0; r01.y -= a1; r23.x -= a2; r23.y -= a3;
-    u01.x += a0; u01.y += a1; u23.x += a2; u23.y += a3;
     *reinterpret_cast<double2 *>(r + row0) = r01;
     *reinterpret_cast<double2 *>(r + row0 + 2) = r23;
-    *reinterpret_cast<double2 *>(u + row0) = u01;
-    *reinterpret_cast<double2 *>(u + row0 + 2) = u23;
     *reinterpret_cast<float4 *>(r32 + row0) = make_float4((float)r01.x, (float)r01.y, (float)r23.x, (float)r23.y);
+    if (total) {
+        u01.x += a0; u01.y += a1; u23.x += a2; u23.y += a3;
+        *reinterpret_cast<double2 *>(u + row0) = u01;
+        *reinterpret_cast<double2 *>(u + row0 + 2) = u23;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -925,11 +1367,17 @@ static inline int kpad_for(int model, int n_fold)
 }
 
 // LDS budget of k_chain: as many Gram rows as fit beside the event lists
-static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128 + 128)) / ((size_t)P * 4)); }
-static size_t chain_smem(int P) { return (size_t)chain_nslot(P) * P * 4 + (size_t)P * 16 + 128 + 128; }
+static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128 + 128 + 64)) / ((size_t)P * 4)); }
+static int persist_nslot(int P) { return std::min(P, std::min(160, (int)((160 * 1024 - ((size_t)P * 16 + 128 + 128 + 64)) / ((size_t)P * 8)))); }
+// the whole 160 KiB: nothing that needs LDS (mat-vec, update) can then be co-scheduled on the chain's CU
+static size_t persist_smem(int) { return (size_t)160 * 1024; }
+static size_t chain_smem(int P) { return (size_t)chain_nslot(P) * P * 4 + (size_t)P * 16 + 128 + 128 + 64; }
 
 int hbk_init_attrs()
 {
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_persist<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_persist<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_persist<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -947,7 +1395,7 @@ static hipError_t launch_chain(hb_ctx *c, const chain_view &cv, int p, hipStream
 // residual version v (moves of panels <= v applied; v = -1: start of the sweep) lives in slot (v+1) mod NB
 static inline int ver_slot(const hb_ctx *c, int v) { return (v + 1) % c->NB; }
 
-static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr)
+static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, unsigned *ticket = nullptr)
 {
     if (!st) st = c->stream;
     const dim3 grid(ncols / 8, c->nsplit), block(256);
@@ -957,11 +1405,11 @@ static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t
     const double *r64 = c->r + (size_t)slot * c->ld;
     const bool sgn = c->xmin < 0;
     if (c->precise) {
-        if (sgn) hipLaunchKernelGGL((k_dot<true, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad);
-        else     hipLaunchKernelGGL((k_dot<true, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad);
+        if (sgn) hipLaunchKernelGGL((k_dot<true, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket);
+        else     hipLaunchKernelGGL((k_dot<true, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket);
     } else {
-        if (sgn) hipLaunchKernelGGL((k_dot<false, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad);
-        else     hipLaunchKernelGGL((k_dot<false, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad);
+        if (sgn) hipLaunchKernelGGL((k_dot<false, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket);
+        else     hipLaunchKernelGGL((k_dot<false, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket);
     }
 }
 
@@ -1009,7 +1457,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
 {
     phase_timer tm(c, timed);
     const int kp = kpad_for(model, n_fold);
-    const int L = c->L, np = c->npanels;
+    const int L = c->Lv, np = c->npanels; // per-panel launches: lag Lv with one panel per mat-vec
     hipStream_t sA = c->stream, sB = timed ? c->stream : c->s_chain, sC = timed ? c->stream : c->s_upd;
     HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, sA));
     hipEvent_t t_all = tm.begin();
@@ -1024,7 +1472,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
         HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
         HB_HIP(hipStreamWaitEvent(sC, c->ev_fork, 0));
     }
-    chain_view cv{c->m_pad, c->P, c->nsplit, L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
+    chain_view cv{c->m_pad, c->P, c->nsplit, L, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg};
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
@@ -1051,9 +1499,9 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
             b = tm.begin();
             if (!timed) HB_HIP(hipStreamWaitEvent(sC, c->ev_chain[pc], 0));
             const int sin = ver_slot(c, pc - 1), sout = ver_slot(c, pc);
-            hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sC, c->X, c->ld, c->P, pc, c->ev_count, c->ev_idx,
+            hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sC, c->X, c->ld, c->P, pc, pc + 1, c->ev_count, c->ev_idx,
                                c->ev_delta, c->r + (size_t)sin * c->ld, c->r + (size_t)sout * c->ld, c->u,
-                               c->r32 + (size_t)sout * c->ld);
+                               c->r32 + (size_t)sout * c->ld, (unsigned *)nullptr);
             if (!timed) HB_HIP(hipEventRecord(c->ev_upd[pc], sC));
             tm.end(2, b);
         }
@@ -1098,17 +1546,95 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
     return HB_OK;
 }
 
+template <int K1>
+static hipError_t launch_chain_persist(hb_ctx *c, const chain_view &cv, const persist_view &pv, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_chain_persist<K1>, dim3(1), dim3(c->P), persist_smem(c->P), st, c->d_in, cv, pv, persist_nslot(c->P));
+    return hipGetLastError();
+}
+
+// Persistent pipeline: stream A = mat-vec groups, stream B = ONE chain workgroup for the whole sweep,
+// stream C = residual updates.  Device-side hand-offs: mat-vec -> chain through the group's ticket word,
+// chain -> update through chain_done; update -> mat-vec stays a kernel-boundary dependency (graph edge),
+// and every update also has an edge from its own mat-vec group so that a spinning update kernel can never
+// sit in front of work the chain is waiting for.
+static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
+{
+    const int kp = kpad_for(model, n_fold);
+    const int np = c->npanels, D = c->D, Lv = c->Lv;
+    const int ngroups = (np + D - 1) / D;
+    hipStream_t sA = c->stream, sB = c->s_chain, sC = c->s_upd;
+    HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, sA));
+    HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * (HB_FLAG_TICKET0 + HB_NSUB * HB_SUB_STRIDE), sA));
+    {
+        pre_view pvw{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
+        hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pvw);
+    }
+    const int ns = persist_nslot(c->P);
+    hipLaunchKernelGGL(k_hotlist, dim3(np), dim3(c->P), 0, sA, c->vx, c->g, c->P, ns, c->hot_slot, c->hot_list, c->hot_n);
+    HB_HIP(hipEventRecord(c->ev_fork, sA));
+    HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
+    HB_HIP(hipStreamWaitEvent(sC, c->ev_fork, 0));
+    chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
+                  c->thr, c->invv, c->sdz, c->gram, c->partial, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
+                  c->wind, c->wflag, c->dbg};
+    const unsigned per_panel = (unsigned)(c->P / 8) * (unsigned)c->nsplit;
+    const int last_panels = np - (ngroups - 1) * D;
+    persist_view pv{np, D, Lv, c->L, per_panel * (unsigned)D, per_panel * (unsigned)last_panels, ngroups, c->flags,
+                    c->hot_slot, c->hot_list, c->hot_n};
+    {
+        hipError_t e = kp == 1 ? launch_chain_persist<1>(c, cv, pv, sB) : kp == 3 ? launch_chain_persist<3>(c, cv, pv, sB)
+                                                                                 : launch_chain_persist<7>(c, cv, pv, sB);
+        if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_persist launch: ") + hipGetErrorString(e));
+    }
+    const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
+    // residual versions advance per mat-vec group: version h = every panel of groups <= h applied, slot (h+1) % NB;
+    // mat-vec(g) reads version g - Lv - 1, update(h) is one launch for the D panels of group h.
+    for (int g = 0; g < ngroups; g++) {
+        const int p0 = g * D, p1 = std::min(np, p0 + D);
+        const int vread = g - Lv - 1;
+        if (vread >= 0) HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[vread], 0));
+        launch_dot(c, p0 * c->P, (p1 - p0) * c->P, ver_slot(c, vread < -1 ? -1 : vread), sA, c->flags + HB_FLAG_TICKET0);
+        HB_HIP(hipEventRecord(c->ev_dot[g], sA));
+        HB_HIP(hipStreamWaitEvent(sC, c->ev_dot[g], 0));
+        const int sin = ver_slot(c, g - 1), sout = ver_slot(c, g);
+        hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sC, c->X, c->ld, c->P, p0, p1, c->ev_count, c->ev_idx,
+                           c->ev_delta, c->r + (size_t)sin * c->ld, c->r + (size_t)sout * c->ld, c->u,
+                           c->r32 + (size_t)sout * c->ld, c->flags);
+        HB_HIP(hipEventRecord(c->ev_upd[g], sC));
+    }
+    HB_HIP(hipEventRecord(c->ev_chain[0], sB));
+    HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[ngroups - 1], 0));
+    HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
+    const int sfin = ver_slot(c, ngroups - 1);
+    if (sfin != 0) {
+        HB_HIP(hipMemcpyAsync(c->r, c->r + (size_t)sfin * c->ld, sizeof(double) * c->ld, hipMemcpyDeviceToDevice, sA));
+        HB_HIP(hipMemcpyAsync(c->r32, c->r32 + (size_t)sfin * c->ld, sizeof(float) * c->ld, hipMemcpyDeviceToDevice, sA));
+    }
+    if (model == 5) {
+        hipLaunchKernelGGL(k_bayesl_post, dim3((c->m + 255) / 256), dim3(256), 0, sA, c->d_in, c->m, c->m_offset, c->seed,
+                           c->vx, c->g, c->vargL);
+        hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(1024), 0, sA, c->vargL, c->m, c->acc + HB_ACC_SUMVARGL);
+    }
+    hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(1024), 0, sA, c->r, c->u, c->n, c->acc);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
 {
     *c->h_in = *in;
     HB_HIP(hipMemcpyAsync(c->d_in, c->h_in, sizeof(hb_sweep_in), hipMemcpyHostToDevice, c->stream));
-    if (timed || !c->use_graph) return enqueue_sweep_kernels(c, in->model_index, in->n_fold, timed);
+    if (timed) return enqueue_sweep_kernels(c, in->model_index, in->n_fold, true);
+    if (!c->use_graph) return c->pipeline ? enqueue_sweep_pipeline(c, in->model_index, in->n_fold)
+                                          : enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
     if (!c->gexec || c->graph_model != in->model_index || c->graph_fold != in->n_fold) {
         if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
         if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
         HB_HIP(hipStreamSynchronize(c->stream));
         HB_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-        int rc = enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
+        int rc = c->pipeline ? enqueue_sweep_pipeline(c, in->model_index, in->n_fold)
+                             : enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
         hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
         if (rc) return rc;
         if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -1253,5 +1779,32 @@ int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out)
     const dim3 grid((unsigned)((c->ld / 4 + 255) / 256), (unsigned)((c->m_pad + 255) / 256));
     hipLaunchKernelGGL(k_xalpha, grid, dim3(256), 0, c->stream, c->X, c->ld, c->m_pad, dev_alpha, dev_out);
     HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+// development probe (not part of the ABI): average duration of mat-vec launches of D panels each, back to back
+extern "C" int hbk_dot_bench(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us)
+{
+    HB_HIP(hipSetDevice(c->device));
+    hipEvent_t e0, e1;
+    HB_HIP(hipEventCreate(&e0));
+    HB_HIP(hipEventCreate(&e1));
+    const int ngroups = (c->npanels + D - 1) / D;
+    HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * (HB_FLAG_TICKET0 + HB_NSUB * HB_SUB_STRIDE), c->stream));
+    for (int warm = 0; warm < 2; warm++) {
+        if (warm) HB_HIP(hipEventRecord(e0, c->stream));
+        for (int r = 0; r < (warm ? reps : 1); r++)
+            for (int g = 0; g < ngroups; g++) {
+                const int p0 = g * D, p1 = std::min(c->npanels, p0 + D);
+                launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, use_ticket ? c->flags + HB_FLAG_TICKET0 : nullptr);
+            }
+    }
+    HB_HIP(hipEventRecord(e1, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = (double)ms * 1e3 / ((double)reps * ngroups);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return HB_OK;
 }

@@ -12,7 +12,7 @@ rng = np.random.default_rng(3)
 beta = np.zeros(m); idx = rng.choice(m, max(1, m // 1000), replace=False); beta[idx] = rng.normal(0, 0.05, idx.size)
 xb = np.zeros(n); check(c.L.hb_ctx_matvec(c.h, beta.ctypes.data, xb.ctypes.data))
 y = xb - xb.mean(); y = y * np.sqrt(0.5 / y.var()) + rng.normal(0, np.sqrt(0.5), n)
-c.set_profiling(3)
+c.set_profiling(3 if os.environ.get('HB_PIPELINE','1')=='0' else 2)
 Pi, fold = ([0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2]) if model == "BayesR" else ([0.95, 0.05], None)
 from hibayes_amd._lib import BayesArgs, RunInfo
 a = BayesArgs(); a.n, a.m = n, m; yv = np.ascontiguousarray(y); a.y = yv.ctypes.data; a.model = model.encode()
@@ -28,6 +28,9 @@ c.L.hb_ctx_debug_stamps.argtypes = [ct.c_void_p, ct.c_void_p]; check(c.L.hb_ctx_
 S = P // 64
 d = st - st[:, :1]
 print("panel", P, "timing(ms/sweep)", {k: round(v, 3) for k, v in tm.items()}, "events/sweep", info.mean_events, "nnz", info.nnz)
+if os.environ.get('HB_PIPELINE','1')!='0':
+    dd = np.diff(st[5:, :7], axis=1); per = np.diff(st[5:, 0])
+    print("persist: median cycles per phase [take,prefetch-issue,turns,tail,publish,results,fwd]:", [int(np.median(dd[:, i])) for i in range(6)], "per panel total", int(np.median(per)), "-> us", np.median(per)/2100.)
 print("cycles (100MHz? shader clk) medians: staged+coef", np.median(d[:, 1]), "turns", [int(np.median(d[:, 2 + s] - d[:, 1 + s])) for s in range(min(S, 24))],
       "loop_end", np.median(d[:, 26]), "end", np.median(d[:, 27]))
 print("per panel avg us: dot %.2f chain %.2f update %.2f" % (tm["dot_ms"] / npan * 1e3, tm["chain_ms"] / npan * 1e3, tm["update_ms"] / npan * 1e3))
