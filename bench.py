@@ -2,6 +2,8 @@
 """bench.py — Gibbs sweeps/sec of the individual-level marker sweep on MI355X.
 
 Metric (BASELINE.json): "Gibbs sweeps/sec (full m-marker pass) + achieved HBM GB/s, n=50k m=500k".
+The headline model is BayesCpi (the model BASELINE.json's north_star target is stated for, at n=50k, m=500k);
+BayesR (configs[2]) is measured on the same genotypes and reported under "secondary".
 One step = one iteration of the reference's MCMC loop (src/Bayes.cpp:477-917): intercept draw,
 the full m-marker sweep on the device, the end-of-sweep reductions and the host hyper-parameter
 draws — on synthetic int8 genotypes already resident in HBM (SURVEY.md §8 d).
@@ -30,15 +32,15 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--m", type=int, default=500000)
-    ap.add_argument("--model", default="BayesR")
+    ap.add_argument("--model", default="BayesCpi", help="BASELINE.json north_star target: BayesCpi at n=50k, m=500k")
+    ap.add_argument("--secondary", default="BayesR", help="second model measured on the same genotypes ('' = none)")
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--precise", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20240901)
-    ap.add_argument("--profile-sweeps", type=int, default=3, help="extra sweeps timed kernel by kernel with HIP events")
     ap.add_argument("--cpu-m", type=int, default=8000, help="markers of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-sweeps", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
@@ -118,58 +120,34 @@ def cpu_baseline(ctx, y, args, Pi, fold):
             "value_1thread": out[1], "host_cores": cores}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    comm = None
-    import torch
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        from hibayes_amd.dist import TorchComm
-        comm = TorchComm(device=torch.device("cuda", local_rank))
-    import hibayes_amd as H
-    from hibayes_amd import _lib
-    from hibayes_amd._lib import BayesArgs, BayesOut, RunInfo, check
-    L = H.lib()
+PIPELINE = {  # (pipeline, look-ahead groups, panels per mat-vec launch): see DESIGN.md §2
+    "BayesCpi": (1, 2, 4), "BayesC": (1, 2, 4), "BayesB": (1, 2, 4), "BayesBpi": (1, 2, 4),
+    "BayesR": (1, 2, 1), "BayesRR": (1, 1, 1), "BayesA": (1, 1, 1), "BayesL": (1, 1, 1),
+}
 
+
+def prior(model):
+    if model == "BayesR":
+        return [0.95, 0.02, 0.02, 0.01], [0.0, 1e-4, 1e-3, 1e-2]  # R/bayes.r:273-275
+    return [0.95, 0.05], None
+
+
+def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, m_global, comm, torch, note):
+    """W warm-up iterations, then exactly K iterations between barriers; returns the result dict pieces."""
+    from hibayes_amd._lib import BayesArgs, RunInfo, check
     n, m = args.n, args.m
-    m_global, m_offset = m * world, m * rank
-    if args.model == "BayesR":
-        Pi, fold = [0.95, 0.02, 0.02, 0.01], [0.0, 1e-4, 1e-3, 1e-2]  # R/bayes.r:273-275
-    else:
-        Pi, fold = [0.95, 0.05], None
-
-    def note(msg):
-        if rank == 0:
-            print("[bench %.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
-
-    t_start = t0 = time.time()
-    ctx = H.Context(n, m, device=local_rank, panel=args.panel, precise=bool(args.precise), m_offset=m_offset,
-                    seed=args.seed)
-    ctx.generate(args.seed, mono_every=1000)
-    gen_s = time.time() - t0
-    note("genotypes generated on device (%.2fs)" % gen_s)
-    y = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, args.model)
-    note("phenotype built")
-    gram_s = ctx.build_gram()
-    note("Gram blocks built (%.2fs)" % gram_s)
-
-    K, W, PS = args.steps, args.warmup, args.profile_sweeps
+    Pi, fold = prior(model)
     a = BayesArgs()
     a.n, a.m = n, m
     yv = np.ascontiguousarray(y)
     a.y = yv.ctypes.data
-    a.model = args.model.encode()
+    a.model = model.encode()
     pv = np.array(Pi)
     a.Pi, a.n_pi = pv.ctypes.data, pv.size
     if fold is not None:
         fv = np.array(fold)
         a.fold, a.n_fold = fv.ctypes.data, fv.size
-    a.niter, a.nburn, a.thin = W + K + PS + 5, 0, 5  # every sweep counts PIP, every 5th is a stored record
+    a.niter, a.nburn, a.thin = W + K + 5, 0, 5  # every sweep counts PIP, every 5th is a stored record
     a.outfreq, a.verbose = 0, 0
     a.seed, a.device, a.precise, a.store_alpha = args.seed, local_rank, args.precise, 0
     a.ctx = ctx.h
@@ -189,64 +167,108 @@ def main():
             comm.barrier()
             torch.cuda.synchronize(local_rank)
 
-    note("run created")
     check(L.hb_run_step(run, W, ct.byref(fin)))
     sync()
-    note("warm-up done")
+    note("%s: warm-up done" % model)
     t1 = time.perf_counter()
     check(L.hb_run_step(run, K, ct.byref(fin)))
     sync()
     elapsed = time.perf_counter() - t1
-    note("timed region done: %.3fs for %d steps" % (elapsed, K))
+    note("%s: timed region done: %.3fs for %d steps" % (model, elapsed, K))
     if comm is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm.device)
         comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
         elapsed = float(t.item())
     info = RunInfo()
     check(L.hb_run_state(run, ct.byref(info)))
+    L.hb_run_destroy(run)
+    del keep
+    return elapsed, info.mean_events, info.nnz
 
-    # kernel-by-kernel pass: HIP events on the stream the kernels run on
-    roof = None
-    if PS > 0:
-        ctx.set_profiling(True)
-        dot_ms, launches, tot, chain, upd = 0.0, 0, 0.0, 0.0, 0.0
-        for _ in range(PS):
-            check(L.hb_run_step(run, 1, ct.byref(fin)))
-            tm = ctx.last_timing()
-            dot_ms += tm["dot_ms"]; launches += tm["dot_launches"]; tot += tm["total_ms"]
-            chain += tm["chain_ms"]; upd += tm["update_ms"]
-        ctx.set_profiling(False)
-        P = ctx.panel
-        avg_ms = dot_ms / max(launches, 1)
-        alg_bytes = float(n) * P  # one read of the panel's int8 genotypes (SURVEY §8 d: n*m per sweep)
-        ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": alg_bytes,
-                "avg_launch_ms": avg_ms, "launches_per_sweep": launches // PS,
-                "sweep_phase_ms": {"total": tot / PS, "dot": dot_ms / PS, "chain": chain / PS, "update": upd / PS}}
 
-    note("profiling pass done")
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    comm = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        from hibayes_amd.dist import TorchComm
+        comm = TorchComm(device=torch.device("cuda", local_rank))
+    import hibayes_amd as H
+    L = H.lib()
+
+    n, m = args.n, args.m
+    m_global, m_offset = m * world, m * rank
+
+    def note(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
+
+    t_start = t0 = time.time()
+    ctx = H.Context(n, m, device=local_rank, panel=args.panel, precise=bool(args.precise), m_offset=m_offset,
+                    seed=args.seed)
+    ctx.generate(args.seed, mono_every=1000)
+    gen_s = time.time() - t0
+    note("genotypes generated on device (%.2fs)" % gen_s)
+    y = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, args.model)
+    note("phenotype built")
+    geo = PIPELINE.get(args.model, (1, 1, 1))
+    ctx.set_pipeline(*geo)
+    gram_s = ctx.build_gram()
+    note("Gram blocks built (%.2fs)" % gram_s)
+
+    K, W = args.steps, args.warmup
+    elapsed, mean_events, nnz = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
+                                        m_global, comm, torch, note)
+    # the dominant kernel on its own: the sweep's mat-vec launches, back to back, HIP events on their stream
+    avg_ms, launches, cols = ctx.time_matvec(reps=3)
+    alg_bytes = float(n) * cols  # one read of the launch's int8 genotypes (SURVEY.md §8 d: n*m per sweep)
+    ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": alg_bytes,
+            "avg_launch_ms": avg_ms, "launches_per_sweep": launches, "columns_per_launch": cols}
+    note("mat-vec timing pass done")
+
     value = world * K / elapsed
+    Pi, fold = prior(args.model)
     res = {
         "metric": "Gibbs sweeps/sec (full m-marker pass), n=50k m=500k",
         "value": value, "unit": "sweeps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64" if args.precise else "f32", "data": "synthetic",
         "config": {"workload": "%s marker sweep, n=%d individuals x m=%d int8 markers per GPU (m_global=%d), "
-                               "panel=%d" % (args.model, n, m, m_global, ctx.panel),
+                               "panel=%d, pipeline=%s" % (args.model, n, m, m_global, ctx.panel, (geo,)),
                    "model": args.model, "n": n, "m_per_gpu": m, "m_global": m_global, "panel": ctx.panel,
+                   "pipeline": {"persistent_chain": geo[0], "lookahead_groups": geo[1], "panels_per_matvec": geo[2]},
                    "sharding": "markers, contiguous ranges, one residual all-reduce per sweep" if world > 1 else "none",
-                   "mean_changed_markers_per_sweep": info.mean_events, "NumNZSnp_last": info.nnz,
+                   "mean_changed_markers_per_sweep": mean_events, "NumNZSnp_last": nnz,
                    "setup_seconds": {"generate": gen_s, "gram": gram_s}},
         "achieved_GBps": value * n * m / 1e9, "achieved_frac_of_hbm_peak": value * n * m / 1e9 / (HBM_PEAK_GBPS * world),
         "roofline": roof,
     }
+    if args.secondary and args.secondary != args.model and world == 1:
+        # the other model family of BASELINE.json's configs on the same genotypes, shorter run
+        geo2 = PIPELINE.get(args.secondary, (1, 1, 1))
+        ctx.set_pipeline(*geo2)
+        ctx.build_gram()
+        K2, W2 = max(10, K // 4), max(5, min(W, 30))
+        y2 = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, args.secondary)
+        el2, ev2, nnz2 = measure(H, L, ctx, y2, args.secondary, K2, W2, args, rank, local_rank, world, m_offset,
+                                 m_global, comm, torch, note)
+        res["secondary"] = {"model": args.secondary, "value": K2 / el2, "unit": "sweeps/s", "steps": K2, "warmup": W2,
+                            "ms_per_step": el2 / K2 * 1e3, "achieved_frac_of_hbm_peak": K2 / el2 * n * m / 1e9 / HBM_PEAK_GBPS,
+                            "mean_changed_markers_per_sweep": ev2, "NumNZSnp_last": nnz2,
+                            "pipeline": {"persistent_chain": geo2[0], "lookahead_groups": geo2[1], "panels_per_matvec": geo2[2]}}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
             res["cpu_baseline"] = cpu_baseline(ctx, y, args, Pi, fold)
         except Exception as e:  # the baseline is a reported side number, never the measured path
             res["cpu_baseline"] = {"error": repr(e)}
-    L.hb_run_destroy(run)
     ctx.close()
     if rank == 0:
         print(json.dumps(res))

@@ -125,7 +125,7 @@ SYMBOLS = [
     "hb_ctx_get_residual", "hb_ctx_set_effects", "hb_ctx_get_effects", "hb_ctx_dot", "hb_ctx_residual_sums",
     "hb_ctx_residual_shift", "hb_ctx_set_covariates", "hb_ctx_cov_dot", "hb_ctx_cov_axpy", "hb_ctx_set_levels",
     "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_sweep", "hb_ctx_get_counters", "hb_ctx_set_windows",
-    "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec",
+    "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec",
     "hb_run_create", "hb_run_step", "hb_run_state", "hb_run_ctx", "hb_run_finish", "hb_run_destroy",
 ]
 
@@ -180,6 +180,8 @@ def lib():
     L.hb_ctx_last_timing.argtypes = [vp, C.POINTER(SweepTiming)]
     L.hb_ctx_set_profiling.argtypes = [vp, i32]
     L.hb_ctx_matvec.argtypes = [vp, vp, vp]
+    L.hb_ctx_set_pipeline.argtypes = [vp, i32, i32, i32]
+    L.hb_ctx_time_matvec.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(i32), C.POINTER(i32)]
     L.hb_run_create.argtypes = [C.POINTER(BayesArgs), C.POINTER(vp)]
     L.hb_run_step.argtypes = [vp, i32, C.POINTER(i32)]
     L.hb_run_state.argtypes = [vp, C.POINTER(RunInfo)]

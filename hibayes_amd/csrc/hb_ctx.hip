@@ -23,6 +23,7 @@ int hbk_f64_to_i8(hb_ctx *c, const double *dsrc, int64_t lds, int ncols, int8_t 
 int hbk_bed_decode(hb_ctx *c, const uint8_t *dbed, int64_t bpc, int nind, const int32_t *drows, int col0, int ncols);
 int hbk_generate(hb_ctx *c, uint64_t seed, int mono_every);
 int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out);
+int hbk_time_matvec(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us, int *launches);
 
 static thread_local std::string g_err;
 
@@ -39,6 +40,19 @@ static int dev_alloc(T **p, size_t count, bool zero = true)
     HB_HIP(hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T)));
     if (zero) HB_HIP(hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(T)));
     return HB_OK;
+}
+
+// normalise (pipeline, Lv, D) and derive the Gram band / version ring sizes
+static void hb_pipeline_geometry(hb_ctx *c)
+{
+    c->Lv = std::max(0, std::min(6, c->Lv));
+    c->D = c->pipeline ? std::max(1, std::min(8, c->D)) : 1;
+    // Lv counts mat-vec GROUPS of look-ahead; the Gram band then spans (Lv + 1) * D - 1 earlier panels
+    while ((c->Lv + 1) * c->D - 1 > 12) { // HB_LBMAX in hb_kernels.hip
+        if (c->Lv > 1) c->Lv--; else c->D--;
+    }
+    c->L = std::max((c->Lv + 1) * c->D - 1, c->Lv);
+    c->NB = c->Lv + 1;
 }
 
 extern "C" {
@@ -92,19 +106,16 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     c->seed = p->seed;
     c->nchunks = (int)((c->ld + 4095) / 4096);
     c->nsplit = c->nchunks;
-    // pipeline geometry: HB_PIPELINE=0 serial kernels, 1 persistent chain workgroup
+    // pipeline geometry; hb_ctx_set_pipeline() changes it later
     c->pipeline = 1;
     c->Lv = 2;
-    c->D = 1;
+    c->D = 4;
     if (const char *e = getenv("HB_PIPELINE")) c->pipeline = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("HB_LOOKAHEAD")) c->Lv = std::max(0, std::min(6, atoi(e)));
-    if (const char *e = getenv("HB_DOTGROUP")) c->D = std::max(1, std::min(4, atoi(e)));
+    if (const char *e = getenv("HB_LOOKAHEAD")) c->Lv = atoi(e);
+    if (const char *e = getenv("HB_DOTGROUP")) c->D = atoi(e);
+    c->env_pinned = getenv("HB_PIPELINE") || getenv("HB_LOOKAHEAD") || getenv("HB_DOTGROUP");
     if (!c->pipeline && !getenv("HB_LOOKAHEAD")) c->Lv = 0;
-    if (!c->pipeline) c->D = 1;
-    // Lv counts mat-vec GROUPS of look-ahead; the Gram band then spans (Lv + 1) * D - 1 earlier panels
-    while ((c->Lv + 1) * c->D - 1 > 6) c->Lv--; // HB_LBMAX in hb_kernels.hip
-    c->L = std::max((c->Lv + 1) * c->D - 1, c->Lv);
-    c->NB = c->Lv + 1;
+    hb_pipeline_geometry(c);
     int rc = HB_OK;
 #define TRY(x)                   \
     do {                         \
@@ -148,10 +159,9 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->alpha_sq, mp));
     TRY(dev_alloc(&c->tracker, mp));
     TRY(dev_alloc(&c->nzrate, mp));
-    TRY(dev_alloc(&c->r, (size_t)c->ld * c->NB));      // NB versions; slot 0 is the residual between sweeps
+    TRY(dev_alloc(&c->r, (size_t)c->ld * 8));          // up to 8 versions; slot 0 is the residual between sweeps
     TRY(dev_alloc(&c->u, (size_t)c->ld));
-    TRY(dev_alloc(&c->r32, (size_t)c->ld * c->NB));
-    TRY(dev_alloc(&c->gram, mp * (size_t)P * (c->L + 1)));
+    TRY(dev_alloc(&c->r32, (size_t)c->ld * 8));
     TRY(dev_alloc(&c->xinfo, 2));
     TRY(dev_alloc(&c->thr, mp * (HB_MAX_FOLD - 1)));
     TRY(dev_alloc(&c->invv, mp * (HB_MAX_FOLD - 1)));
@@ -354,10 +364,35 @@ int hb_ctx_marker_stats(hb_ctx *c, double *xpx, double *vx, double *sumvx, int32
     return HB_OK;
 }
 
+int hb_ctx_set_pipeline(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t dotgroup)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_set_pipeline");
+    if (rc) return rc;
+    if (c->env_pinned) return HB_OK; // HB_PIPELINE / HB_LOOKAHEAD / HB_DOTGROUP in the environment win (tuning runs)
+    const int op = c->pipeline, ol = c->Lv, od = c->D;
+    c->pipeline = pipeline ? 1 : 0;
+    c->Lv = lookahead;
+    c->D = dotgroup;
+    hb_pipeline_geometry(c);
+    if (op != c->pipeline || ol != c->Lv || od != c->D) {
+        c->gram_ready = false;
+        c->graph_model = -1;
+    }
+    return HB_OK;
+}
+
 int hb_ctx_build_gram(hb_ctx *c, double *seconds)
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_build_gram");
     if (rc) return rc;
+    const size_t need = (size_t)c->m_pad * (size_t)c->P * (size_t)(c->L + 1);
+    if (need > c->gram_cap) {
+        if (c->gram) { (void)hipFree(c->gram); c->gram = nullptr; }
+        c->gram_cap = 0;
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->gram), need * sizeof(int32_t)));
+        c->gram_cap = need;
+    }
+    HB_HIP(hipMemsetAsync(c->gram, 0, need * sizeof(int32_t), c->stream));
     if (!c->stats_ready) {
         rc = hbk_stats(c);
         if (rc) return rc;
@@ -664,6 +699,25 @@ int hb_ctx_get_windows(hb_ctx *c, double *wppa)
     if (!c->nw) return hb_fail(HB_ERR_INVALID, "hb_ctx_get_windows: no windows set");
     HB_HIP(hipStreamSynchronize(c->stream));
     HB_HIP(hipMemcpy(wppa, c->wppa, sizeof(double) * c->nw, hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
+int hb_ctx_time_matvec(hb_ctx *c, int32_t reps, double *avg_ms, int32_t *launches_per_sweep, int32_t *cols_per_launch)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_time_matvec");
+    if (rc) return rc;
+    if (!c->stats_ready) {
+        rc = hbk_stats(c);
+        if (rc) return rc;
+    }
+    double us = 0;
+    int nl = 0;
+    const int D = c->pipeline ? c->D : 1;
+    rc = hbk_time_matvec(c, D, reps > 0 ? reps : 1, c->pipeline, &us, &nl);
+    if (rc) return rc;
+    if (avg_ms) *avg_ms = us * 1e-3;
+    if (launches_per_sweep) *launches_per_sweep = nl;
+    if (cols_per_launch) *cols_per_launch = D * c->P;
     return HB_OK;
 }
 

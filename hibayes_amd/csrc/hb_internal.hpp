@@ -58,6 +58,8 @@ struct hb_ctx {
     double *r = nullptr, *u = nullptr;
     float *r32 = nullptr;
     int32_t *gram = nullptr;
+    size_t gram_cap = 0; // ints allocated
+    bool env_pinned = false;
     bool gram_ready = false, stats_ready = false;
     int *xinfo = nullptr; // device: [0]=min value, [1]=max value over X
     int xmin = 0, xmax = 0;

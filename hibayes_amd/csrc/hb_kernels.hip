@@ -679,7 +679,7 @@ struct persist_view {
     const int *slot_of, *hotlist, *nhot; // per-sweep hot-lists from k_hotlist
 };
 
-#define HB_LBMAX 6
+#define HB_LBMAX 12
 
 // hot-list of every panel (markers certain to move: polymorphic with g_old != 0), in marker order, capped at
 // nslot rows per panel; produced once per sweep, off the chain's critical path.  One workgroup per panel.
@@ -726,6 +726,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     int *cnts = reinterpret_cast<int *>(base + (size_t)P * 16 + 128);
     int *s_ok = cnts + 16;
     int *s_tk = cnts + 17;
+    int *cand = cnts + 18; // cand[w] != 0: sub-block w holds a marker that may move given the current rhs
 
     const int model = pin->model_index;
     const int count_pip = pin->count_pip, store = pin->store;
@@ -847,13 +848,32 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                 nh_reg = pv.nhot[p + 2];
             }
         }
-        int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0; // row pieces in flight across a turn boundary
-        int plin0 = -1, plin1 = -1;
+        // Gram rows of the next panel's hot markers: four 1-KiB pieces per wave travel during the turns
+        int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
+        int plin0 = -1, plin1 = -1, plin2 = -1, plin3 = -1;
+        const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
+        {
+            // a marker at zero moves only if q >= thr[0]; a hot one always moves
+            const unsigned long long c0 = (__ballot(rhs * rhs >= thr[0]) & __ballot(active)) | hmask;
+            if (lane == 0) cand[wave] = c0 != 0ull;
+        }
+        __syncthreads(); // cand[], hl[] staged
+        if (have_next) {
+            if (wave < n_items) { plin0 = min((wave << 8) + lane * 4, n_total - 4);
+                pre0 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin0 >> lgP] << lgP) + (plin0 & (P - 1))); }
+            if (wave + S < n_items) { plin1 = min(((wave + S) << 8) + lane * 4, n_total - 4);
+                pre1 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin1 >> lgP] << lgP) + (plin1 & (P - 1))); }
+            if (wave + 2 * S < n_items) { plin2 = min(((wave + 2 * S) << 8) + lane * 4, n_total - 4);
+                pre2 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin2 >> lgP] << lgP) + (plin2 & (P - 1))); }
+            if (wave + 3 * S < n_items) { plin3 = min(((wave + 3 * S) << 8) + lane * 4, n_total - 4);
+                pre3 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin3 >> lgP] << lgP) + (plin3 & (P - 1))); }
+        }
 
         int cls_f = 0;
         double g_f = 0.0;
         int ev_prev = 0;
         for (int s = 0; s < S; s++) {
+            if (!cand[s]) continue; // uniform: nothing in this sub-block can move, its markers stay at zero
             if (wave == s) {
                 int cnt = cnts[0];
                 int lo = 0;
@@ -900,48 +920,35 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                     hleft &= ~((2ull << k) - 1ull);
                 }
                 if (lane == 0) cnts[0] = cnt;
-            } else if (have_next) {
-                // ---- prefetch duty of the waiting waves: land the pieces issued at the previous boundary,
-                // issue the next two (piece index advances by 2 per boundary per wave)
-                const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
-                if (plin0 >= 0) *reinterpret_cast<int4 *>(rown + plin0) = pre0;
-                if (plin1 >= 0) *reinterpret_cast<int4 *>(rown + plin1) = pre1;
-                plin0 = plin1 = -1;
-                if (s >= 1) { // hl[] was written before the barrier of turn 0
-                    const int slotw = wave < s ? wave : wave - 1;              // rank among the S-1 waiting waves
-                    const int it = ((s - 1) * (S - 1) + slotw) * 2;
-                    if (it < n_items) {
-                        plin0 = min((it << 8) + lane * 4, n_total - 4);
-                        pre0 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin0 >> lgP] << lgP) + (plin0 & (P - 1)));
-                    }
-                    if (it + 1 < n_items) {
-                        plin1 = min(((it + 1) << 8) + lane * 4, n_total - 4);
-                        pre1 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin1 >> lgP] << lgP) + (plin1 & (P - 1)));
-                    }
-                }
             }
             __syncthreads();
             const int ev_now = cnts[0];
-            if (wave > s) {
-                for (int e0 = ev_prev; e0 < ev_now; e0 += 8) {
-                    int rec[8], gv[8];
-                    double dl[8];
+            if (ev_now > ev_prev) { // uniform
+                if (wave > s) {
+                    for (int e0 = ev_prev; e0 < ev_now; e0 += 8) {
+                        int rec[8], gv[8];
+                        double dl[8];
 #pragma unroll
-                    for (int q8 = 0; q8 < 8; q8++) {
-                        const int e = min(e0 + q8, ev_now - 1);
-                        rec[q8] = ev_ix[e];
-                        dl[q8] = (e0 + q8 < ev_now) ? ev_del[e] : 0.0;
+                        for (int q8 = 0; q8 < 8; q8++) {
+                            const int e = min(e0 + q8, ev_now - 1);
+                            rec[q8] = ev_ix[e];
+                            dl[q8] = (e0 + q8 < ev_now) ? ev_del[e] : 0.0;
+                        }
+#pragma unroll
+                        for (int q8 = 0; q8 < 8; q8++) {
+                            const int slot = __builtin_amdgcn_readfirstlane(rec[q8] >> 16);
+                            const int k = __builtin_amdgcn_readfirstlane(rec[q8] & 0xffff);
+                            if (slot >= 0) gv[q8] = rowc[(size_t)slot * P + t];
+                            else gv[q8] = gp[(size_t)k * P + t];
+                        }
+#pragma unroll
+                        for (int q8 = 0; q8 < 8; q8++) rhs = fma(-(double)gv[q8], dl[q8], rhs);
                     }
-#pragma unroll
-                    for (int q8 = 0; q8 < 8; q8++) {
-                        const int slot = __builtin_amdgcn_readfirstlane(rec[q8] >> 16);
-                        const int k = __builtin_amdgcn_readfirstlane(rec[q8] & 0xffff);
-                        if (slot >= 0) gv[q8] = rowc[(size_t)slot * P + t];
-                        else gv[q8] = gp[(size_t)k * P + t];
-                    }
-#pragma unroll
-                    for (int q8 = 0; q8 < 8; q8++) rhs = fma(-(double)gv[q8], dl[q8], rhs);
+                    // the later sub-blocks have moved: refresh their candidate flags
+                    const unsigned long long c1 = (__ballot(rhs * rhs >= thr[0]) & __ballot(active)) | hmask;
+                    if (lane == 0) cand[wave] = c1 != 0ull;
                 }
+                __syncthreads();
             }
             ev_prev = ev_now;
         }
@@ -950,9 +957,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         if (have_next) {
             if (plin0 >= 0) *reinterpret_cast<int4 *>(rown + plin0) = pre0;
             if (plin1 >= 0) *reinterpret_cast<int4 *>(rown + plin1) = pre1;
-            const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
-            const int covered = (S - 1) * (S - 1) * 2;
-            for (int it = covered + wave; it < n_items; it += S) {
+            if (plin2 >= 0) *reinterpret_cast<int4 *>(rown + plin2) = pre2;
+            if (plin3 >= 0) *reinterpret_cast<int4 *>(rown + plin3) = pre3;
+            for (int it = 4 * S + wave; it < n_items; it += S) { // many hot markers: the rest, synchronously
                 const int lin = min((it << 8) + lane * 4, n_total - 4);
                 *reinterpret_cast<int4 *>(rown + lin) = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[lin >> lgP] << lgP) + (lin & (P - 1)));
             }
@@ -963,14 +970,21 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         }
 
         HB_STAMP(3);
-        // ---- publish the panel's moves: the update kernel of this group is waiting for them. The write-through
-        // stores travel while the per-marker results are written; one drain covers both. ----
+        // ---- publish the panel's moves (the update kernel of this group waits for them). Only the last wave
+        // does it, from the LDS lists: write-through stores now, and the drain + chain_done flag one panel later,
+        // so that no wave of the chain ever waits for a store to reach memory. ----
         const int nev = cnts[0];
-        for (int e = t; e < nev; e += P) {
-            st_sc1(&v.ev_idx[(size_t)p * P + e], ev_ix[e] & 0xffff);
-            st_sc1(&v.ev_delta[(size_t)p * P + e], ev_del[e]);
+        if (wave == S - 1) {
+            if (p > 0) { // the previous panel's stores have had a whole panel to land
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)p);
+            }
+            for (int e = lane; e < nev; e += 64) {
+                st_sc1(&v.ev_idx[(size_t)p * P + e], ev_ix[e] & 0xffff);
+                st_sc1(&v.ev_delta[(size_t)p * P + e], ev_del[e]);
+            }
+            if (lane == 0) st_sc1(&v.ev_count[p], nev);
         }
-        if (t == 0) st_sc1(&v.ev_count[p], nev);
         HB_STAMP(4);
         if (!active) { cls_f = 0; g_f = 0.0; }
         if (g_f != gold) v.g[j] = g_f;
@@ -987,37 +1001,42 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
 #pragma unroll
         for (int c = 0; c <= K1; c++) cacc[c] += (active && cls_f == c) ? 1 : 0;
         evacc = nev + evacc;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)p + 1u);
+        __syncthreads(); // *s_tk
         if (have_next && *s_tk) { // next panel's mat-vec already done: its partials travel while we finish this one
             issue_partials(p + 1);
             n_have_ps = true;
         }
         HB_STAMP(5);
         // ---- fold the moves forward into the corrections of the next Lb panels ----
-        if (nev > 0) {
+        constexpr int FW = (K1 == 1) ? 4 : 2; // moves per batch: all their band blocks are in flight together
+        for (int e0 = 0; e0 < nev; e0 += FW) {
+            int gv[HB_LBMAX][FW];
+            int kk[FW];
+            double dl[FW];
+#pragma unroll
+            for (int q4 = 0; q4 < FW; q4++) {
+                const int e = min(e0 + q4, nev - 1);
+                kk[q4] = ev_ix[e] & 0xffff;
+                dl[q4] = (e0 + q4 < nev) ? ev_del[e] : 0.0;
+            }
 #pragma unroll
             for (int l = 1; l <= HB_LBMAX; l++) {
                 const int q = p + l;
                 // panel q's mat-vec group g = q / D read the residual with every panel < (g - Lv) * D applied
                 const bool need = l <= pv.Lb && q < np && p >= (q / pv.D - pv.Lv) * pv.D;
                 if (need) {
-                    const int32_t *gx = v.gram + ((size_t)q * (pv.Lb + 1) + l) * P * P;
-                    double acc = 0.0;
-                    for (int e0 = 0; e0 < nev; e0 += 8) {
-                        int gv[8];
-                        double dl[8];
+                    const int32_t *gx = v.gram + ((size_t)q * (pv.Lb + 1) + l) * P * P + t;
 #pragma unroll
-                        for (int q8 = 0; q8 < 8; q8++) {
-                            const int e = min(e0 + q8, nev - 1);
-                            gv[q8] = gx[(size_t)(ev_ix[e] & 0xffff) * P + t];
-                            dl[q8] = (e0 + q8 < nev) ? ev_del[e] : 0.0;
-                        }
+                    for (int q4 = 0; q4 < FW; q4++) gv[l - 1][q4] = gx[(size_t)kk[q4] * P];
+                }
+            }
 #pragma unroll
-                        for (int q8 = 0; q8 < 8; q8++) acc = fma((double)gv[q8], dl[q8], acc);
-                    }
-                    corr[l - 1] += acc;
+            for (int l = 1; l <= HB_LBMAX; l++) {
+                const int q = p + l;
+                const bool need = l <= pv.Lb && q < np && p >= (q / pv.D - pv.Lv) * pv.D;
+                if (need) {
+#pragma unroll
+                    for (int q4 = 0; q4 < FW; q4++) corr[l - 1] = fma((double)gv[l - 1][q4], dl[q4], corr[l - 1]);
                 }
             }
         }
@@ -1026,6 +1045,11 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         if (t == 0) cnts[0] = 0;
     }
 
+    // ---- the last panel's moves: drain and publish ----
+    if (wave == S - 1 && ok) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)np);
+    }
     // ---- sweep totals for the hyper-parameter draws ----
     __syncthreads();
     const double wsum = block_sum(wacc, red);
@@ -1782,8 +1806,9 @@ int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out)
     return HB_OK;
 }
 
-// development probe (not part of the ABI): average duration of mat-vec launches of D panels each, back to back
-extern "C" int hbk_dot_bench(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us)
+// hb_ctx_time_matvec: the panel mat-vec launches of one sweep, exactly as the pipeline issues them (same grouping,
+// same arrival counters), back to back on the context's stream between two HIP events
+int hbk_time_matvec(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us, int *launches)
 {
     HB_HIP(hipSetDevice(c->device));
     hipEvent_t e0, e1;
@@ -1804,7 +1829,13 @@ extern "C" int hbk_dot_bench(hb_ctx *c, int D, int reps, int use_ticket, double 
     float ms = 0;
     HB_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = (double)ms * 1e3 / ((double)reps * ngroups);
+    if (launches) *launches = ngroups;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return HB_OK;
+}
+
+extern "C" int hbk_dot_bench(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us)
+{
+    return hbk_time_matvec(c, D, reps, use_ticket, avg_us, nullptr);
 }

@@ -74,6 +74,9 @@ class Context:
         check(self.L.hb_ctx_marker_stats(self.h, xpx.ctypes.data, vx.ctypes.data, C.byref(s), C.byref(z)))
         return xpx, vx, s.value, z.value
 
+    def set_pipeline(self, pipeline=1, lookahead=2, dotgroup=4):
+        check(self.L.hb_ctx_set_pipeline(self.h, pipeline, lookahead, dotgroup))
+
     def build_gram(self):
         s = C.c_double()
         check(self.L.hb_ctx_build_gram(self.h, C.byref(s)))
@@ -181,6 +184,11 @@ class Context:
         check(self.L.hb_ctx_sweep(self.h, C.byref(si), C.byref(so)))
         return {"sum_g2": so.sum_g2, "class_count": np.array(so.class_count[:]), "sum_vargL": so.sum_vargL,
                 "sum_r": so.sum_r, "sum_r2": so.sum_r2, "var_u": so.var_u, "n_events": so.n_events}
+
+    def time_matvec(self, reps=3):
+        ms, nl, nc = C.c_double(), C.c_int32(), C.c_int32()
+        check(self.L.hb_ctx_time_matvec(self.h, reps, C.byref(ms), C.byref(nl), C.byref(nc)))
+        return ms.value, nl.value, nc.value
 
     def set_profiling(self, on):
         check(self.L.hb_ctx_set_profiling(self.h, int(on)))

@@ -225,7 +225,11 @@ int hb_ctx_download_genotype(hb_ctx *c, int8_t *X, int64_t ld, int32_t col0, int
 
 /* xpx_i = sum x^2, vx_i = var(x_i) (N-1), reference src/Bayes.cpp:310-317; integer-exact */
 int hb_ctx_marker_stats(hb_ctx *c, double *xpx, double *vx, double *sumvx, int32_t *nvar0);
-/* per-panel Gram blocks G = X_p' X_p (int32, exact); also reports seconds spent */
+/* Pipeline geometry of the sweep: pipeline 0 = one kernel per step and panel, 1 = persistent
+ * chain workgroup overlapped with the mat-vec stream; `lookahead` mat-vec groups of `dotgroup` panels each run
+ * ahead of the chain. Results do not depend on it (same chain, bit for bit). Invalidates the Gram blocks. */
+int hb_ctx_set_pipeline(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t dotgroup);
+/* per-panel Gram blocks G = X_p' X_p (int32, exact) plus the look-ahead band; also reports seconds spent */
 int hb_ctx_build_gram(hb_ctx *c, double *seconds);
 /* rows x cols window of panel p's Gram (row-major int32, P x P) for exactness tests */
 int hb_ctx_download_gram(hb_ctx *c, int32_t panel_index, int32_t *G);
@@ -295,6 +299,9 @@ typedef struct hb_sweep_timing {
     double other_ms;
 } hb_sweep_timing;
 int hb_ctx_last_timing(hb_ctx *c, hb_sweep_timing *t);
+/* measurement helper: the panel mat-vec launches of one sweep, issued back to back exactly as the sweep issues them
+ * (same columns per launch), timed with HIP events on the context's stream; average milliseconds per launch */
+int hb_ctx_time_matvec(hb_ctx *c, int32_t reps, double *avg_ms, int32_t *launches_per_sweep, int32_t *cols_per_launch);
 int hb_ctx_set_profiling(hb_ctx *c, int32_t on);
 
 #ifdef __cplusplus
