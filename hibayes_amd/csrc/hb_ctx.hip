@@ -113,6 +113,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_PIPELINE")) c->pipeline = atoi(e) ? 1 : 0;
     if (const char *e = getenv("HB_LOOKAHEAD")) c->Lv = atoi(e);
     if (const char *e = getenv("HB_DOTGROUP")) c->D = atoi(e);
+    if (const char *e = getenv("HB_GRAPH")) c->use_graph = atoi(e) != 0;
     c->env_pinned = getenv("HB_PIPELINE") || getenv("HB_LOOKAHEAD") || getenv("HB_DOTGROUP");
     if (!c->pipeline && !getenv("HB_LOOKAHEAD")) c->Lv = 0;
     hb_pipeline_geometry(c);

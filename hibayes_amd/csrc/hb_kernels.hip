@@ -15,6 +15,7 @@
 #include "hb_rng.hpp"
 #include <type_traits>
 #include <algorithm>
+#include <cstdlib>
 
 #define HB_INF __builtin_huge_val()
 
@@ -161,6 +162,80 @@ __global__ __launch_bounds__(256) void k_stats(const int8_t *__restrict__ X, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// residual update: yadj -= sum_e x_e D_e for the markers that moved (shared by k_update and by the extra grid row of
+// the fused mat-vec launch). thread = 4 consecutive rows; the move list is staged in LDS, 8 column loads in flight.
+// ---------------------------------------------------------------------------------------------
+struct upd_view {
+    const int8_t *X;             // base of the genotype matrix
+    int P, p0, p1;               // panels [p0, p1) whose moves are applied (p1 <= p0: nothing to do)
+    const int32_t *ev_count, *ev_idx;
+    const double *ev_delta;
+    const double *r_in;          // residual before, and ...
+    double *r, *u;               // ... after (distinct buffers under look-ahead); u updated in place
+    float *r32;
+    unsigned *flags;             // non-null: wait for chain_done >= p1 first (persistent pipeline)
+};
+
+// rows [row0, row0 + 4) of the residual: yadj -= sum_e x_e D_e, u += the same, r32 = (float)yadj
+__device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int blk, int *s_ix,
+                                            double *s_dl, int *s_ok)
+{
+    const int64_t row0 = ((int64_t)blk * blockDim.x + threadIdx.x) * 4;
+    const bool mine = row0 < ld;
+    // the residual rows do not depend on the chain: fetch them before waiting for it
+    double2 r01 = make_double2(0, 0), r23 = r01, u01 = r01, u23 = r01;
+    if (mine) {
+        r01 = *reinterpret_cast<const double2 *>(q.r_in + row0);
+        r23 = *reinterpret_cast<const double2 *>(q.r_in + row0 + 2);
+        u01 = *reinterpret_cast<const double2 *>(q.u + row0);
+        u23 = *reinterpret_cast<const double2 *>(q.u + row0 + 2);
+    }
+    if (q.flags) { // the chain workgroup publishes a panel's moves and then chain_done = panel + 1
+        if (threadIdx.x == 0) *s_ok = wait_ge(q.flags, HB_FLAG_CHAIN_DONE, (unsigned)q.p1) ? 1 : 0;
+        __syncthreads();
+        if (!*s_ok) return;
+    }
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int total = 0;
+    for (int p = q.p0; p < q.p1; p++) {
+        const int nev = ld_sc1(q.ev_count + p);
+        if (nev == 0) continue; // uniform
+        total += nev;
+        __syncthreads();
+        for (int e = threadIdx.x; e < nev; e += blockDim.x) {
+            s_ix[e] = ld_sc1(q.ev_idx + (size_t)p * q.P + e);
+            s_dl[e] = ld_sc1(q.ev_delta + (size_t)p * q.P + e);
+        }
+        __syncthreads();
+        if (!mine) continue;
+        const int8_t *xp = q.X + (int64_t)p * q.P * ld + row0;
+        for (int e = 0; e < nev; e += 8) {
+            int w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = *reinterpret_cast<const int *>(xp + (int64_t)s_ix[min(e + k, nev - 1)] * ld);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const double d = (e + k < nev) ? s_dl[e + k] : 0.0;
+                a0 = fma((double)(int8_t)(w[k]), d, a0);
+                a1 = fma((double)(int8_t)(w[k] >> 8), d, a1);
+                a2 = fma((double)(int8_t)(w[k] >> 16), d, a2);
+                a3 = fma((double)(int8_t)(w[k] >> 24), d, a3);
+            }
+        }
+    }
+    if (!mine || (total == 0 && q.r_in == q.r)) return;
+    r01.x -= a0; r01.y -= a1; r23.x -= a2; r23.y -= a3;
+    *reinterpret_cast<double2 *>(q.r + row0) = r01;
+    *reinterpret_cast<double2 *>(q.r + row0 + 2) = r23;
+    *reinterpret_cast<float4 *>(q.r32 + row0) = make_float4((float)r01.x, (float)r01.y, (float)r23.x, (float)r23.y);
+    if (total) {
+        u01.x += a0; u01.y += a1; u23.x += a2; u23.y += a3;
+        *reinterpret_cast<double2 *>(q.u + row0) = u01;
+        *reinterpret_cast<double2 *>(q.u + row0 + 2) = u23;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_dot: partial[split][col] = sum over the split's rows of x[row][col] * yadj[row]
 // tile = 8 columns x (256 threads x 16 rows); grid = (ncols/8, nsplit)
 // ---------------------------------------------------------------------------------------------
@@ -176,11 +251,20 @@ __global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64
                                              const float *__restrict__ r32,
                                              const double *__restrict__ r64, int nchunks,
                                              int chunks_per_split, double *__restrict__ partial,
-                                             int pstride, unsigned *__restrict__ ticket)
+                                             int pstride, unsigned *__restrict__ ticket, upd_view uq)
 {
     using acc_t = typename std::conditional<PRECISE, double, float>::type;
     __shared__ acc_t red[4][8];
     const int ct = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
+    if (uq.p1 > uq.p0 && sp == (int)gridDim.y - 1) {
+        // fused launch: the last grid row carries the residual update of an earlier group (its result is the
+        // version the NEXT launch reads), so the pipeline needs no third stream and no cross-stream events
+        __shared__ int s_ix[512];
+        __shared__ double s_dl[512];
+        __shared__ int s_ok;
+        for (int blk = ct; (int64_t)blk * 1024 < ld; blk += gridDim.x) update_rows(ld, uq, blk, s_ix, s_dl, &s_ok);
+        return;
+    }
     const int8_t *xc = X + (int64_t)ct * 8 * ld;
     acc_t acc[8];
 #pragma unroll
@@ -1070,71 +1154,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
 // thread = 4 consecutive rows; the event list is staged in LDS once, then the column loads of 8
 // events are in flight together.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update(const int8_t *__restrict__ X, int64_t ld, int P, int p0, int p1,
-                                                const int32_t *__restrict__ ev_count,
-                                                const int32_t *__restrict__ ev_idx,
-                                                const double *__restrict__ ev_delta,
-                                                const double *__restrict__ r_in, double *__restrict__ r,
-                                                double *__restrict__ u, float *__restrict__ r32,
-                                                unsigned *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_update(int64_t ld, upd_view q)
 {
-    // r_in -> r: the residual with the moves of panels [p0, p1) applied (distinct buffers under look-ahead)
     __shared__ int s_ix[512];
     __shared__ double s_dl[512];
     __shared__ int s_ok;
-    const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const bool mine = row0 < ld;
-    // the residual rows do not depend on the chain: fetch them before waiting for it
-    double2 r01 = make_double2(0, 0), r23 = r01, u01 = r01, u23 = r01;
-    if (mine) {
-        r01 = *reinterpret_cast<const double2 *>(r_in + row0);
-        r23 = *reinterpret_cast<const double2 *>(r_in + row0 + 2);
-        u01 = *reinterpret_cast<const double2 *>(u + row0);
-        u23 = *reinterpret_cast<const double2 *>(u + row0 + 2);
-    }
-    if (flags) { // persistent pipeline: the chain workgroup publishes a panel's moves and then chain_done = panel + 1
-        if (threadIdx.x == 0) s_ok = wait_ge(flags, HB_FLAG_CHAIN_DONE, (unsigned)p1) ? 1 : 0;
-        __syncthreads();
-        if (!s_ok) return;
-    }
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    int total = 0;
-    for (int p = p0; p < p1; p++) {
-        const int nev = ld_sc1(ev_count + p);
-        if (nev == 0) continue; // uniform
-        total += nev;
-        __syncthreads();
-        for (int e = threadIdx.x; e < nev; e += blockDim.x) {
-            s_ix[e] = ld_sc1(ev_idx + (size_t)p * P + e);
-            s_dl[e] = ld_sc1(ev_delta + (size_t)p * P + e);
-        }
-        __syncthreads();
-        if (!mine) continue;
-        const int8_t *xp = X + (int64_t)p * P * ld + row0;
-        for (int e = 0; e < nev; e += 16) {
-            int w[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) w[q] = *reinterpret_cast<const int *>(xp + (int64_t)s_ix[min(e + q, nev - 1)] * ld);
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const double d = (e + q < nev) ? s_dl[e + q] : 0.0;
-                a0 = fma((double)(int8_t)(w[q]), d, a0);
-                a1 = fma((double)(int8_t)(w[q] >> 8), d, a1);
-                a2 = fma((double)(int8_t)(w[q] >> 16), d, a2);
-                a3 = fma((double)(int8_t)(w[q] >> 24), d, a3);
-            }
-        }
-    }
-    if (!mine || (total == 0 && r_in == r)) return;
-    r01.x -= a0; r01.y -= a1; r23.x -= a2; r23.y -= a3;
-    *reinterpret_cast<double2 *>(r + row0) = r01;
-    *reinterpret_cast<double2 *>(r + row0 + 2) = r23;
-    *reinterpret_cast<float4 *>(r32 + row0) = make_float4((float)r01.x, (float)r01.y, (float)r23.x, (float)r23.y);
-    if (total) {
-        u01.x += a0; u01.y += a1; u23.x += a2; u23.y += a3;
-        *reinterpret_cast<double2 *>(u + row0) = u01;
-        *reinterpret_cast<double2 *>(u + row0 + 2) = u23;
-    }
+    update_rows(ld, q, blockIdx.x, s_ix, s_dl, &s_ok);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1419,22 +1444,31 @@ static hipError_t launch_chain(hb_ctx *c, const chain_view &cv, int p, hipStream
 // residual version v (moves of panels <= v applied; v = -1: start of the sweep) lives in slot (v+1) mod NB
 static inline int ver_slot(const hb_ctx *c, int v) { return (v + 1) % c->NB; }
 
-static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, unsigned *ticket = nullptr)
+static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, unsigned *ticket = nullptr,
+                       const upd_view *upd = nullptr)
 {
     if (!st) st = c->stream;
-    const dim3 grid(ncols / 8, c->nsplit), block(256);
+    upd_view uq{};
+    if (upd) uq = *upd;
+    const dim3 grid(ncols / 8, c->nsplit + (uq.p1 > uq.p0 ? 1 : 0)), block(256);
     const int8_t *Xp = c->X + (int64_t)col0 * c->ld;
     double *part = c->partial + col0;
     const float *r32 = c->r32 + (size_t)slot * c->ld;
     const double *r64 = c->r + (size_t)slot * c->ld;
     const bool sgn = c->xmin < 0;
     if (c->precise) {
-        if (sgn) hipLaunchKernelGGL((k_dot<true, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket);
-        else     hipLaunchKernelGGL((k_dot<true, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket);
+        if (sgn) hipLaunchKernelGGL((k_dot<true, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket, uq);
+        else     hipLaunchKernelGGL((k_dot<true, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket, uq);
     } else {
-        if (sgn) hipLaunchKernelGGL((k_dot<false, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket);
-        else     hipLaunchKernelGGL((k_dot<false, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket);
+        if (sgn) hipLaunchKernelGGL((k_dot<false, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket, uq);
+        else     hipLaunchKernelGGL((k_dot<false, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket, uq);
     }
+}
+
+static upd_view make_upd(hb_ctx *c, int p0, int p1, int sin, int sout, unsigned *flags)
+{
+    return upd_view{c->X, c->P, p0, p1, c->ev_count, c->ev_idx, c->ev_delta, c->r + (size_t)sin * c->ld,
+                    c->r + (size_t)sout * c->ld, c->u, c->r32 + (size_t)sout * c->ld, flags};
 }
 
 struct phase_timer {
@@ -1523,9 +1557,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
             b = tm.begin();
             if (!timed) HB_HIP(hipStreamWaitEvent(sC, c->ev_chain[pc], 0));
             const int sin = ver_slot(c, pc - 1), sout = ver_slot(c, pc);
-            hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sC, c->X, c->ld, c->P, pc, pc + 1, c->ev_count, c->ev_idx,
-                               c->ev_delta, c->r + (size_t)sin * c->ld, c->r + (size_t)sout * c->ld, c->u,
-                               c->r32 + (size_t)sout * c->ld, (unsigned *)nullptr);
+            hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sC, c->ld, make_upd(c, pc, pc + 1, sin, sout, nullptr));
             if (!timed) HB_HIP(hipEventRecord(c->ev_upd[pc], sC));
             tm.end(2, b);
         }
@@ -1587,7 +1619,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     const int kp = kpad_for(model, n_fold);
     const int np = c->npanels, D = c->D, Lv = c->Lv;
     const int ngroups = (np + D - 1) / D;
-    hipStream_t sA = c->stream, sB = c->s_chain, sC = c->s_upd;
+    hipStream_t sA = c->stream, sB = c->s_chain;
     HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, sA));
     HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * (HB_FLAG_TICKET0 + HB_NSUB * HB_SUB_STRIDE), sA));
     {
@@ -1598,7 +1630,6 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     hipLaunchKernelGGL(k_hotlist, dim3(np), dim3(c->P), 0, sA, c->vx, c->g, c->P, ns, c->hot_slot, c->hot_list, c->hot_n);
     HB_HIP(hipEventRecord(c->ev_fork, sA));
     HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
-    HB_HIP(hipStreamWaitEvent(sC, c->ev_fork, 0));
     chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg};
@@ -1612,25 +1643,23 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
         if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_persist launch: ") + hipGetErrorString(e));
     }
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
-    // residual versions advance per mat-vec group: version h = every panel of groups <= h applied, slot (h+1) % NB;
-    // mat-vec(g) reads version g - Lv - 1, update(h) is one launch for the D panels of group h.
+    // Residual versions advance per mat-vec group: version h = every panel of groups <= h applied. Mat-vec launch g
+    // reads version g - Lv - 1 and, in one extra grid row, carries update(h = g - Lv): version h-1 -> h, which the
+    // NEXT launch reads. Two buffers ping-pong (slot = (version + 1) & 1). No third stream, no cross-stream events.
+    auto slot2 = [](int v) { return v < 0 ? 0 : ((v + 1) & 1); };
     for (int g = 0; g < ngroups; g++) {
         const int p0 = g * D, p1 = std::min(np, p0 + D);
-        const int vread = g - Lv - 1;
-        if (vread >= 0) HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[vread], 0));
-        launch_dot(c, p0 * c->P, (p1 - p0) * c->P, ver_slot(c, vread < -1 ? -1 : vread), sA, c->flags + HB_FLAG_TICKET0);
-        HB_HIP(hipEventRecord(c->ev_dot[g], sA));
-        HB_HIP(hipStreamWaitEvent(sC, c->ev_dot[g], 0));
-        const int sin = ver_slot(c, g - 1), sout = ver_slot(c, g);
-        hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sC, c->X, c->ld, c->P, p0, p1, c->ev_count, c->ev_idx,
-                           c->ev_delta, c->r + (size_t)sin * c->ld, c->r + (size_t)sout * c->ld, c->u,
-                           c->r32 + (size_t)sout * c->ld, c->flags);
-        HB_HIP(hipEventRecord(c->ev_upd[g], sC));
+        const int h = g - Lv;
+        upd_view uq{};
+        if (h >= 0) uq = make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags);
+        launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, c->flags + HB_FLAG_TICKET0, h >= 0 ? &uq : nullptr);
     }
+    for (int h = std::max(0, ngroups - Lv); h < ngroups; h++) // the updates that had no later mat-vec to ride on
+        hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sA, c->ld,
+                           make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags));
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
-    HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[ngroups - 1], 0));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
-    const int sfin = ver_slot(c, ngroups - 1);
+    const int sfin = slot2(ngroups - 1);
     if (sfin != 0) {
         HB_HIP(hipMemcpyAsync(c->r, c->r + (size_t)sfin * c->ld, sizeof(double) * c->ld, hipMemcpyDeviceToDevice, sA));
         HB_HIP(hipMemcpyAsync(c->r32, c->r32 + (size_t)sfin * c->ld, sizeof(float) * c->ld, hipMemcpyDeviceToDevice, sA));
