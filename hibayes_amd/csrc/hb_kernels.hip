@@ -956,8 +956,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         int cls_f = 0;
         double g_f = 0.0;
         int ev_prev = 0;
+        unsigned cmask = (unsigned)__ballot(lane < S && cand[lane < S ? lane : 0] != 0); // one LDS read for all sub-blocks
         for (int s = 0; s < S; s++) {
-            if (!cand[s]) continue; // uniform: nothing in this sub-block can move, its markers stay at zero
+            if (!((cmask >> s) & 1u)) continue; // uniform: nothing in this sub-block can move, its markers stay at zero
             if (wave == s) {
                 int cnt = cnts[0];
                 int lo = 0;
@@ -1033,24 +1034,17 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                     if (lane == 0) cand[wave] = c1 != 0ull;
                 }
                 __syncthreads();
+                cmask = (unsigned)__ballot(lane < S && cand[lane < S ? lane : 0] != 0);
             }
             ev_prev = ev_now;
         }
         HB_STAMP(2);
         // pieces still in flight + whatever the turn schedule did not cover (many hot markers)
-        if (have_next) {
-            if (plin0 >= 0) *reinterpret_cast<int4 *>(rown + plin0) = pre0;
-            if (plin1 >= 0) *reinterpret_cast<int4 *>(rown + plin1) = pre1;
-            if (plin2 >= 0) *reinterpret_cast<int4 *>(rown + plin2) = pre2;
-            if (plin3 >= 0) *reinterpret_cast<int4 *>(rown + plin3) = pre3;
-            for (int it = 4 * S + wave; it < n_items; it += S) { // many hot markers: the rest, synchronously
-                const int lin = min((it << 8) + lane * 4, n_total - 4);
-                *reinterpret_cast<int4 *>(rown + lin) = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[lin >> lgP] << lgP) + (lin & (P - 1)));
-            }
-            if (wave == 0) {
-                const bool r = ticket_ready(p + 1);
-                if (lane == 0) *s_tk = r ? 1 : 0;
-            }
+        if (have_next && wave == 0) {
+            // the next panel's mat-vec: already known to be complete unless it opens a new group
+            bool r = true;
+            if ((p + 1) % pv.D == 0) r = ticket_ready(p + 1);
+            if (lane == 0) *s_tk = r ? 1 : 0;
         }
 
         HB_STAMP(3);
@@ -1122,6 +1116,16 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
 #pragma unroll
                     for (int q4 = 0; q4 < FW; q4++) corr[l - 1] = fma((double)gv[l - 1][q4], dl[q4], corr[l - 1]);
                 }
+            }
+        }
+        if (have_next) { // the next panel's hot rows: they have had the whole panel to arrive
+            if (plin0 >= 0) *reinterpret_cast<int4 *>(rown + plin0) = pre0;
+            if (plin1 >= 0) *reinterpret_cast<int4 *>(rown + plin1) = pre1;
+            if (plin2 >= 0) *reinterpret_cast<int4 *>(rown + plin2) = pre2;
+            if (plin3 >= 0) *reinterpret_cast<int4 *>(rown + plin3) = pre3;
+            for (int it = 4 * S + wave; it < n_items; it += S) { // many hot markers: the rest, synchronously
+                const int lin = min((it << 8) + lane * 4, n_total - 4);
+                *reinterpret_cast<int4 *>(rown + lin) = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[lin >> lgP] << lgP) + (lin & (P - 1)));
             }
         }
         HB_STAMP(6);
