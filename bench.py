@@ -183,7 +183,7 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
     check(L.hb_run_state(run, ct.byref(info)))
     L.hb_run_destroy(run)
     del keep
-    return elapsed, info.mean_events, info.nnz
+    return elapsed, info.mean_events, info.nnz, info.mean_misses
 
 
 def main():
@@ -223,7 +223,7 @@ def main():
     note("Gram blocks built (%.2fs)" % gram_s)
 
     K, W = args.steps, args.warmup
-    elapsed, mean_events, nnz = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
+    elapsed, mean_events, nnz, misses = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
                                         m_global, comm, torch, note)
     # the dominant kernel on its own: the sweep's mat-vec launches, back to back, HIP events on their stream
     avg_ms, launches, cols = ctx.time_matvec(reps=3)
@@ -253,7 +253,7 @@ def main():
                    "model": args.model, "n": n, "m_per_gpu": m, "m_global": m_global, "panel": ctx.panel,
                    "pipeline": {"persistent_chain": geo[0], "lookahead_groups": geo[1], "panels_per_matvec": geo[2]},
                    "sharding": "markers, contiguous ranges, one residual all-reduce per sweep" if world > 1 else "none",
-                   "mean_changed_markers_per_sweep": mean_events, "NumNZSnp_last": nnz,
+                   "mean_changed_markers_per_sweep": mean_events, "row_cache_misses_per_sweep": misses, "NumNZSnp_last": nnz,
                    "setup_seconds": {"generate": gen_s, "gram": gram_s}},
         "achieved_GBps": value * n * m / 1e9, "achieved_frac_of_hbm_peak": value * n * m / 1e9 / (HBM_PEAK_GBPS * world),
         "roofline": roof,
@@ -265,11 +265,11 @@ def main():
         ctx.build_gram()
         K2, W2 = max(10, K // 4), max(5, min(W, 30))
         y2 = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, args.secondary)
-        el2, ev2, nnz2 = measure(H, L, ctx, y2, args.secondary, K2, W2, args, rank, local_rank, world, m_offset,
+        el2, ev2, nnz2, miss2 = measure(H, L, ctx, y2, args.secondary, K2, W2, args, rank, local_rank, world, m_offset,
                                  m_global, comm, torch, note)
         res["secondary"] = {"model": args.secondary, "value": K2 / el2, "unit": "sweeps/s", "steps": K2, "warmup": W2,
                             "ms_per_step": el2 / K2 * 1e3, "achieved_frac_of_hbm_peak": K2 / el2 * n * m / 1e9 / HBM_PEAK_GBPS,
-                            "mean_changed_markers_per_sweep": ev2, "NumNZSnp_last": nnz2,
+                            "mean_changed_markers_per_sweep": ev2, "row_cache_misses_per_sweep": miss2, "NumNZSnp_last": nnz2,
                             "pipeline": {"persistent_chain": geo2[0], "lookahead_groups": geo2[1], "panels_per_matvec": geo2[2]}}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:

@@ -79,7 +79,7 @@ class RunInfo(C.Structure):
     _fields_ = [
         ("iter", C.c_int32), ("records", C.c_int32), ("nnz", C.c_double),
         ("vara", C.c_double), ("vare", C.c_double), ("varg", C.c_double), ("mu", C.c_double),
-        ("pi", C.c_double * HB_MAX_FOLD), ("mean_events", C.c_double),
+        ("pi", C.c_double * HB_MAX_FOLD), ("mean_events", C.c_double), ("mean_misses", C.c_double), ("mean_redo", C.c_double),
         ("loop_seconds", C.c_double), ("setup_seconds", C.c_double), ("gram_seconds", C.c_double),
     ]
 
@@ -106,6 +106,7 @@ class SweepOut(C.Structure):
     _fields_ = [
         ("sum_g2", C.c_double), ("class_count", C.c_double * HB_MAX_FOLD), ("sum_vargL", C.c_double),
         ("sum_r", C.c_double), ("sum_r2", C.c_double), ("var_u", C.c_double), ("n_events", C.c_double),
+        ("n_cache_miss", C.c_double), ("n_redo", C.c_double),
     ]
 
 

@@ -114,6 +114,8 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_LOOKAHEAD")) c->Lv = atoi(e);
     if (const char *e = getenv("HB_DOTGROUP")) c->D = atoi(e);
     if (const char *e = getenv("HB_GRAPH")) c->use_graph = atoi(e) != 0;
+    if (const char *e = getenv("HB_KAPPA")) c->kappa = atof(e);
+    if (const char *e = getenv("HB_CANDF")) c->candf = std::min(1.0, std::max(0.0, atof(e)));
     c->env_pinned = getenv("HB_PIPELINE") || getenv("HB_LOOKAHEAD") || getenv("HB_DOTGROUP");
     if (!c->pipeline && !getenv("HB_LOOKAHEAD")) c->Lv = 0;
     hb_pipeline_geometry(c);
@@ -651,6 +653,8 @@ int hb_ctx_sweep(hb_ctx *c, const hb_sweep_in *in, hb_sweep_out *out)
     out->sum_r2 = a[HB_ACC_SUMR2];
     out->var_u = a[HB_ACC_VARU];
     out->n_events = a[HB_ACC_EVENTS];
+    out->n_cache_miss = a[HB_ACC_MISS];
+    out->n_redo = a[HB_ACC_REDO];
     return HB_OK;
 }
 
@@ -738,6 +742,16 @@ int hb_ctx_set_profiling(hb_ctx *c, int32_t on)
         HB_HIP(hipMemset(c->dbg, 0, sizeof(long long) * 32 * (size_t)c->npanels));
         c->graph_model = -1;
     }
+    return HB_OK;
+}
+
+// development aid (not in the header): row-cache prediction width and chain-candidate factor
+int hb_ctx_debug_tune(hb_ctx *c, double kappa, double candf)
+{
+    if (!c) return hb_fail(HB_ERR_INVALID, "hb_ctx_debug_tune: null context");
+    c->kappa = kappa;
+    c->candf = std::min(1.0, std::max(0.0, candf));
+    c->graph_model = -1;
     return HB_OK;
 }
 

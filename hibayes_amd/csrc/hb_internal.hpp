@@ -26,6 +26,8 @@ enum {
     HB_ACC_SUMR = 11,
     HB_ACC_SUMR2 = 12,
     HB_ACC_VARU = 13,
+    HB_ACC_MISS = 14, // moves whose Gram row was not in the LDS row cache
+    HB_ACC_REDO = 15, // chain rounds rolled back and repeated (a non-candidate crossed its threshold)
     HB_ACC_N = 16
 };
 
@@ -60,6 +62,8 @@ struct hb_ctx {
     int32_t *gram = nullptr;
     size_t gram_cap = 0; // ints allocated
     bool env_pinned = false;
+    double candf = 0.64; // chain candidates: markers at zero with q >= candf * thr0
+    double kappa = 6.0; // row-cache prediction: markers with thr0 <= kappa * xx * vare get their Gram row prefetched
     bool gram_ready = false, stats_ready = false;
     int *xinfo = nullptr; // device: [0]=min value, [1]=max value over X
     int xmin = 0, xmax = 0;

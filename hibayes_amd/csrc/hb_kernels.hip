@@ -761,19 +761,26 @@ struct persist_view {
     int ngroups;
     unsigned *flags;
     const int *slot_of, *hotlist, *nhot; // per-sweep hot-lists from k_hotlist
+    double candf;                        // a marker at zero is a chain candidate when q >= candf * thr0 (candf <= 1)
 };
 
 #define HB_LBMAX 12
 
-// hot-list of every panel (markers certain to move: polymorphic with g_old != 0), in marker order, capped at
-// nslot rows per panel; produced once per sweep, off the chain's critical path.  One workgroup per panel.
-__global__ __launch_bounds__(512) void k_hotlist(const double *__restrict__ vx, const double *__restrict__ g, int P, int nslot,
+// Row-cache list of every panel, in marker order, capped at nslot rows: the markers that are certain to move
+// (polymorphic, g_old != 0) and the markers that are LIKELY to enter the model this sweep. Entry means q >= thr0
+// with thr0 already fixed by the marker's uniform draw, and a marker at zero has q ~ xx*vare*chi2_1, so
+// "thr0 <= kappa * xx * vare" predicts almost every entry (history does not: re-entry is at chance level).
+// A predicted marker only gets its Gram row prefetched; whether it moves is still decided by the chain.
+// Produced once per sweep, off the chain's critical path. One workgroup per panel.
+__global__ __launch_bounds__(512) void k_hotlist(const hb_sweep_in *__restrict__ pin, const double *__restrict__ vx,
+                                                 const double *__restrict__ g, const double *__restrict__ thr0,
+                                                 const double *__restrict__ xpx, double kappa, int P, int nslot,
                                                  int *__restrict__ slot_of, int *__restrict__ hotlist, int *__restrict__ nhot)
 {
     __shared__ int wcnt[16];
     const int p = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63, S = P >> 6;
     const int j = p * P + t;
-    const bool hot = vx[j] != 0.0 && g[j] != 0.0;
+    const bool hot = vx[j] != 0.0 && (g[j] != 0.0 || thr0[j] <= kappa * xpx[j] * pin->vare);
     const unsigned long long hmask = __ballot(hot);
     if (lane == 0) wcnt[wave] = __popcll(hmask);
     __syncthreads();
@@ -788,6 +795,44 @@ __global__ __launch_bounds__(512) void k_hotlist(const double *__restrict__ vx, 
     slot_of[j] = slot;
     if (slot >= 0) hotlist[(size_t)p * nslot + slot] = t;
     if (t == 0) nhot[p] = min(tot, nslot);
+}
+
+// Forward corrections of one batch shape: FW moves x up to LB band blocks, all loads in flight together.
+template <int LB, int FW>
+__device__ __forceinline__ void fold_forward(double (&corr)[HB_LBMAX], const int32_t *__restrict__ gram, const persist_view &pv, int p, int np,
+                                             int P, int t, int nev, const int *ev_ix, const double *ev_del)
+{
+    for (int e0 = 0; e0 < nev; e0 += FW) {
+        int gv[LB][FW];
+        int kk[FW];
+        double dl[FW];
+#pragma unroll
+        for (int f = 0; f < FW; f++) {
+            const int e = min(e0 + f, nev - 1);
+            kk[f] = ev_ix[e] & 0xffff;
+            dl[f] = (e0 + f < nev) ? ev_del[e] : 0.0;
+        }
+#pragma unroll
+        for (int l = 1; l <= LB; l++) {
+            const int q = p + l;
+            // panel q's mat-vec group g = q / D read the residual with every panel < (g - Lv) * D applied
+            const bool need = l <= pv.Lb && q < np && p >= (q / pv.D - pv.Lv) * pv.D;
+            if (need) {
+                const int32_t *gx = gram + ((size_t)q * (pv.Lb + 1) + l) * P * P + t;
+#pragma unroll
+                for (int f = 0; f < FW; f++) gv[l - 1][f] = gx[(size_t)kk[f] * P];
+            }
+        }
+#pragma unroll
+        for (int l = 1; l <= LB; l++) {
+            const int q = p + l;
+            const bool need = l <= pv.Lb && q < np && p >= (q / pv.D - pv.Lv) * pv.D;
+            if (need) {
+#pragma unroll
+                for (int f = 0; f < FW; f++) corr[l - 1] = fma((double)gv[l - 1][f], dl[f], corr[l - 1]);
+            }
+        }
+    }
 }
 
 // Software-pipelined version: everything panel p+1 needs that does not depend on panel p's outcome is fetched
@@ -810,7 +855,15 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     int *cnts = reinterpret_cast<int *>(base + (size_t)P * 16 + 128);
     int *s_ok = cnts + 16;
     int *s_tk = cnts + 17;
-    int *cand = cnts + 18; // cand[w] != 0: sub-block w holds a marker that may move given the current rhs
+    int *s_thi = cnts + 18;   // first candidate left for the next round
+    int *wcnt = cnts + 32;    // candidates per wave
+    int *wviol = cnts + 48;   // wave saw a mis-speculated marker
+    // staging of one round's candidates (<= 64): [field][candidate]
+    double *cs_d = reinterpret_cast<double *>(base + (size_t)P * 16 + 128 + 256); // rhs, gold, thr[K1], invv[K1], sdz[K1]
+    double *res_g = cs_d + (2 + 3 * K1) * 64;
+    int *cs_t = reinterpret_cast<int *>(res_g + 64);
+    int *cs_slot = cs_t + 64;
+    int *res_c = cs_slot + 64;
 
     const int model = pin->model_index;
     const int count_pip = pin->count_pip, store = pin->store;
@@ -823,7 +876,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     int cacc[K1 + 1];
 #pragma unroll
     for (int c = 0; c <= K1; c++) cacc[c] = 0;
-    int evacc = 0;
+    int evacc = 0, missacc = 0, redoacc = 0;
 
     // ---- "next" registers: filled one panel ahead ----
     double n_vx, n_gold, n_xx, n_thr[K1], n_invv[K1], n_sdz[K1], n_ps[16];
@@ -861,7 +914,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         const bool r = wait_tickets(pv.flags, tickets_after_group(0, pv.ngroups, pv.total_per_group, pv.total_last, lane));
         if (lane == 0) *s_ok = r ? 1 : 0;
     }
-    if (t < 16) cnts[t] = 0;
+    if (t < 64 && t != 16 && t != 17) cnts[t] = 0; // (s_ok / s_tk are being written by wave 0)
     __syncthreads();
     bool ok = *s_ok != 0;
     if (ok) {
@@ -896,6 +949,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
 #pragma unroll
         for (int c = 0; c < K1; c++) { thr[c] = n_thr[c]; invv[c] = n_invv[c]; sdz[c] = n_sdz[c]; }
         const int myslot = n_slot;
+        if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + 11] = n_have_ps ? 0 : 1;
         if (!n_have_ps) { // the mat-vec was not finished when we looked: wait for it now
             if (wave == 0) {
                 const bool r = wait_tickets(pv.flags, tickets_after_group(p / pv.D, pv.ngroups, pv.total_per_group, pv.total_last, lane));
@@ -936,12 +990,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
         int plin0 = -1, plin1 = -1, plin2 = -1, plin3 = -1;
         const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
-        {
-            // a marker at zero moves only if q >= thr[0]; a hot one always moves
-            const unsigned long long c0 = (__ballot(rhs * rhs >= thr[0]) & __ballot(active)) | hmask;
-            if (lane == 0) cand[wave] = c0 != 0ull;
-        }
-        __syncthreads(); // cand[], hl[] staged
+        __syncthreads(); // hl[] staged
         if (have_next) {
             if (wave < n_items) { plin0 = min((wave << 8) + lane * 4, n_total - 4);
                 pre0 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin0 >> lgP] << lgP) + (plin0 & (P - 1))); }
@@ -953,71 +1002,126 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                 pre3 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin3 >> lgP] << lgP) + (plin3 & (P - 1))); }
         }
 
+        HB_STAMP(7);
+        // ---- the serial chain, speculatively compacted ----
+        // Only markers that are in the model (certain to move) or whose q is near their entry threshold can move.
+        // Each round compacts the next <= 64 such candidates, in marker order, into the lanes of wave 0, which runs
+        // the exact serial chain over them alone; every other marker then applies the round's moves to its own rhs
+        // and checks that it really stayed below its threshold. If one did not (a move pushed a non-candidate over),
+        // the round is rolled back and repeated with that marker as a candidate — the outcome is always the exact
+        // sequential one, the speculation only decides how much of it runs in one wave without barriers.
         int cls_f = 0;
         double g_f = 0.0;
-        int ev_prev = 0;
-        unsigned cmask = (unsigned)__ballot(lane < S && cand[lane < S ? lane : 0] != 0); // one LDS read for all sub-blocks
-        for (int s = 0; s < S; s++) {
-            if (!((cmask >> s) & 1u)) continue; // uniform: nothing in this sub-block can move, its markers stay at zero
-            if (wave == s) {
-                int cnt = cnts[0];
-                int lo = 0;
-                unsigned long long hleft = hmask;
-                const unsigned long long amask = __ballot(active);
-                for (;;) {
-                    const int knext = hleft ? (__ffsll((long long)hleft) - 1) : 0;
-                    const int snext = __builtin_amdgcn_readlane(myslot, knext);
-                    int gnext = 0;
-                    if (hleft && snext >= 0) gnext = rowc[(size_t)snext * P + t];
-                    const double q = rhs * rhs;
-                    const unsigned long long live = ~0ull << lo;
-                    const unsigned long long mask = ((__ballot(q >= thr[0]) & amask) | hleft) & live;
-                    if (mask == 0ull) break;
-                    const int k = __ffsll((long long)mask) - 1;
-                    int cls = 0;
-                    double iv = 0.0, sz = 0.0;
+        {
+            int t_lo = 0, nev0 = 0;
+            bool forced = false;
+            for (;;) {
+                const bool undec = t >= t_lo;
+                const bool isc = undec && active && (hot || forced || rhs * rhs >= pv.candf * thr[0]);
+                const unsigned long long cm = __ballot(isc);
+                if (lane == 0) wcnt[wave] = __popcll(cm);
+                __syncthreads();
+                int basec = 0, tot = 0;
+                for (int w = 0; w < S; w++) {
+                    const int c = wcnt[w];
+                    basec += (w < wave) ? c : 0;
+                    tot += c;
+                }
+                if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(8);
+                if (tot == 0) break; // nobody left can move
+                const int rank = basec + __popcll(cm & ((1ull << lane) - 1ull));
+                const bool inr = isc && rank < 64;
+                const int ncr = min(tot, 64);
+                if (isc && rank == 64) *s_thi = t;
+                if (inr) {
+                    cs_d[rank] = rhs;
+                    cs_d[64 + rank] = gold;
 #pragma unroll
                     for (int c = 0; c < K1; c++) {
-                        const bool ge = q >= thr[c];
-                        cls += ge ? 1 : 0;
-                        iv = ge ? invv[c] : iv;
-                        sz = ge ? sdz[c] : sz;
+                        cs_d[(2 + c) * 64 + rank] = thr[c];
+                        cs_d[(2 + K1 + c) * 64 + rank] = invv[c];
+                        cs_d[(2 + 2 * K1 + c) * 64 + rank] = sdz[c];
                     }
-                    double gn = (cls > 0) ? fma(rhs, iv, sz) : 0.0;
-                    if (model == 5 && fabs(gn) < 1e-6) gn = 1e-6;
-                    const double delta = gn - gold;
-                    if (lane == k) { cls_f = cls; g_f = gn; }
-                    const double dk = readlane_f64(delta, k);
-                    const int tk = 64 * s + k;
-                    if (dk != 0.0) {
-                        int gv;
-                        int slot = snext;
-                        if (!(hleft && k == knext)) slot = __builtin_amdgcn_readlane(myslot, k);
-                        if (hleft && k == knext && snext >= 0) gv = gnext;
-                        else if (slot >= 0) gv = rowc[(size_t)slot * P + t];
-                        else gv = gp[(size_t)tk * P + t];
-                        if (lane > k) rhs = fma(-(double)gv, dk, rhs);
-                        if (lane == k) { ev_ix[cnt] = (slot << 16) | tk; ev_del[cnt] = dk; }
-                        cnt++;
-                    }
-                    lo = k + 1;
-                    if (lo >= 64) break;
-                    hleft &= ~((2ull << k) - 1ull);
+                    cs_t[rank] = t;
+                    cs_slot[rank] = myslot;
                 }
-                if (lane == 0) cnts[0] = cnt;
-            }
-            __syncthreads();
-            const int ev_now = cnts[0];
-            if (ev_now > ev_prev) { // uniform
-                if (wave > s) {
-                    for (int e0 = ev_prev; e0 < ev_now; e0 += 8) {
+                __syncthreads();
+                const int t_hi = tot > 64 ? *s_thi : P;
+                if (wave == 0) {
+                    const bool lv = lane < ncr;
+                    double crhs = cs_d[lane];
+                    const double cgold = lv ? cs_d[64 + lane] : 0.0;
+                    double cthr[K1], cinvv[K1], csdz[K1];
+#pragma unroll
+                    for (int c = 0; c < K1; c++) {
+                        cthr[c] = cs_d[(2 + c) * 64 + lane];
+                        cinvv[c] = cs_d[(2 + K1 + c) * 64 + lane];
+                        csdz[c] = cs_d[(2 + 2 * K1 + c) * 64 + lane];
+                    }
+                    const int ct = lv ? cs_t[lane] : 0;
+                    const int cslot = lv ? cs_slot[lane] : -1;
+                    const unsigned long long vmask = __ballot(lv);
+                    unsigned long long hleft = __ballot(lv && cgold != 0.0);
+                    int rc = 0;
+                    double rg = 0.0;
+                    int cnt = nev0, lo = 0;
+                    for (;;) {
+                        const int knext = hleft ? (__ffsll((long long)hleft) - 1) : 0;
+                        const int snext = __builtin_amdgcn_readlane(cslot, knext);
+                        int gnext = 0;
+                        if (hleft && snext >= 0) gnext = rowc[(size_t)snext * P + ct];
+                        const double q = crhs * crhs;
+                        const unsigned long long live = ~0ull << lo;
+                        const unsigned long long mask = ((__ballot(q >= cthr[0]) & vmask) | hleft) & live;
+                        if (mask == 0ull) break;
+                        const int k = __ffsll((long long)mask) - 1;
+                        int cls = 0;
+                        double iv = 0.0, sz = 0.0;
+#pragma unroll
+                        for (int c = 0; c < K1; c++) {
+                            const bool ge = q >= cthr[c];
+                            cls += ge ? 1 : 0;
+                            iv = ge ? cinvv[c] : iv;
+                            sz = ge ? csdz[c] : sz;
+                        }
+                        double gn = (cls > 0) ? fma(crhs, iv, sz) : 0.0;
+                        if (model == 5 && fabs(gn) < 1e-6) gn = 1e-6;
+                        const double delta = gn - cgold;
+                        if (lane == k) { rc = cls; rg = gn; }
+                        const double dk = readlane_f64(delta, k);
+                        if (dk != 0.0) {
+                            const int tk = __builtin_amdgcn_readlane(ct, k);
+                            int gv;
+                            int slot = snext;
+                            if (!(hleft && k == knext)) slot = __builtin_amdgcn_readlane(cslot, k);
+                            if (hleft && k == knext && snext >= 0) gv = gnext;
+                            else if (slot >= 0) gv = rowc[(size_t)slot * P + ct];
+                            else { gv = gp[(size_t)tk * P + ct]; missacc++; }
+                            if (lane > k) crhs = fma(-(double)gv, dk, crhs);
+                            if (lane == k) { ev_ix[cnt] = (slot << 16) | tk; ev_del[cnt] = dk; }
+                            cnt++;
+                        }
+                        lo = k + 1;
+                        if (lo >= 64) break;
+                        hleft &= ~((2ull << k) - 1ull);
+                    }
+                    res_c[lane] = rc;
+                    res_g[lane] = rg;
+                    if (lane == 0) cnts[0] = cnt;
+                }
+                __syncthreads();
+                const int nev1 = cnts[0];
+                // everybody still undecided applies the round's moves (those of earlier markers) to its own rhs
+                double rhs_new = rhs;
+                if (undec && !inr) {
+                    for (int e0 = nev0; e0 < nev1; e0 += 8) {
                         int rec[8], gv[8];
                         double dl[8];
 #pragma unroll
                         for (int q8 = 0; q8 < 8; q8++) {
-                            const int e = min(e0 + q8, ev_now - 1);
+                            const int e = min(e0 + q8, nev1 - 1);
                             rec[q8] = ev_ix[e];
-                            dl[q8] = (e0 + q8 < ev_now) ? ev_del[e] : 0.0;
+                            dl[q8] = ev_del[e];
                         }
 #pragma unroll
                         for (int q8 = 0; q8 < 8; q8++) {
@@ -1027,16 +1131,30 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                             else gv[q8] = gp[(size_t)k * P + t];
                         }
 #pragma unroll
-                        for (int q8 = 0; q8 < 8; q8++) rhs = fma(-(double)gv[q8], dl[q8], rhs);
+                        for (int q8 = 0; q8 < 8; q8++) {
+                            const bool ap = e0 + q8 < nev1 && (rec[q8] & 0xffff) < t;
+                            rhs_new = ap ? fma(-(double)gv[q8], dl[q8], rhs_new) : rhs_new;
+                        }
                     }
-                    // the later sub-blocks have moved: refresh their candidate flags
-                    const unsigned long long c1 = (__ballot(rhs * rhs >= thr[0]) & __ballot(active)) | hmask;
-                    if (lane == 0) cand[wave] = c1 != 0ull;
                 }
+                const bool viol = undec && !inr && t < t_hi && active && rhs_new * rhs_new >= thr[0];
+                const unsigned long long vm = __ballot(viol);
+                if (lane == 0) wviol[wave] = vm != 0ull;
                 __syncthreads();
-                cmask = (unsigned)__ballot(lane < S && cand[lane < S ? lane : 0] != 0);
+                bool anyv = false;
+                for (int w = 0; w < S; w++) anyv |= wviol[w] != 0;
+                if (anyv) { // roll the round back; the markers that crossed their threshold join the candidates
+                    forced |= viol;
+                    if (t == 0) cnts[0] = nev0;
+                    if (t == 0) redoacc++;
+                    continue;
+                }
+                rhs = rhs_new;
+                if (inr) { cls_f = res_c[rank]; g_f = res_g[rank]; }
+                nev0 = nev1;
+                t_lo = t_hi;
+                if (t_lo >= P) break;
             }
-            ev_prev = ev_now;
         }
         HB_STAMP(2);
         // pieces still in flight + whatever the turn schedule did not cover (many hot markers)
@@ -1052,6 +1170,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         // does it, from the LDS lists: write-through stores now, and the drain + chain_done flag one panel later,
         // so that no wave of the chain ever waits for a store to reach memory. ----
         const int nev = cnts[0];
+        if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + 10] = nev;
         if (wave == S - 1) {
             if (p > 0) { // the previous panel's stores have had a whole panel to land
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1086,37 +1205,10 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         }
         HB_STAMP(5);
         // ---- fold the moves forward into the corrections of the next Lb panels ----
-        constexpr int FW = (K1 == 1) ? 4 : 2; // moves per batch: all their band blocks are in flight together
-        for (int e0 = 0; e0 < nev; e0 += FW) {
-            int gv[HB_LBMAX][FW];
-            int kk[FW];
-            double dl[FW];
-#pragma unroll
-            for (int q4 = 0; q4 < FW; q4++) {
-                const int e = min(e0 + q4, nev - 1);
-                kk[q4] = ev_ix[e] & 0xffff;
-                dl[q4] = (e0 + q4 < nev) ? ev_del[e] : 0.0;
-            }
-#pragma unroll
-            for (int l = 1; l <= HB_LBMAX; l++) {
-                const int q = p + l;
-                // panel q's mat-vec group g = q / D read the residual with every panel < (g - Lv) * D applied
-                const bool need = l <= pv.Lb && q < np && p >= (q / pv.D - pv.Lv) * pv.D;
-                if (need) {
-                    const int32_t *gx = v.gram + ((size_t)q * (pv.Lb + 1) + l) * P * P + t;
-#pragma unroll
-                    for (int q4 = 0; q4 < FW; q4++) gv[l - 1][q4] = gx[(size_t)kk[q4] * P];
-                }
-            }
-#pragma unroll
-            for (int l = 1; l <= HB_LBMAX; l++) {
-                const int q = p + l;
-                const bool need = l <= pv.Lb && q < np && p >= (q / pv.D - pv.Lv) * pv.D;
-                if (need) {
-#pragma unroll
-                    for (int q4 = 0; q4 < FW; q4++) corr[l - 1] = fma((double)gv[l - 1][q4], dl[q4], corr[l - 1]);
-                }
-            }
+        if (nev > 0) { // batch shape by band width: as many loads in flight as the registers allow
+            if (pv.Lb <= 2) fold_forward<2, 16>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
+            else if (pv.Lb <= 5) fold_forward<5, 8>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
+            else fold_forward<HB_LBMAX, 4>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
         }
         if (have_next) { // the next panel's hot rows: they have had the whole panel to arrive
             if (plin0 >= 0) *reinterpret_cast<int4 *>(rown + plin0) = pre0;
@@ -1145,12 +1237,20 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         v.acc[HB_ACC_SUMG2] = wsum;
         v.acc[HB_ACC_EVENTS] = (double)evacc;
     }
+    {
+        const double ms = block_sum((double)(lane == 0 ? missacc : 0), red);
+        if (t == 0) v.acc[HB_ACC_MISS] = ms;
+        if (t == 0) v.acc[HB_ACC_REDO] = (double)redoacc;
+    }
 #pragma unroll
     for (int c = 0; c <= K1; c++) {
         const double cs = block_sum((double)cacc[c], red);
         if (t == 0 && c < HB_MAX_FOLD) v.acc[HB_ACC_COUNT0 + c] = cs;
     }
-    if (t == 0 && !ok) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, 0x7fffffffu); // aborted: release every waiter
+    if (t == 0 && !ok) { // aborted: the host must see it (fetch_acc checks the flag), then release every waiter
+        st_flag(pv.flags + HB_FLAG_ABORT, 1u);
+        st_flag(pv.flags + HB_FLAG_CHAIN_DONE, 0x7fffffffu);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1421,7 +1521,8 @@ static inline int kpad_for(int model, int n_fold)
 
 // LDS budget of k_chain: as many Gram rows as fit beside the event lists
 static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128 + 128 + 64)) / ((size_t)P * 4)); }
-static int persist_nslot(int P) { return std::min(P, std::min(160, (int)((160 * 1024 - ((size_t)P * 16 + 128 + 128 + 64)) / ((size_t)P * 8)))); }
+#define HB_PERSIST_FIXED(P) ((size_t)(P) * 16 + 128 + 256 + 64 * (8 * (3 + 3 * 7) + 12))
+static int persist_nslot(int P) { return std::min(P, std::min(160, (int)((160 * 1024 - HB_PERSIST_FIXED(P)) / ((size_t)P * 8)))); }
 // the whole 160 KiB: nothing that needs LDS (mat-vec, update) can then be co-scheduled on the chain's CU
 static size_t persist_smem(int) { return (size_t)160 * 1024; }
 static size_t chain_smem(int P) { return (size_t)chain_nslot(P) * P * 4 + (size_t)P * 16 + 128 + 128 + 64; }
@@ -1631,7 +1732,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
         hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pvw);
     }
     const int ns = persist_nslot(c->P);
-    hipLaunchKernelGGL(k_hotlist, dim3(np), dim3(c->P), 0, sA, c->vx, c->g, c->P, ns, c->hot_slot, c->hot_list, c->hot_n);
+    hipLaunchKernelGGL(k_hotlist, dim3(np), dim3(c->P), 0, sA, c->d_in, c->vx, c->g, c->thr, c->xpx, c->kappa, c->P, ns, c->hot_slot,
+                       c->hot_list, c->hot_n);
     HB_HIP(hipEventRecord(c->ev_fork, sA));
     HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
     chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
@@ -1640,7 +1742,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     const unsigned per_panel = (unsigned)(c->P / 8) * (unsigned)c->nsplit;
     const int last_panels = np - (ngroups - 1) * D;
     persist_view pv{np, D, Lv, c->L, per_panel * (unsigned)D, per_panel * (unsigned)last_panels, ngroups, c->flags,
-                    c->hot_slot, c->hot_list, c->hot_n};
+                    c->hot_slot, c->hot_list, c->hot_n, c->candf};
     {
         hipError_t e = kp == 1 ? launch_chain_persist<1>(c, cv, pv, sB) : kp == 3 ? launch_chain_persist<3>(c, cv, pv, sB)
                                                                                  : launch_chain_persist<7>(c, cv, pv, sB);

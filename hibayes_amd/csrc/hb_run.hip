@@ -81,7 +81,7 @@ struct hb_run {
     double sum_r = 0, sum_r2 = 0;
     int iter = 0, count = 0, nzct = 0;
     long long NnzSnp = 0;
-    double mu_sum = 0, vara_sum = 0, vare_sum = 0, hsq_sum = 0, events_sum = 0;
+    double mu_sum = 0, vara_sum = 0, vare_sum = 0, hsq_sum = 0, events_sum = 0, miss_sum = 0, redo_sum = 0;
     bool done = false;
     double setup_seconds = 0, gram_seconds = 0, loop_seconds = 0;
     // MCMC sample stores kept inside the run (copied out by finish)
@@ -503,11 +503,15 @@ int hb_run::step()
         for (int k = 0; k < HB_MAX_FOLD; k++) so.class_count[k] = c->h_acc[HB_ACC_COUNT0 + k];
         so.sum_vargL = c->h_acc[HB_ACC_SUMVARGL];
         so.n_events = c->h_acc[HB_ACC_EVENTS];
+        so.n_cache_miss = c->h_acc[HB_ACC_MISS];
+        so.n_redo = c->h_acc[HB_ACC_REDO];
         so.sum_r = c->h_acc[HB_ACC_SUMR];
         so.sum_r2 = c->h_acc[HB_ACC_SUMR2];
         so.var_u = c->h_acc[HB_ACC_VARU];
     }
     events_sum += so.n_events;
+    miss_sum += so.n_cache_miss;
+    redo_sum += so.n_redo;
     sum_r = so.sum_r;
     sum_r2 = so.sum_r2;
 
@@ -759,6 +763,8 @@ int hb_run_state(hb_run *r, hb_run_info *info)
     info->mu = r->mu;
     for (int j = 0; j < HB_MAX_FOLD; j++) info->pi[j] = j < r->n_fold ? r->Pi[j] : 0.0;
     info->mean_events = r->iter > 0 ? r->events_sum / r->iter : 0.0;
+    info->mean_misses = r->iter > 0 ? r->miss_sum / r->iter : 0.0;
+    info->mean_redo = r->iter > 0 ? r->redo_sum / r->iter : 0.0;
     info->loop_seconds = r->loop_seconds;
     info->setup_seconds = r->setup_seconds;
     info->gram_seconds = r->gram_seconds;

@@ -179,6 +179,8 @@ typedef struct hb_run_info {
     double vara, vare, varg, mu;
     double pi[HB_MAX_FOLD];
     double mean_events;      /* mean markers changed per sweep so far */
+    double mean_misses;      /* mean row-cache misses per sweep so far */
+    double mean_redo;        /* mean rolled-back chain rounds per sweep so far */
     double loop_seconds, setup_seconds, gram_seconds;
 } hb_run_info;
 int hb_run_create(const hb_bayes_args *args, hb_run **out);
@@ -281,6 +283,8 @@ typedef struct hb_sweep_out {
     double sum_r, sum_r2;     /* over yadj after the sweep                                   */
     double var_u;             /* var(u), N-1                                                 */
     double n_events;          /* markers whose effect changed                                */
+    double n_cache_miss;      /* ... of which the Gram row was not in the chain's LDS row cache */
+    double n_redo;            /* speculative chain rounds that were rolled back and repeated    */
 } hb_sweep_out;
 
 int hb_ctx_sweep(hb_ctx *c, const hb_sweep_in *in, hb_sweep_out *out);

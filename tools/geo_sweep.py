@@ -1,0 +1,48 @@
+"""Development aid: burn a run in to steady state once, then time sweeps under several pipeline geometries.
+usage: geo_sweep.py n m model burn panel "Lv,D Lv,D ..." [sweeps]"""
+import sys, os, ctypes as ct, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import hibayes_amd as H
+from hibayes_amd._lib import check, BayesArgs, RunInfo
+import bench
+n, m = int(sys.argv[1]), int(sys.argv[2]); model = sys.argv[3]; burn = int(sys.argv[4]); panel = int(sys.argv[5])
+geos = [tuple(int(v) for v in g.split(",")) for g in sys.argv[6].split()]
+K = int(sys.argv[7]) if len(sys.argv) > 7 else 60
+c = H.Context(n, m, panel=panel); c.set_pipeline(1, *geos[0]); c.generate(20240901, 1000)
+y = bench.synth_phenotype(c, n, m, 0, m, 20240901, None, model)
+Pi, fold = ([0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2]) if model == "BayesR" else ([0.95, 0.05], None)
+a = BayesArgs(); a.n, a.m = n, m; yv = np.ascontiguousarray(y); a.y = yv.ctypes.data; a.model = model.encode()
+pv = np.array(Pi); a.Pi, a.n_pi = pv.ctypes.data, pv.size
+if fold: fv = np.array(fold, dtype=float); a.fold, a.n_fold = fv.ctypes.data, fv.size
+a.niter, a.nburn, a.thin = burn + (K + 20) * len(geos) * 12 + 5, 0, 5; a.seed = 1; a.ctx = c.h
+run = ct.c_void_p(); check(c.L.hb_run_create(ct.byref(a), ct.byref(run)))
+fin = ct.c_int32(); info = RunInfo()
+t0 = time.time(); check(c.L.hb_run_step(run, burn, ct.byref(fin))); print("burn %d sweeps %.1f s" % (burn, time.time() - t0), flush=True)
+tunes = [tuple(float(v) for v in g.split(",")) for g in os.environ.get("TUNES", "6,0.64").split()]
+c.L.hb_ctx_debug_tune.argtypes = [ct.c_void_p, ct.c_double, ct.c_double]
+for tune in tunes:
+    for geo in geos:
+        c.set_pipeline(1, *geo); c.build_gram(); check(c.L.hb_ctx_debug_tune(c.h, *tune)); print("kappa,candf", tune, end=" ")
+        check(c.L.hb_run_step(run, 20, ct.byref(fin)))
+        check(c.L.hb_run_state(run, ct.byref(info))); e0, m0, i0, r0 = info.mean_events * info.iter, info.mean_misses * info.iter, info.iter, info.mean_redo * info.iter
+        t0 = time.time(); check(c.L.hb_run_step(run, K, ct.byref(fin))); dt = time.time() - t0
+        check(c.L.hb_run_state(run, ct.byref(info)))
+        print("P %d geo %s: %.3f ms/sweep (%.1f sweeps/s) moves %.0f misses %.0f redo %.1f nnz %d" % (
+            panel, geo, dt / K * 1e3, K / dt, (info.mean_events * info.iter - e0) / K, (info.mean_misses * info.iter - m0) / K, (info.mean_redo * info.iter - r0) / K, info.nnz), flush=True)
+if os.environ.get("STAMPS"):
+    P = c.panel; npan = (m + P - 1) // P
+    c.set_profiling(2); check(c.L.hb_run_step(run, 3, ct.byref(fin)))
+    st = np.zeros((npan, 32), dtype=np.int64)
+    c.L.hb_ctx_debug_stamps.argtypes = [ct.c_void_p, ct.c_void_p]; check(c.L.hb_ctx_debug_stamps(c.h, st.ctypes.data))
+    dd = np.diff(st[5:-2, :7], axis=1); per = np.diff(st[5:-1, 0])
+    names = ["take", "prefetch-issue", "turns", "tail", "publish", "results", "fwd+landing"]
+    print("phase mean cycles:", {names[i]: int(dd[:, i].mean()) for i in range(6)}, "loop-top gap", int((per - dd.sum(1)).mean()), "per panel", int(per.mean()), "-> us %.2f" % (per.mean() / 2100.))
+    a = st[5:-2]
+    print("fine: 1->7 (issue next) %d, 7->8 (first ballot+barrier) %d, 8->2 (rounds) %d; moves/panel %.2f; waited-for-matvec frac %.3f" % (
+        (a[:, 7] - a[:, 1]).mean(), (a[:, 8] - a[:, 7]).mean(), (a[:, 2] - a[:, 8]).mean(), a[:, 10].mean(), a[:, 11].mean()))
+    nm = a[:, 10]
+    for lo, hi in ((0, 0), (1, 1), (2, 3), (4, 7), (8, 15), (16, 1000)):
+        sel = (nm >= lo) & (nm <= hi)
+        if sel.sum(): print("  moves %d-%d: %d panels, rounds phase %d cyc, whole panel %d cyc, take %d" % (lo, hi, sel.sum(), (a[sel, 2] - a[sel, 8]).mean(), per[:len(sel)][sel[:len(per)]].mean(), (a[sel,1]-a[sel,0]).mean()))
+    print("phase median cycles:", {names[i]: int(np.median(dd[:, i])) for i in range(6)}, "per panel", int(np.median(per)))
