@@ -115,6 +115,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_DOTGROUP")) c->D = atoi(e);
     if (const char *e = getenv("HB_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char *e = getenv("HB_KAPPA")) c->kappa = atof(e);
+    if (const char *e = getenv("HB_DOT_LDS")) c->dot_lds = std::min(65536, std::max(0, atoi(e)));
     if (const char *e = getenv("HB_CANDF")) c->candf = std::min(1.0, std::max(0.0, atof(e)));
     c->env_pinned = getenv("HB_PIPELINE") || getenv("HB_LOOKAHEAD") || getenv("HB_DOTGROUP");
     if (!c->pipeline && !getenv("HB_LOOKAHEAD")) c->Lv = 0;
@@ -170,6 +171,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->invv, mp * (HB_MAX_FOLD - 1)));
     TRY(dev_alloc(&c->sdz, mp * (HB_MAX_FOLD - 1)));
     TRY(dev_alloc(&c->partial, mp * (size_t)c->nsplit));
+    TRY(dev_alloc(&c->dsum, mp));
     TRY(dev_alloc(&c->dots, mp));
     TRY(dev_alloc(&c->ev_count, (size_t)c->npanels));
     TRY(dev_alloc(&c->ev_idx, mp));
@@ -210,7 +212,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
     void *ptrs[] = {c->X, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
-                    c->r32, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dots, c->ev_count, c->ev_idx,
+                    c->r32, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->dots, c->ev_count, c->ev_idx,
                     c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -62,6 +62,7 @@ struct hb_ctx {
     int32_t *gram = nullptr;
     size_t gram_cap = 0; // ints allocated
     bool env_pinned = false;
+    int dot_lds = 0;     // dynamic LDS bytes requested by each mat-vec workgroup: caps the workgroups resident per CU
     double candf = 0.64; // chain candidates: markers at zero with q >= candf * thr0
     double kappa = 6.0; // row-cache prediction: markers with thr0 <= kappa * xx * vare get their Gram row prefetched
     bool gram_ready = false, stats_ready = false;
@@ -70,6 +71,7 @@ struct hb_ctx {
 
     double *thr = nullptr, *invv = nullptr, *sdz = nullptr; // (HB_MAX_FOLD-1) x m_pad each
     double *partial = nullptr;                              // nsplit x m_pad
+    double *dsum = nullptr;                                 // m_pad: the partials added up (by the next mat-vec launch)
     double *dots = nullptr;                                 // m_pad (hb_ctx_dot)
     int nchunks = 0, nsplit = 0;
     int32_t *ev_count = nullptr, *ev_idx = nullptr;

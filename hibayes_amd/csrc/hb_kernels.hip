@@ -239,6 +239,34 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
 // k_dot: partial[split][col] = sum over the split's rows of x[row][col] * yadj[row]
 // tile = 8 columns x (256 threads x 16 rows); grid = (ncols/8, nsplit)
 // ---------------------------------------------------------------------------------------------
+// Pipeline hand-off of a mat-vec launch (all null / 0 outside the pipeline). The split partials of a launch are
+// added up by the FIRST grid row of the NEXT launch (the kernel boundary makes them visible: no per-tile atomics, no
+// write-through stores and no reduction tail in the streaming workgroups); only those few reducing workgroups report
+// to the group's arrival counters, after their sums are in memory. The chain workgroup then reads 8 bytes per marker.
+struct dot_sync {
+    unsigned *ticket;          // 32 arrival counters (cumulative over the sweep's groups)
+    const double *red_partial; // [split][pstride] partials of the previous launch's columns
+    double *red_dsum;          // their sums
+    int red_ncols;             // 0: nothing to reduce in this launch
+    int nsplit;
+};
+
+__device__ __forceinline__ void reduce_partials(const dot_sync &sy, int pstride, int blk, int tid)
+{
+    if (blk * 256 >= sy.red_ncols) return;
+    const int col = blk * 256 + tid;
+    if (col < sy.red_ncols) {
+        double tot = 0.0;
+        for (int q = 0; q < sy.nsplit; q++) tot += sy.red_partial[(int64_t)q * pstride + col]; // split order: a fixed sum
+        st_sc1(&sy.red_dsum[col], tot); // write-through: read by the chain workgroup
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads(); // every wave's sums are in memory
+    if (tid == 0) __hip_atomic_fetch_add(sy.ticket + ((unsigned)blk % HB_NSUB) * HB_SUB_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials(dot_sync sy, int pstride) { reduce_partials(sy, pstride, blockIdx.x, threadIdx.x); }
+
 template <bool SIGNED>
 __device__ __forceinline__ float b2f(unsigned w, int b)
 {
@@ -251,12 +279,20 @@ __global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64
                                              const float *__restrict__ r32,
                                              const double *__restrict__ r64, int nchunks,
                                              int chunks_per_split, double *__restrict__ partial,
-                                             int pstride, unsigned *__restrict__ ticket, upd_view uq)
+                                             int pstride, dot_sync sy, upd_view uq)
 {
     using acc_t = typename std::conditional<PRECISE, double, float>::type;
     __shared__ acc_t red[4][8];
-    const int ct = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
-    if (uq.p1 > uq.p0 && sp == (int)gridDim.y - 1) {
+    const int ct = blockIdx.x, tid = threadIdx.x;
+    int sp = blockIdx.y;
+    if (sy.red_ncols > 0) { // first grid row: add up the previous launch's partials
+        if (sp == 0) {
+            reduce_partials(sy, pstride, ct, tid);
+            return;
+        }
+        sp -= 1;
+    }
+    if (uq.p1 > uq.p0 && blockIdx.y == gridDim.y - 1) {
         // fused launch: the last grid row carries the residual update of an earlier group (its result is the
         // version the NEXT launch reads), so the pipeline needs no third stream and no cross-stream events
         __shared__ int s_ix[512];
@@ -315,14 +351,7 @@ __global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64
     __syncthreads();
     if (tid < 8) {
         const acc_t s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-        st_sc1(&partial[(int64_t)sp * pstride + ct * 8 + tid], (double)s); // write-through: read by the chain workgroup
-    }
-    if (ticket && tid < 64) { // this wave made the stores: drain them, then count this workgroup in.
-        // A single arrival word would serialise ~12 ns per workgroup at its L2 channel (measured: it doubled the
-        // kernel time); 32 words on 32 different lines take the arrivals in parallel.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned id = blockIdx.x + blockIdx.y * gridDim.x;
-        if (tid == 0) __hip_atomic_fetch_add(ticket + (id % HB_NSUB) * HB_SUB_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        partial[(int64_t)sp * pstride + ct * 8 + tid] = (double)s;
     }
 }
 
@@ -488,7 +517,8 @@ struct chain_view {
     double *alpha_sum, *alpha_sq;
     const double *thr, *invv, *sdz;
     const int32_t *gram;
-    const double *partial;
+    const double *partial; // [split][m_pad] (serial pipeline)
+    const double *dsum;    // [m_pad] reduced by the mat-vec itself (persistent pipeline)
     int32_t *ev_count, *ev_idx;
     double *ev_delta;
     double *acc;
@@ -850,16 +880,17 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     char *base = smem + (size_t)2 * nslot * P * 4;
     double *ev_del = reinterpret_cast<double *>(base);
     int *ev_ix = reinterpret_cast<int *>(base + (size_t)P * 8);
-    int *hl = reinterpret_cast<int *>(base + (size_t)P * 12);                 // hot-list of the panel being prefetched
-    double *red = reinterpret_cast<double *>(base + (size_t)P * 16);
-    int *cnts = reinterpret_cast<int *>(base + (size_t)P * 16 + 128);
+    int *hl0 = reinterpret_cast<int *>(base + (size_t)P * 12);                // hot-lists being prefetched, by panel parity
+    double *red = reinterpret_cast<double *>(base + (size_t)P * 20);
+    int *cnts = reinterpret_cast<int *>(base + (size_t)P * 20 + 128);
     int *s_ok = cnts + 16;
     int *s_tk = cnts + 17;
     int *s_thi = cnts + 18;   // first candidate left for the next round
-    int *wcnt = cnts + 32;    // candidates per wave
+    int *s_nh0 = cnts + 19;   // [2] hot rows of the panel being prefetched, by panel parity
+    int *wcnt0 = cnts + 32;   // candidates per wave: [32..47] even panels, [64..79] odd panels
     int *wviol = cnts + 48;   // wave saw a mis-speculated marker
     // staging of one round's candidates (<= 64): [field][candidate]
-    double *cs_d = reinterpret_cast<double *>(base + (size_t)P * 16 + 128 + 256); // rhs, gold, thr[K1], invv[K1], sdz[K1]
+    double *cs_d = reinterpret_cast<double *>(base + (size_t)P * 20 + 128 + 512); // rhs, gold, thr[K1], invv[K1], sdz[K1]
     double *res_g = cs_d + (2 + 3 * K1) * 64;
     int *cs_t = reinterpret_cast<int *>(res_g + 64);
     int *cs_slot = cs_t + 64;
@@ -879,9 +910,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     int evacc = 0, missacc = 0, redoacc = 0;
 
     // ---- "next" registers: filled one panel ahead ----
-    double n_vx, n_gold, n_xx, n_thr[K1], n_invv[K1], n_sdz[K1], n_ps[16];
+    double n_vx, n_gold, n_xx, n_thr[K1], n_invv[K1], n_sdz[K1], n_d = 0.0;
     int n_slot, n_nhot = 0;
-    int hl_reg = 0, nh_reg = 0; // hot-list entry / count two panels ahead (landed by the time they are stored)
+    // hot-list entry / count two panels ahead (landed by the time they are stored). The count is loaded by thread 0
+    // alone and travels through LDS: a wave-uniform load would be waited for on the spot (s_waitcnt vmcnt(0) +
+    // readfirstlane), draining every prefetch issued before it.
+    int hl_reg = 0, nh_reg = 0;
     bool n_have_ps = false;
     auto issue_static = [&](int q) { // coefficients of panel q -> next registers (plain loads, fixed before the sweep)
         const int jq = q * P + t;
@@ -896,11 +930,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         }
         n_slot = pv.slot_of[jq];
     };
-    auto issue_partials = [&](int q) { // write-through by the mat-vec workgroups: read with sc1 loads
-        const int jq = q * P + t;
-        const int last = v.nsplit - 1;
-#pragma unroll
-        for (int sp = 0; sp < 16; sp++) n_ps[sp] = ld_sc1(&v.partial[(size_t)min(sp, last) * v.m_pad + jq]);
+    auto issue_partials = [&](int q) { // x_j . yadj, reduced and written through by the mat-vec: read with an sc1 load
+        n_d = ld_sc1(&v.dsum[q * P + t]);
     };
     auto ticket_ready = [&](int q) -> bool { // wave 0, non-blocking
         const unsigned want = tickets_after_group(q / pv.D, pv.ngroups, pv.total_per_group, pv.total_last, lane);
@@ -914,7 +945,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         const bool r = wait_tickets(pv.flags, tickets_after_group(0, pv.ngroups, pv.total_per_group, pv.total_last, lane));
         if (lane == 0) *s_ok = r ? 1 : 0;
     }
-    if (t < 64 && t != 16 && t != 17) cnts[t] = 0; // (s_ok / s_tk are being written by wave 0)
+    if (t < 128 && t != 16 && t != 17) cnts[t] = 0; // (s_ok / s_tk are being written by wave 0)
     __syncthreads();
     bool ok = *s_ok != 0;
     if (ok) {
@@ -932,7 +963,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     }
     if (np > 1) {
         if (t < nslot) hl_reg = pv.hotlist[(size_t)nslot + t];
-        nh_reg = pv.nhot[1];
+        if (t == 0) nh_reg = pv.nhot[1];
     }
     __syncthreads();
 
@@ -942,6 +973,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         int32_t *rowc = rowc0 + (size_t)cur * nslot * P;
         int32_t *rown = rowc0 + (size_t)(cur ^ 1) * nslot * P;
         const int32_t *gp = v.gram + (size_t)p * (pv.Lb + 1) * P * P;
+        int *hl = hl0 + (size_t)cur * P, *s_nh = s_nh0 + cur, *wcnt = wcnt0 + (cur << 5);
         HB_STAMP(0);
         // ---- take over the prefetched panel ----
         const double vxj = n_vx, gold = n_gold, xx = n_xx;
@@ -959,10 +991,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             if (!*s_ok) { ok = false; break; }
             issue_partials(p);
         }
-        double rhs = 0.0;
-#pragma unroll
-        for (int sp = 0; sp < 16; sp++) rhs += (sp < v.nsplit) ? n_ps[sp] : 0.0;
-        for (int sp = 16; sp < v.nsplit; sp++) rhs += ld_sc1(&v.partial[(size_t)sp * v.m_pad + j]);
+        double rhs = n_d;
         if (gold != 0.0) rhs = fma(xx, gold, rhs);
         rhs -= corr[0];
 #pragma unroll
@@ -970,27 +999,46 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         corr[HB_LBMAX - 1] = 0.0;
         const bool active = vxj != 0.0;
         const bool hot = active && gold != 0.0;
-        const unsigned long long hmask = __ballot(hot);
-
+        if (wave == S - 1 && p > 0) {
+            // the previous panel's moves were stored a whole panel ago, and every load this wave had in flight has
+            // just been consumed: the drain is free here, unlike anywhere after the next prefetches are issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)p);
+        }
+        {   // who can move at all: certain movers and markers near their entry threshold (first round of the chain)
+            const unsigned long long cm0 = __ballot(active && (hot || rhs * rhs >= pv.candf * thr[0]));
+            if (lane == 0) wcnt[wave] = __popcll(cm0);
+        }
         HB_STAMP(1);
-        // ---- start fetching panel p+1 ----
+        // ---- start fetching panel p+1 (everything here is issued, nothing waited for) ----
         const bool have_next = p + 1 < np;
+        const bool tk_new_group = have_next && (p + 1) % pv.D == 0;
         n_have_ps = false;
         const int32_t *gpn = gp + (size_t)(pv.Lb + 1) * P * P;
+        unsigned tk_got = 0xffffffffu;
         if (have_next) {
+            if (t < nslot) hl[t] = hl_reg; // fetched one panel ago: consumed before anything new is issued
+            if (t == 0) *s_nh = nh_reg;
             issue_static(p + 1);
-            if (t < nslot) hl[t] = hl_reg; // fetched one panel ago
-            n_nhot = nh_reg;
             if (p + 2 < np) {
                 if (t < nslot) hl_reg = pv.hotlist[(size_t)(p + 2) * nslot + t];
-                nh_reg = pv.nhot[p + 2];
+                if (t == 0) nh_reg = pv.nhot[p + 2];
+            }
+            if (!tk_new_group) { // same mat-vec launch as this panel: known to be complete
+                issue_partials(p + 1);
+                n_have_ps = true;
+            } else if (wave == 0 && lane < HB_NSUB) { // look at the next launch's arrivals now, use the answer later
+                tk_got = ld_flag(pv.flags + HB_FLAG_TICKET0 + lane * HB_SUB_STRIDE);
             }
         }
-        // Gram rows of the next panel's hot markers: four 1-KiB pieces per wave travel during the turns
+        __syncthreads(); // the panel's one fixed barrier: wcnt[], hl[], *s_nh staged; everybody is done with panel p-1
+        int tot0 = 0;
+        for (int w = 0; w < S; w++) tot0 += wcnt[w];
+        if (have_next) n_nhot = *s_nh;
+        const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
+        // Gram rows of the next panel's hot markers: four 1-KiB pieces per wave travel during the rounds
         int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
         int plin0 = -1, plin1 = -1, plin2 = -1, plin3 = -1;
-        const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
-        __syncthreads(); // hl[] staged
         if (have_next) {
             if (wave < n_items) { plin0 = min((wave << 8) + lane * 4, n_total - 4);
                 pre0 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin0 >> lgP] << lgP) + (plin0 & (P - 1))); }
@@ -1001,8 +1049,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             if (wave + 3 * S < n_items) { plin3 = min(((wave + 3 * S) << 8) + lane * 4, n_total - 4);
                 pre3 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin3 >> lgP] << lgP) + (plin3 & (P - 1))); }
         }
-
         HB_STAMP(7);
+
         // ---- the serial chain, speculatively compacted ----
         // Only markers that are in the model (certain to move) or whose q is near their entry threshold can move.
         // Each round compacts the next <= 64 such candidates, in marker order, into the lanes of wave 0, which runs
@@ -1012,22 +1060,26 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         // sequential one, the speculation only decides how much of it runs in one wave without barriers.
         int cls_f = 0;
         double g_f = 0.0;
-        {
+        int nev = 0;
+        if (tot0 > 0) {
             int t_lo = 0, nev0 = 0;
             bool forced = false;
+            bool first = true; // the first round's candidate counts were staged before the panel's opening barrier
             for (;;) {
                 const bool undec = t >= t_lo;
                 const bool isc = undec && active && (hot || forced || rhs * rhs >= pv.candf * thr[0]);
                 const unsigned long long cm = __ballot(isc);
-                if (lane == 0) wcnt[wave] = __popcll(cm);
-                __syncthreads();
+                if (!first) {
+                    if (lane == 0) wcnt[wave] = __popcll(cm);
+                    __syncthreads();
+                }
+                first = false;
                 int basec = 0, tot = 0;
                 for (int w = 0; w < S; w++) {
                     const int c = wcnt[w];
                     basec += (w < wave) ? c : 0;
                     tot += c;
                 }
-                if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(8);
                 if (tot == 0) break; // nobody left can move
                 const int rank = basec + __popcll(cm & ((1ull << lane) - 1ull));
                 const bool inr = isc && rank < 64;
@@ -1155,74 +1207,91 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                 t_lo = t_hi;
                 if (t_lo >= P) break;
             }
+            nev = cnts[0];
         }
         HB_STAMP(2);
-        // pieces still in flight + whatever the turn schedule did not cover (many hot markers)
-        if (have_next && wave == 0) {
-            // the next panel's mat-vec: already known to be complete unless it opens a new group
-            bool r = true;
-            if ((p + 1) % pv.D == 0) r = ticket_ready(p + 1);
-            if (lane == 0) *s_tk = r ? 1 : 0;
-        }
-
-        HB_STAMP(3);
-        // ---- publish the panel's moves (the update kernel of this group waits for them). Only the last wave
-        // does it, from the LDS lists: write-through stores now, and the drain + chain_done flag one panel later,
-        // so that no wave of the chain ever waits for a store to reach memory. ----
-        const int nev = cnts[0];
         if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + 10] = nev;
-        if (wave == S - 1) {
-            if (p > 0) { // the previous panel's stores have had a whole panel to land
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)p);
+        if (tk_new_group) { // the next panel opens a new mat-vec launch: has it arrived?
+            if (wave == 0) {
+                const unsigned want = tickets_after_group((p + 1) / pv.D, pv.ngroups, pv.total_per_group, pv.total_last, lane);
+                bool r = __all(lane >= HB_NSUB || tk_got >= want);
+                if (!r) r = ticket_ready(p + 1); // not yet when we looked: look again
+                if (lane == 0) *s_tk = r ? 1 : 0;
             }
-            for (int e = lane; e < nev; e += 64) {
-                st_sc1(&v.ev_idx[(size_t)p * P + e], ev_ix[e] & 0xffff);
-                st_sc1(&v.ev_delta[(size_t)p * P + e], ev_del[e]);
+            __syncthreads();
+            if (*s_tk) { // its reduced dots travel while we finish this panel
+                issue_partials(p + 1);
+                n_have_ps = true;
             }
-            if (lane == 0) st_sc1(&v.ev_count[p], nev);
         }
-        HB_STAMP(4);
-        if (!active) { cls_f = 0; g_f = 0.0; }
-        if (g_f != gold) v.g[j] = g_f;
-        v.tracker[j] = (uint8_t)cls_f;
-        if (count_pip && cls_f != 0) {
-            v.nzrate[j] += 1u;
-            if (v.wind) v.wflag[v.wind[j] - 1u] = 1;
-        }
-        if (store && g_f != 0.0) {
-            v.alpha_sum[j] += g_f;
-            v.alpha_sq[j] += g_f * g_f;
-        }
-        if (cls_f > 0) wacc += (model == 6) ? g_f * g_f / pin->fold[cls_f] : g_f * g_f;
+        HB_STAMP(3);
+        if (tot0 > 0) {
+            // ---- publish the panel's moves (the update of this group waits for them). Only the last wave does it,
+            // from the LDS lists: write-through stores now; the drain + chain_done flag at the next panel's take, so
+            // that no wave of the chain ever waits for a store to reach memory. A quiet panel keeps the zero count
+            // the sweep started with. ----
+            if (wave == S - 1 && nev > 0) {
+                for (int e = lane; e < nev; e += 64) {
+                    st_sc1(&v.ev_idx[(size_t)p * P + e], ev_ix[e] & 0xffff);
+                    st_sc1(&v.ev_delta[(size_t)p * P + e], ev_del[e]);
+                }
+                if (lane == 0) st_sc1(&v.ev_count[p], nev);
+            }
+            HB_STAMP(4);
+            if (!active) { cls_f = 0; g_f = 0.0; }
+            if (g_f != gold) v.g[j] = g_f;
+            if (hot || cls_f != 0) v.tracker[j] = (uint8_t)cls_f; // a marker at zero that stays there keeps its 0
+            if (count_pip && cls_f != 0) {
+                v.nzrate[j] += 1u;
+                if (v.wind) v.wflag[v.wind[j] - 1u] = 1;
+            }
+            if (store && g_f != 0.0) {
+                v.alpha_sum[j] += g_f;
+                v.alpha_sq[j] += g_f * g_f;
+            }
+            if (cls_f > 0) wacc += (model == 6) ? g_f * g_f / pin->fold[cls_f] : g_f * g_f;
 #pragma unroll
-        for (int c = 0; c <= K1; c++) cacc[c] += (active && cls_f == c) ? 1 : 0;
-        evacc = nev + evacc;
-        __syncthreads(); // *s_tk
-        if (have_next && *s_tk) { // next panel's mat-vec already done: its partials travel while we finish this one
-            issue_partials(p + 1);
-            n_have_ps = true;
+            for (int c = 0; c <= K1; c++) cacc[c] += (active && cls_f == c) ? 1 : 0;
+            evacc = nev + evacc;
+            HB_STAMP(5);
+            // ---- fold the moves forward into the corrections of the next Lb panels ----
+            if (nev > 0) { // batch shape by band width: as many loads in flight as the registers allow
+                if (pv.Lb <= 2) fold_forward<2, 16>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
+                else if (pv.Lb <= 5) fold_forward<5, 8>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
+                else fold_forward<HB_LBMAX, 4>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
+            }
+        } else {
+            cacc[0] += active ? 1 : 0; // a quiet panel: nothing moved, nothing to write
         }
-        HB_STAMP(5);
-        // ---- fold the moves forward into the corrections of the next Lb panels ----
-        if (nev > 0) { // batch shape by band width: as many loads in flight as the registers allow
-            if (pv.Lb <= 2) fold_forward<2, 16>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
-            else if (pv.Lb <= 5) fold_forward<5, 8>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
-            else fold_forward<HB_LBMAX, 4>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
-        }
-        if (have_next) { // the next panel's hot rows: they have had the whole panel to arrive
+        if (have_next && n_items > 0) { // the next panel's hot rows: they have had the whole panel to arrive
             if (plin0 >= 0) *reinterpret_cast<int4 *>(rown + plin0) = pre0;
             if (plin1 >= 0) *reinterpret_cast<int4 *>(rown + plin1) = pre1;
             if (plin2 >= 0) *reinterpret_cast<int4 *>(rown + plin2) = pre2;
             if (plin3 >= 0) *reinterpret_cast<int4 *>(rown + plin3) = pre3;
-            for (int it = 4 * S + wave; it < n_items; it += S) { // many hot markers: the rest, synchronously
-                const int lin = min((it << 8) + lane * 4, n_total - 4);
-                *reinterpret_cast<int4 *>(rown + lin) = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[lin >> lgP] << lgP) + (lin & (P - 1)));
+            for (int it = 4 * S + wave; it < n_items; it += 4 * S) { // many hot markers: the rest, four pieces in flight
+                int4 r4[4];
+                int l4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int iu = it + u * S;
+                    l4[u] = (iu < n_items) ? min((iu << 8) + lane * 4, n_total - 4) : -1;
+                    const int lc = max(l4[u], 0);
+                    r4[u] = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[lc >> lgP] << lgP) + (lc & (P - 1)));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (l4[u] >= 0) *reinterpret_cast<int4 *>(rown + l4[u]) = r4[u];
             }
         }
+        if (wave == S - 1 && tk_new_group) {
+            // last panel of its mat-vec group: the update of this group is waiting for exactly these moves, and the
+            // next panel's take may itself have to wait for a later launch — publish now rather than at that take
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(p + 1));
+        }
         HB_STAMP(6);
-        __syncthreads(); // LDS lists and the row cache half are free for the next panel
-        if (t == 0) cnts[0] = 0;
+        // no closing barrier: the next panel's opening barrier separates every reuse of the LDS lists, the candidate
+        // staging and the row-cache halves; what is written before it (wcnt, hl, s_nh) alternates by panel parity
     }
 
     // ---- the last panel's moves: drain and publish ----
@@ -1521,7 +1590,7 @@ static inline int kpad_for(int model, int n_fold)
 
 // LDS budget of k_chain: as many Gram rows as fit beside the event lists
 static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128 + 128 + 64)) / ((size_t)P * 4)); }
-#define HB_PERSIST_FIXED(P) ((size_t)(P) * 16 + 128 + 256 + 64 * (8 * (3 + 3 * 7) + 12))
+#define HB_PERSIST_FIXED(P) ((size_t)(P) * 20 + 128 + 512 + 64 * (8 * (3 + 3 * 7) + 12))
 static int persist_nslot(int P) { return std::min(P, std::min(160, (int)((160 * 1024 - HB_PERSIST_FIXED(P)) / ((size_t)P * 8)))); }
 // the whole 160 KiB: nothing that needs LDS (mat-vec, update) can then be co-scheduled on the chain's CU
 static size_t persist_smem(int) { return (size_t)160 * 1024; }
@@ -1550,24 +1619,33 @@ static hipError_t launch_chain(hb_ctx *c, const chain_view &cv, int p, hipStream
 static inline int ver_slot(const hb_ctx *c, int v) { return (v + 1) % c->NB; }
 
 static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, unsigned *ticket = nullptr,
-                       const upd_view *upd = nullptr)
+                       const upd_view *upd = nullptr, int red_col0 = 0, int red_ncols = 0)
 {
     if (!st) st = c->stream;
     upd_view uq{};
     if (upd) uq = *upd;
-    const dim3 grid(ncols / 8, c->nsplit + (uq.p1 > uq.p0 ? 1 : 0)), block(256);
+    if (!ticket) red_ncols = 0;
+    const dim3 grid(ncols / 8, c->nsplit + (uq.p1 > uq.p0 ? 1 : 0) + (red_ncols > 0 ? 1 : 0)), block(256);
     const int8_t *Xp = c->X + (int64_t)col0 * c->ld;
     double *part = c->partial + col0;
     const float *r32 = c->r32 + (size_t)slot * c->ld;
     const double *r64 = c->r + (size_t)slot * c->ld;
     const bool sgn = c->xmin < 0;
+    dot_sync sy{ticket, c->partial + red_col0, c->dsum + red_col0, red_ncols, c->nsplit};
     if (c->precise) {
-        if (sgn) hipLaunchKernelGGL((k_dot<true, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket, uq);
-        else     hipLaunchKernelGGL((k_dot<true, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket, uq);
+        if (sgn) hipLaunchKernelGGL((k_dot<true, true>), grid, block, c->dot_lds, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, sy, uq);
+        else     hipLaunchKernelGGL((k_dot<true, false>), grid, block, c->dot_lds, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, sy, uq);
     } else {
-        if (sgn) hipLaunchKernelGGL((k_dot<false, true>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket, uq);
-        else     hipLaunchKernelGGL((k_dot<false, false>), grid, block, 0, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, ticket, uq);
+        if (sgn) hipLaunchKernelGGL((k_dot<false, true>), grid, block, c->dot_lds, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, sy, uq);
+        else     hipLaunchKernelGGL((k_dot<false, false>), grid, block, c->dot_lds, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, sy, uq);
     }
+}
+
+// the reduction of the last launch's partials (there is no next launch to carry it)
+static void launch_reduce(hb_ctx *c, int col0, int ncols, hipStream_t st, unsigned *ticket)
+{
+    dot_sync sy{ticket, c->partial + col0, c->dsum + col0, ncols, c->nsplit};
+    hipLaunchKernelGGL(k_reduce_partials, dim3((ncols + 255) / 256), dim3(256), 0, st, sy, c->m_pad);
 }
 
 static upd_view make_upd(hb_ctx *c, int p0, int p1, int sin, int sout, unsigned *flags)
@@ -1636,7 +1714,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
         HB_HIP(hipStreamWaitEvent(sC, c->ev_fork, 0));
     }
     chain_view cv{c->m_pad, c->P, c->nsplit, L, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
-                  c->thr, c->invv, c->sdz, c->gram, c->partial, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
+                  c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg};
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
     // software pipeline in issue order: mat-vec runs L panels ahead of chain/update in program order too,
@@ -1727,6 +1805,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     hipStream_t sA = c->stream, sB = c->s_chain;
     HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, sA));
     HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * (HB_FLAG_TICKET0 + HB_NSUB * HB_SUB_STRIDE), sA));
+    HB_HIP(hipMemsetAsync(c->ev_count, 0, sizeof(int32_t) * (size_t)np, sA)); // quiet panels do not write theirs
     {
         pre_view pvw{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
         hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pvw);
@@ -1737,11 +1816,11 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     HB_HIP(hipEventRecord(c->ev_fork, sA));
     HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
     chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
-                  c->thr, c->invv, c->sdz, c->gram, c->partial, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
+                  c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg};
-    const unsigned per_panel = (unsigned)(c->P / 8) * (unsigned)c->nsplit;
+    // arrivals per group: the workgroups that reduce its partials, 256 columns each
     const int last_panels = np - (ngroups - 1) * D;
-    persist_view pv{np, D, Lv, c->L, per_panel * (unsigned)D, per_panel * (unsigned)last_panels, ngroups, c->flags,
+    persist_view pv{np, D, Lv, c->L, (unsigned)((D * c->P + 255) / 256), (unsigned)((last_panels * c->P + 255) / 256), ngroups, c->flags,
                     c->hot_slot, c->hot_list, c->hot_n, c->candf};
     {
         hipError_t e = kp == 1 ? launch_chain_persist<1>(c, cv, pv, sB) : kp == 3 ? launch_chain_persist<3>(c, cv, pv, sB)
@@ -1758,8 +1837,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
         const int h = g - Lv;
         upd_view uq{};
         if (h >= 0) uq = make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags);
-        launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, c->flags + HB_FLAG_TICKET0, h >= 0 ? &uq : nullptr);
+        launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, c->flags + HB_FLAG_TICKET0, h >= 0 ? &uq : nullptr,
+                   g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0);
     }
+    launch_reduce(c, (ngroups - 1) * D * c->P, last_panels * c->P, sA, c->flags + HB_FLAG_TICKET0);
     for (int h = std::max(0, ngroups - Lv); h < ngroups; h++) // the updates that had no later mat-vec to ride on
         hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sA, c->ld,
                            make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags));
@@ -1953,11 +2034,14 @@ int hbk_time_matvec(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us, 
     HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * (HB_FLAG_TICKET0 + HB_NSUB * HB_SUB_STRIDE), c->stream));
     for (int warm = 0; warm < 2; warm++) {
         if (warm) HB_HIP(hipEventRecord(e0, c->stream));
-        for (int r = 0; r < (warm ? reps : 1); r++)
+        for (int r = 0; r < (warm ? reps : 1); r++) {
             for (int g = 0; g < ngroups; g++) {
                 const int p0 = g * D, p1 = std::min(c->npanels, p0 + D);
-                launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, use_ticket ? c->flags + HB_FLAG_TICKET0 : nullptr);
+                launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, use_ticket ? c->flags + HB_FLAG_TICKET0 : nullptr, nullptr,
+                           g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0);
             }
+            if (use_ticket) launch_reduce(c, (ngroups - 1) * D * c->P, (c->npanels - (ngroups - 1) * D) * c->P, c->stream, c->flags + HB_FLAG_TICKET0);
+        }
     }
     HB_HIP(hipEventRecord(e1, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));

@@ -39,10 +39,10 @@ if os.environ.get("STAMPS"):
     names = ["take", "prefetch-issue", "turns", "tail", "publish", "results", "fwd+landing"]
     print("phase mean cycles:", {names[i]: int(dd[:, i].mean()) for i in range(6)}, "loop-top gap", int((per - dd.sum(1)).mean()), "per panel", int(per.mean()), "-> us %.2f" % (per.mean() / 2100.))
     a = st[5:-2]
-    print("fine: 1->7 (issue next) %d, 7->8 (first ballot+barrier) %d, 8->2 (rounds) %d; moves/panel %.2f; waited-for-matvec frac %.3f" % (
-        (a[:, 7] - a[:, 1]).mean(), (a[:, 8] - a[:, 7]).mean(), (a[:, 2] - a[:, 8]).mean(), a[:, 10].mean(), a[:, 11].mean()))
+    print("fine: 0->1 take %d, 1->7 issue+barrier %d, 7->2 rounds %d, 2->3 ticket %d, 3->6 results+fwd+landing %d; moves/panel %.2f; waited-for-matvec frac %.3f" % (
+        (a[:, 1] - a[:, 0]).mean(), (a[:, 7] - a[:, 1]).mean(), (a[:, 2] - a[:, 7]).mean(), (a[:, 3] - a[:, 2]).mean(), (a[:, 6] - a[:, 3]).mean(), a[:, 10].mean(), a[:, 11].mean()))
     nm = a[:, 10]
     for lo, hi in ((0, 0), (1, 1), (2, 3), (4, 7), (8, 15), (16, 1000)):
         sel = (nm >= lo) & (nm <= hi)
-        if sel.sum(): print("  moves %d-%d: %d panels, rounds phase %d cyc, whole panel %d cyc, take %d" % (lo, hi, sel.sum(), (a[sel, 2] - a[sel, 8]).mean(), per[:len(sel)][sel[:len(per)]].mean(), (a[sel,1]-a[sel,0]).mean()))
-    print("phase median cycles:", {names[i]: int(np.median(dd[:, i])) for i in range(6)}, "per panel", int(np.median(per)))
+        if sel.sum(): print("  moves %d-%d: %d panels, rounds phase %d cyc, whole panel %d cyc, take %d" % (lo, hi, sel.sum(), (a[sel, 2] - a[sel, 7]).mean(), per[:len(sel)][sel[:len(per)]].mean(), (a[sel,1]-a[sel,0]).mean()))
+    0 and print("phase median cycles:", {names[i]: int(np.median(dd[:, i])) for i in range(6)}, "per panel", int(np.median(per)))
