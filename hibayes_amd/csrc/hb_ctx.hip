@@ -193,6 +193,8 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
         }
     }
 #undef TRY
+    // the allocation memsets ran on the null stream, which the context's non-blocking streams do not wait for
+    HB_HIP(hipDeviceSynchronize());
     *out = c;
     return HB_OK;
 }
@@ -692,9 +694,9 @@ int hb_ctx_set_windows(hb_ctx *c, const uint32_t *windindx, int32_t nw)
     HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->wind), sizeof(uint32_t) * c->m_pad));
     HB_HIP(hipMemcpy(c->wind, w.data(), sizeof(uint32_t) * c->m_pad, hipMemcpyHostToDevice));
     HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->wflag), (size_t)nw));
-    HB_HIP(hipMemset(c->wflag, 0, (size_t)nw));
+    HB_HIP(hipMemsetAsync(c->wflag, 0, (size_t)nw, c->stream));
     HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->wppa), sizeof(double) * nw));
-    HB_HIP(hipMemset(c->wppa, 0, sizeof(double) * nw));
+    HB_HIP(hipMemsetAsync(c->wppa, 0, sizeof(double) * nw, c->stream));
     c->nw = nw;
     return HB_OK;
 }
@@ -741,7 +743,7 @@ int hb_ctx_set_profiling(hb_ctx *c, int32_t on)
     c->profiling = (on & 1) != 0;
     if ((on & 2) && !c->dbg) { // bit 1: cycle stamps inside k_chain (development aid)
         HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->dbg), sizeof(long long) * 32 * (size_t)c->npanels));
-        HB_HIP(hipMemset(c->dbg, 0, sizeof(long long) * 32 * (size_t)c->npanels));
+        HB_HIP(hipMemsetAsync(c->dbg, 0, sizeof(long long) * 32 * (size_t)c->npanels, c->stream));
         c->graph_model = -1;
     }
     return HB_OK;

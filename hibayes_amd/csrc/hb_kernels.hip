@@ -53,30 +53,6 @@ __device__ __forceinline__ bool wait_ge(unsigned *flags, int word, unsigned want
     }
 }
 
-// lanes 0..31 of one wave wait until counter[lane] >= want[lane] for all of them; returns false on abort/timeout
-__device__ __forceinline__ bool wait_tickets(unsigned *flags, unsigned want)
-{
-    const int lane = threadIdx.x & 63;
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-        const unsigned got = lane < HB_NSUB ? ld_flag(flags + HB_FLAG_TICKET0 + lane * HB_SUB_STRIDE) : 0xffffffffu;
-        if (__all(lane >= HB_NSUB || got >= want)) return true;
-        if (ld_flag(flags + HB_FLAG_ABORT)) return false;
-        if (wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
-            if (lane == 0) st_flag(flags + HB_FLAG_ABORT, 1u);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(4);
-    }
-}
-// arrivals expected at sub-counter `lane` once mat-vec group g (0-based) has finished: groups complete in order
-__device__ __forceinline__ unsigned tickets_after_group(int g, int ngroups, unsigned total_full, unsigned total_last, int lane)
-{
-    const unsigned full = total_full / HB_NSUB + ((unsigned)lane < total_full % HB_NSUB ? 1u : 0u);
-    const unsigned last = total_last / HB_NSUB + ((unsigned)lane < total_last % HB_NSUB ? 1u : 0u);
-    return (g == ngroups - 1) ? (unsigned)(ngroups - 1) * full + last : (unsigned)(g + 1) * full;
-}
-
 // ---------------------------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------------------------
@@ -239,12 +215,12 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
 // k_dot: partial[split][col] = sum over the split's rows of x[row][col] * yadj[row]
 // tile = 8 columns x (256 threads x 16 rows); grid = (ncols/8, nsplit)
 // ---------------------------------------------------------------------------------------------
-// Pipeline hand-off of a mat-vec launch (all null / 0 outside the pipeline). The split partials of a launch are
+// Pipeline hand-off of a mat-vec launch (red_ncols = 0 outside the pipeline). The split partials of a launch are
 // added up by the FIRST grid row of the NEXT launch (the kernel boundary makes them visible: no per-tile atomics, no
-// write-through stores and no reduction tail in the streaming workgroups); only those few reducing workgroups report
-// to the group's arrival counters, after their sums are in memory. The chain workgroup then reads 8 bytes per marker.
+// write-through stores and no reduction tail in the streaming workgroups). The sums are written through to dsum[],
+// which the sweep pre-filled with a NaN bit pattern: the chain workgroup needs no flag to know a value has arrived,
+// and reads 8 bytes per marker instead of 8 per split.
 struct dot_sync {
-    unsigned *ticket;          // 32 arrival counters (cumulative over the sweep's groups)
     const double *red_partial; // [split][pstride] partials of the previous launch's columns
     double *red_dsum;          // their sums
     int red_ncols;             // 0: nothing to reduce in this launch
@@ -253,16 +229,11 @@ struct dot_sync {
 
 __device__ __forceinline__ void reduce_partials(const dot_sync &sy, int pstride, int blk, int tid)
 {
-    if (blk * 256 >= sy.red_ncols) return;
     const int col = blk * 256 + tid;
-    if (col < sy.red_ncols) {
-        double tot = 0.0;
-        for (int q = 0; q < sy.nsplit; q++) tot += sy.red_partial[(int64_t)q * pstride + col]; // split order: a fixed sum
-        st_sc1(&sy.red_dsum[col], tot); // write-through: read by the chain workgroup
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads(); // every wave's sums are in memory
-    if (tid == 0) __hip_atomic_fetch_add(sy.ticket + ((unsigned)blk % HB_NSUB) * HB_SUB_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (col >= sy.red_ncols) return;
+    double tot = 0.0;
+    for (int q = 0; q < sy.nsplit; q++) tot += sy.red_partial[(int64_t)q * pstride + col]; // split order: a fixed sum
+    st_sc1(&sy.red_dsum[col], tot);
 }
 
 __global__ __launch_bounds__(256) void k_reduce_partials(dot_sync sy, int pstride) { reduce_partials(sy, pstride, blockIdx.x, threadIdx.x); }
@@ -786,9 +757,6 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
 // ---------------------------------------------------------------------------------------------
 struct persist_view {
     int npanels, D, Lv, Lb;
-    unsigned total_per_group; // mat-vec workgroups of a full group
-    unsigned total_last;      // ... of the last (possibly shorter) group
-    int ngroups;
     unsigned *flags;
     const int *slot_of, *hotlist, *nhot; // per-sweep hot-lists from k_hotlist
     double candf;                        // a marker at zero is a chain candidate when q >= candf * thr0 (candf <= 1)
@@ -822,7 +790,7 @@ __global__ __launch_bounds__(512) void k_hotlist(const hb_sweep_in *__restrict__
     }
     const int raw = sbase + __popcll(hmask & ((1ull << lane) - 1ull));
     const int slot = (hot && raw < nslot) ? raw : -1;
-    slot_of[j] = slot;
+    slot_of[j] = vx[j] != 0.0 ? slot : -2; // -2: monomorphic marker, skipped by the chain
     if (slot >= 0) hotlist[(size_t)p * nslot + slot] = t;
     if (t == 0) nhot[p] = min(tot, nslot);
 }
@@ -883,8 +851,6 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     int *hl0 = reinterpret_cast<int *>(base + (size_t)P * 12);                // hot-lists being prefetched, by panel parity
     double *red = reinterpret_cast<double *>(base + (size_t)P * 20);
     int *cnts = reinterpret_cast<int *>(base + (size_t)P * 20 + 128);
-    int *s_ok = cnts + 16;
-    int *s_tk = cnts + 17;
     int *s_thi = cnts + 18;   // first candidate left for the next round
     int *s_nh0 = cnts + 19;   // [2] hot rows of the panel being prefetched, by panel parity
     int *wcnt0 = cnts + 32;   // candidates per wave: [32..47] even panels, [64..79] odd panels
@@ -909,49 +875,48 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     for (int c = 0; c <= K1; c++) cacc[c] = 0;
     int evacc = 0, missacc = 0, redoacc = 0;
 
-    // ---- "next" registers: filled one panel ahead ----
-    double n_vx, n_gold, n_xx, n_thr[K1], n_invv[K1], n_sdz[K1], n_d = 0.0;
-    int n_slot, n_nhot = 0;
+    // ---- prefetch registers ----
+    // What the opening of a panel needs (its reduced dot, entry threshold, old effect, x'x, row-cache slot) is kept in
+    // a ring of Q register sets filled Q panels ahead: with the mat-vec streaming at full rate a load takes several
+    // microseconds to come back, far longer than a quiet panel lasts. The loop below is unrolled Q times so that every
+    // ring access has a static index, every ring load is unconditional (a conditional load would make the compiler
+    // merge register copies, and a copy waits for the load), and nothing the loop consumes early is issued late:
+    // the memory counter is in-order, so using a young load forces every older one of the wave to land first.
+    // What only a panel with candidates needs (the remaining thresholds and the conditional-mean coefficients) is
+    // fetched one panel ahead into two alternating sets.
+    // The reduced dots need no flag: the sweep starts with dsum[] filled with a NaN bit pattern no sum can produce,
+    // every 8-byte result lands atomically, so a value is either that pattern (not there yet: re-read) or final.
+    constexpr int Q = (K1 <= 3) ? 4 : 2;
+    constexpr long long HB_SENT = -1ll; // memset 0xFF
+    double rg_d[Q], rg_thr0[Q], rg_gold[Q], rg_xx[Q];
+    int rg_slot[Q];   // row-cache slot, -1: none, -2: monomorphic marker (skipped)
+    double n_thr[2][K1], n_invv[2][K1], n_sdz[2][K1];
+    int n_nhot = 0;
     // hot-list entry / count two panels ahead (landed by the time they are stored). The count is loaded by thread 0
     // alone and travels through LDS: a wave-uniform load would be waited for on the spot (s_waitcnt vmcnt(0) +
     // readfirstlane), draining every prefetch issued before it.
     int hl_reg = 0, nh_reg = 0;
-    bool n_have_ps = false;
-    auto issue_static = [&](int q) { // coefficients of panel q -> next registers (plain loads, fixed before the sweep)
-        const int jq = q * P + t;
-        n_vx = v.vx[jq];
-        n_gold = v.g[jq];
-        n_xx = v.xpx[jq];
-#pragma unroll
-        for (int c = 0; c < K1; c++) {
-            n_thr[c] = v.thr[(size_t)c * v.m_pad + jq];
-            n_invv[c] = v.invv[(size_t)c * v.m_pad + jq];
-            n_sdz[c] = v.sdz[(size_t)c * v.m_pad + jq];
-        }
-        n_slot = pv.slot_of[jq];
-    };
-    auto issue_partials = [&](int q) { // x_j . yadj, reduced and written through by the mat-vec: read with an sc1 load
-        n_d = ld_sc1(&v.dsum[q * P + t]);
-    };
-    auto ticket_ready = [&](int q) -> bool { // wave 0, non-blocking
-        const unsigned want = tickets_after_group(q / pv.D, pv.ngroups, pv.total_per_group, pv.total_last, lane);
-        const unsigned got = lane < HB_NSUB ? ld_flag(pv.flags + HB_FLAG_TICKET0 + lane * HB_SUB_STRIDE) : 0xffffffffu;
-        return __all(lane >= HB_NSUB || got >= want);
-    };
 
-    // ---- prologue: panel 0 synchronously ----
-    issue_static(0);
-    if (wave == 0) {
-        const bool r = wait_tickets(pv.flags, tickets_after_group(0, pv.ngroups, pv.total_per_group, pv.total_last, lane));
-        if (lane == 0) *s_ok = r ? 1 : 0;
+    // ---- prologue: fill the ring ----
+    if (t < 128) cnts[t] = 0;
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+        const int jq = min(u, np - 1) * P + t;
+        rg_thr0[u] = v.thr[jq];
+        rg_gold[u] = v.g[jq];
+        rg_xx[u] = v.xpx[jq];
+        rg_slot[u] = pv.slot_of[jq];
+        rg_d[u] = ld_sc1(&v.dsum[jq]);
     }
-    if (t < 128 && t != 16 && t != 17) cnts[t] = 0; // (s_ok / s_tk are being written by wave 0)
-    __syncthreads();
-    bool ok = *s_ok != 0;
-    if (ok) {
-        issue_partials(0);
-        n_have_ps = true;
-        // row cache 0 for panel 0
+#pragma unroll
+    for (int c = 0; c < K1; c++) {
+        n_thr[0][c] = v.thr[(size_t)c * v.m_pad + t];
+        n_invv[0][c] = v.invv[(size_t)c * v.m_pad + t];
+        n_sdz[0][c] = v.sdz[(size_t)c * v.m_pad + t];
+        n_thr[1][c] = 0.0; n_invv[1][c] = 0.0; n_sdz[1][c] = 0.0;
+    }
+    bool ok = true;
+    {   // row cache 0 for panel 0
         n_nhot = pv.nhot[0];
         const int total = n_nhot << lgP, items = (total + 255) >> 8;
         const int32_t *gp0 = v.gram;
@@ -967,7 +932,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     }
     __syncthreads();
 
-    for (int p = 0; ok && p < np; p++) {
+    auto panel_body = [&](auto U, const int p) -> bool {
+        constexpr int u = decltype(U)::value;
+        constexpr int sa = u & 1, sb = sa ^ 1; // candidates' coefficient sets: this panel's, the next panel's
         const int j = p * P + t;
         const int cur = p & 1;
         int32_t *rowc = rowc0 + (size_t)cur * nslot * P;
@@ -976,67 +943,60 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         int *hl = hl0 + (size_t)cur * P, *s_nh = s_nh0 + cur, *wcnt = wcnt0 + (cur << 5);
         HB_STAMP(0);
         // ---- take over the prefetched panel ----
-        const double vxj = n_vx, gold = n_gold, xx = n_xx;
-        double thr[K1], invv[K1], sdz[K1];
-#pragma unroll
-        for (int c = 0; c < K1; c++) { thr[c] = n_thr[c]; invv[c] = n_invv[c]; sdz[c] = n_sdz[c]; }
-        const int myslot = n_slot;
-        if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + 11] = n_have_ps ? 0 : 1;
-        if (!n_have_ps) { // the mat-vec was not finished when we looked: wait for it now
-            if (wave == 0) {
-                const bool r = wait_tickets(pv.flags, tickets_after_group(p / pv.D, pv.ngroups, pv.total_per_group, pv.total_last, lane));
-                if (lane == 0) *s_ok = r ? 1 : 0;
+        double dj = rg_d[u];
+        bool aborted = false;
+        {
+            bool bad = __double_as_longlong(dj) == HB_SENT;
+            if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + 11] = bad ? 1 : 0;
+            if (__any(bad)) { // this wave's dots had not been written when the ring slot was filled: re-read until they are
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    if (bad) {
+                        dj = ld_sc1(&v.dsum[j]);
+                        bad = __double_as_longlong(dj) == HB_SENT;
+                    }
+                    if (!__any(bad)) break;
+                    if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
+                        if (lane == 0) st_flag(pv.flags + HB_FLAG_ABORT, 1u);
+                        aborted = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
             }
-            __syncthreads();
-            if (!*s_ok) { ok = false; break; }
-            issue_partials(p);
         }
-        double rhs = n_d;
+        const double gold = rg_gold[u], xx = rg_xx[u];
+        const int myslot = rg_slot[u];
+        double thr[K1], invv[K1], sdz[K1];
+        thr[0] = rg_thr0[u];
+        double rhs = dj;
         if (gold != 0.0) rhs = fma(xx, gold, rhs);
         rhs -= corr[0];
 #pragma unroll
         for (int l = 0; l + 1 < HB_LBMAX; l++) corr[l] = corr[l + 1];
         corr[HB_LBMAX - 1] = 0.0;
-        const bool active = vxj != 0.0;
+        const bool active = myslot > -2;
         const bool hot = active && gold != 0.0;
-        if (wave == S - 1 && p > 0) {
-            // the previous panel's moves were stored a whole panel ago, and every load this wave had in flight has
-            // just been consumed: the drain is free here, unlike anywhere after the next prefetches are issued
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)p);
-        }
+        const bool have_next = p + 1 < np;
+        const bool group_end = have_next && (p + 1) % pv.D == 0;
+        const int32_t *gpn = gp + (size_t)(pv.Lb + 1) * P * P;
         {   // who can move at all: certain movers and markers near their entry threshold (first round of the chain)
             const unsigned long long cm0 = __ballot(active && (hot || rhs * rhs >= pv.candf * thr[0]));
-            if (lane == 0) wcnt[wave] = __popcll(cm0);
+            if (lane == 0) wcnt[wave] = __popcll(cm0) | (aborted ? 0x10000 : 0);
+        }
+        if (have_next) {
+            if (t < nslot) hl[t] = hl_reg; // fetched one panel ago
+            if (t == 0) *s_nh = nh_reg;
         }
         HB_STAMP(1);
-        // ---- start fetching panel p+1 (everything here is issued, nothing waited for) ----
-        const bool have_next = p + 1 < np;
-        const bool tk_new_group = have_next && (p + 1) % pv.D == 0;
-        n_have_ps = false;
-        const int32_t *gpn = gp + (size_t)(pv.Lb + 1) * P * P;
-        unsigned tk_got = 0xffffffffu;
-        if (have_next) {
-            if (t < nslot) hl[t] = hl_reg; // fetched one panel ago: consumed before anything new is issued
-            if (t == 0) *s_nh = nh_reg;
-            issue_static(p + 1);
-            if (p + 2 < np) {
-                if (t < nslot) hl_reg = pv.hotlist[(size_t)(p + 2) * nslot + t];
-                if (t == 0) nh_reg = pv.nhot[p + 2];
-            }
-            if (!tk_new_group) { // same mat-vec launch as this panel: known to be complete
-                issue_partials(p + 1);
-                n_have_ps = true;
-            } else if (wave == 0 && lane < HB_NSUB) { // look at the next launch's arrivals now, use the answer later
-                tk_got = ld_flag(pv.flags + HB_FLAG_TICKET0 + lane * HB_SUB_STRIDE);
-            }
-        }
         __syncthreads(); // the panel's one fixed barrier: wcnt[], hl[], *s_nh staged; everybody is done with panel p-1
         int tot0 = 0;
         for (int w = 0; w < S; w++) tot0 += wcnt[w];
+        if (tot0 >> 16) return false; // a wave gave up waiting for its dots: the sweep is aborted
         if (have_next) n_nhot = *s_nh;
         const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
-        // Gram rows of the next panel's hot markers: four 1-KiB pieces per wave travel during the rounds
+        // ---- prefetch: issued oldest-needed first, nothing waited for ----
+        // (1) Gram rows of the next panel's hot markers: four 1-KiB pieces per wave travel during the rounds
         int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
         int plin0 = -1, plin1 = -1, plin2 = -1, plin3 = -1;
         if (have_next) {
@@ -1048,6 +1008,32 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                 pre2 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin2 >> lgP] << lgP) + (plin2 & (P - 1))); }
             if (wave + 3 * S < n_items) { plin3 = min(((wave + 3 * S) << 8) + lane * 4, n_total - 4);
                 pre3 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin3 >> lgP] << lgP) + (plin3 & (P - 1))); }
+        }
+        // (2) the next panel's candidate coefficients, (3) the hot-list two panels ahead, (4) ring slot u <- panel p + Q
+        {
+            const int j1 = min(p + 1, np - 1) * P + t;
+#pragma unroll
+            for (int c = 0; c < K1; c++) {
+                if (c > 0) n_thr[sb][c] = v.thr[(size_t)c * v.m_pad + j1];
+                n_invv[sb][c] = v.invv[(size_t)c * v.m_pad + j1];
+                n_sdz[sb][c] = v.sdz[(size_t)c * v.m_pad + j1];
+            }
+            if (p + 2 < np) {
+                if (t < nslot) hl_reg = pv.hotlist[(size_t)(p + 2) * nslot + t];
+                if (t == 0) nh_reg = pv.nhot[p + 2];
+            }
+            const int jq = min(p + Q, np - 1) * P + t;
+            rg_thr0[u] = v.thr[jq];
+            rg_gold[u] = v.g[jq];
+            rg_xx[u] = v.xpx[jq];
+            rg_slot[u] = pv.slot_of[jq];
+            rg_d[u] = ld_sc1(&v.dsum[jq]);
+        }
+#pragma unroll
+        for (int c = 0; c < K1; c++) {
+            if (c > 0) thr[c] = n_thr[sa][c];
+            invv[c] = n_invv[sa][c];
+            sdz[c] = n_sdz[sa][c];
         }
         HB_STAMP(7);
 
@@ -1211,19 +1197,6 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         }
         HB_STAMP(2);
         if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + 10] = nev;
-        if (tk_new_group) { // the next panel opens a new mat-vec launch: has it arrived?
-            if (wave == 0) {
-                const unsigned want = tickets_after_group((p + 1) / pv.D, pv.ngroups, pv.total_per_group, pv.total_last, lane);
-                bool r = __all(lane >= HB_NSUB || tk_got >= want);
-                if (!r) r = ticket_ready(p + 1); // not yet when we looked: look again
-                if (lane == 0) *s_tk = r ? 1 : 0;
-            }
-            __syncthreads();
-            if (*s_tk) { // its reduced dots travel while we finish this panel
-                issue_partials(p + 1);
-                n_have_ps = true;
-            }
-        }
         HB_STAMP(3);
         if (tot0 > 0) {
             // ---- publish the panel's moves (the update of this group waits for them). Only the last wave does it,
@@ -1283,7 +1256,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                     if (l4[u] >= 0) *reinterpret_cast<int4 *>(rown + l4[u]) = r4[u];
             }
         }
-        if (wave == S - 1 && tk_new_group) {
+        if (wave == S - 1 && group_end) {
             // last panel of its mat-vec group: the update of this group is waiting for exactly these moves, and the
             // next panel's take may itself have to wait for a later launch — publish now rather than at that take
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1292,6 +1265,13 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         HB_STAMP(6);
         // no closing barrier: the next panel's opening barrier separates every reuse of the LDS lists, the candidate
         // staging and the row-cache halves; what is written before it (wcnt, hl, s_nh) alternates by panel parity
+        return true;
+    };
+    for (int pb = 0; ok && pb < np; pb += Q) {
+        ok = panel_body(std::integral_constant<int, 0>{}, pb);
+        if (Q > 1 && ok && pb + 1 < np) ok = panel_body(std::integral_constant<int, 1 % Q>{}, pb + 1);
+        if (Q > 2 && ok && pb + 2 < np) ok = panel_body(std::integral_constant<int, 2 % Q>{}, pb + 2);
+        if (Q > 3 && ok && pb + 3 < np) ok = panel_body(std::integral_constant<int, 3 % Q>{}, pb + 3);
     }
 
     // ---- the last panel's moves: drain and publish ----
@@ -1618,7 +1598,7 @@ static hipError_t launch_chain(hb_ctx *c, const chain_view &cv, int p, hipStream
 // residual version v (moves of panels <= v applied; v = -1: start of the sweep) lives in slot (v+1) mod NB
 static inline int ver_slot(const hb_ctx *c, int v) { return (v + 1) % c->NB; }
 
-static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, unsigned *ticket = nullptr,
+static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, bool ticket = false,
                        const upd_view *upd = nullptr, int red_col0 = 0, int red_ncols = 0)
 {
     if (!st) st = c->stream;
@@ -1631,7 +1611,7 @@ static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t
     const float *r32 = c->r32 + (size_t)slot * c->ld;
     const double *r64 = c->r + (size_t)slot * c->ld;
     const bool sgn = c->xmin < 0;
-    dot_sync sy{ticket, c->partial + red_col0, c->dsum + red_col0, red_ncols, c->nsplit};
+    dot_sync sy{c->partial + red_col0, c->dsum + red_col0, red_ncols, c->nsplit};
     if (c->precise) {
         if (sgn) hipLaunchKernelGGL((k_dot<true, true>), grid, block, c->dot_lds, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, sy, uq);
         else     hipLaunchKernelGGL((k_dot<true, false>), grid, block, c->dot_lds, st, Xp, c->ld, r32, r64, c->nchunks, 1, part, c->m_pad, sy, uq);
@@ -1642,9 +1622,9 @@ static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t
 }
 
 // the reduction of the last launch's partials (there is no next launch to carry it)
-static void launch_reduce(hb_ctx *c, int col0, int ncols, hipStream_t st, unsigned *ticket)
+static void launch_reduce(hb_ctx *c, int col0, int ncols, hipStream_t st)
 {
-    dot_sync sy{ticket, c->partial + col0, c->dsum + col0, ncols, c->nsplit};
+    dot_sync sy{c->partial + col0, c->dsum + col0, ncols, c->nsplit};
     hipLaunchKernelGGL(k_reduce_partials, dim3((ncols + 255) / 256), dim3(256), 0, st, sy, c->m_pad);
 }
 
@@ -1806,6 +1786,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, sA));
     HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * (HB_FLAG_TICKET0 + HB_NSUB * HB_SUB_STRIDE), sA));
     HB_HIP(hipMemsetAsync(c->ev_count, 0, sizeof(int32_t) * (size_t)np, sA)); // quiet panels do not write theirs
+    HB_HIP(hipMemsetAsync(c->dsum, 0xFF, sizeof(double) * (size_t)c->m_pad, sA)); // "not written yet": a NaN no sum can produce
     {
         pre_view pvw{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
         hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pvw);
@@ -1818,9 +1799,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg};
-    // arrivals per group: the workgroups that reduce its partials, 256 columns each
     const int last_panels = np - (ngroups - 1) * D;
-    persist_view pv{np, D, Lv, c->L, (unsigned)((D * c->P + 255) / 256), (unsigned)((last_panels * c->P + 255) / 256), ngroups, c->flags,
+    persist_view pv{np, D, Lv, c->L, c->flags,
                     c->hot_slot, c->hot_list, c->hot_n, c->candf};
     {
         hipError_t e = kp == 1 ? launch_chain_persist<1>(c, cv, pv, sB) : kp == 3 ? launch_chain_persist<3>(c, cv, pv, sB)
@@ -1837,10 +1817,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
         const int h = g - Lv;
         upd_view uq{};
         if (h >= 0) uq = make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags);
-        launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, c->flags + HB_FLAG_TICKET0, h >= 0 ? &uq : nullptr,
+        launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, true, h >= 0 ? &uq : nullptr,
                    g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0);
     }
-    launch_reduce(c, (ngroups - 1) * D * c->P, last_panels * c->P, sA, c->flags + HB_FLAG_TICKET0);
+    launch_reduce(c, (ngroups - 1) * D * c->P, last_panels * c->P, sA);
     for (int h = std::max(0, ngroups - Lv); h < ngroups; h++) // the updates that had no later mat-vec to ride on
         hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sA, c->ld,
                            make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags));
@@ -2037,10 +2017,10 @@ int hbk_time_matvec(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us, 
         for (int r = 0; r < (warm ? reps : 1); r++) {
             for (int g = 0; g < ngroups; g++) {
                 const int p0 = g * D, p1 = std::min(c->npanels, p0 + D);
-                launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, use_ticket ? c->flags + HB_FLAG_TICKET0 : nullptr, nullptr,
+                launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, use_ticket != 0, nullptr,
                            g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0);
             }
-            if (use_ticket) launch_reduce(c, (ngroups - 1) * D * c->P, (c->npanels - (ngroups - 1) * D) * c->P, c->stream, c->flags + HB_FLAG_TICKET0);
+            if (use_ticket) launch_reduce(c, (ngroups - 1) * D * c->P, (c->npanels - (ngroups - 1) * D) * c->P, c->stream);
         }
     }
     HB_HIP(hipEventRecord(e1, c->stream));

@@ -335,9 +335,9 @@ int hb_run::setup(const hb_bayes_args *args)
         std::vector<uint8_t> t0v(m, 0);
         rc = hb_ctx_set_effects(c, g0.data(), t0v.data(), vl.data()); // vargL.fill(varg), :364-368
         if (rc) return rc;
-        HB_HIP(hipMemset(c->nzrate, 0, sizeof(uint32_t) * (size_t)c->m_pad));
-        HB_HIP(hipMemset(c->alpha_sum, 0, sizeof(double) * (size_t)c->m_pad));
-        HB_HIP(hipMemset(c->alpha_sq, 0, sizeof(double) * (size_t)c->m_pad));
+        HB_HIP(hipMemsetAsync(c->nzrate, 0, sizeof(uint32_t) * (size_t)c->m_pad, c->stream));
+        HB_HIP(hipMemsetAsync(c->alpha_sum, 0, sizeof(double) * (size_t)c->m_pad, c->stream));
+        HB_HIP(hipMemsetAsync(c->alpha_sq, 0, sizeof(double) * (size_t)c->m_pad, c->stream));
     }
     if (!wind.empty()) {
         for (int i = 0; i < m; i++) nw = std::max(nw, (int)wind[i]);
