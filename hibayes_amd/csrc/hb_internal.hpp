@@ -63,8 +63,8 @@ struct hb_ctx {
     size_t gram_cap = 0; // ints allocated
     bool env_pinned = false;
     int dot_lds = 0;     // dynamic LDS bytes requested by each mat-vec workgroup: caps the workgroups resident per CU
-    double candf = 0.64; // chain candidates: markers at zero with q >= candf * thr0
-    double kappa = 6.0; // row-cache prediction: markers with thr0 <= kappa * xx * vare get their Gram row prefetched
+    double candf = 1.0;  // chain candidates: markers at zero with q >= candf * thr0 (tuning knob; <= 1)
+    double kappa = 3.0; // row-cache prediction: markers with thr0 <= kappa * xx * vare get their Gram row prefetched
     bool gram_ready = false, stats_ready = false;
     int *xinfo = nullptr; // device: [0]=min value, [1]=max value over X
     int xmin = 0, xmax = 0;

@@ -238,6 +238,8 @@ __device__ __forceinline__ void reduce_partials(const dot_sync &sy, int pstride,
 
 __global__ __launch_bounds__(256) void k_reduce_partials(dot_sync sy, int pstride) { reduce_partials(sy, pstride, blockIdx.x, threadIdx.x); }
 
+typedef unsigned int hb_u4 __attribute__((ext_vector_type(4)));
+
 template <bool SIGNED>
 __device__ __forceinline__ float b2f(unsigned w, int b)
 {
@@ -282,7 +284,10 @@ __global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64
         if (row0 < ld) {
             uint4 xv[8];
 #pragma unroll
-            for (int c = 0; c < 8; c++) xv[c] = *reinterpret_cast<const uint4 *>(xc + (int64_t)c * ld + row0);
+            for (int c = 0; c < 8; c++) { // streamed once: non-temporal, so that the residual stays in L2
+                const hb_u4 w = __builtin_nontemporal_load(reinterpret_cast<const hb_u4 *>(xc + (int64_t)c * ld + row0));
+                xv[c] = make_uint4(w.x, w.y, w.z, w.w);
+            }
             acc_t rv[16];
             if (PRECISE) {
 #pragma unroll
@@ -1028,6 +1033,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             rg_xx[u] = v.xpx[jq];
             rg_slot[u] = pv.slot_of[jq];
             rg_d[u] = ld_sc1(&v.dsum[jq]);
+            // the dot of panel p + Q may well not be there yet: ask again for the panel two ahead (the later load simply
+            // lands on top of the earlier one; nothing waits)
+            if (Q >= 4) rg_d[(u + 2) % Q] = ld_sc1(&v.dsum[min(p + 2, np - 1) * P + t]);
         }
 #pragma unroll
         for (int c = 0; c < K1; c++) {
@@ -1084,6 +1092,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                     cs_slot[rank] = myslot;
                 }
                 __syncthreads();
+                if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(12);
                 const int t_hi = tot > 64 ? *s_thi : P;
                 if (wave == 0) {
                     const bool lv = lane < ncr;
@@ -1147,6 +1156,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                     res_g[lane] = rg;
                     if (lane == 0) cnts[0] = cnt;
                 }
+                if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(13);
                 __syncthreads();
                 const int nev1 = cnts[0];
                 // everybody still undecided applies the round's moves (those of earlier markers) to its own rhs
@@ -1175,6 +1185,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                         }
                     }
                 }
+                if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(14);
                 const bool viol = undec && !inr && t < t_hi && active && rhs_new * rhs_new >= thr[0];
                 const unsigned long long vm = __ballot(viol);
                 if (lane == 0) wviol[wave] = vm != 0ull;
@@ -1215,12 +1226,13 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             if (g_f != gold) v.g[j] = g_f;
             if (hot || cls_f != 0) v.tracker[j] = (uint8_t)cls_f; // a marker at zero that stays there keeps its 0
             if (count_pip && cls_f != 0) {
-                v.nzrate[j] += 1u;
+                __hip_atomic_fetch_add(&v.nzrate[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // no return value: nothing to wait for
                 if (v.wind) v.wflag[v.wind[j] - 1u] = 1;
             }
             if (store && g_f != 0.0) {
-                v.alpha_sum[j] += g_f;
-                v.alpha_sq[j] += g_f * g_f;
+                // one writer per marker: an atomic add gives the same sum as load-add-store, without the load's round trip
+                unsafeAtomicAdd(&v.alpha_sum[j], g_f);
+                unsafeAtomicAdd(&v.alpha_sq[j], g_f * g_f);
             }
             if (cls_f > 0) wacc += (model == 6) ? g_f * g_f / pin->fold[cls_f] : g_f * g_f;
 #pragma unroll
