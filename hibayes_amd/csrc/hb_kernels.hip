@@ -1001,6 +1001,10 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         if (have_next) n_nhot = *s_nh;
         const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
         // ---- prefetch: issued oldest-needed first, nothing waited for ----
+        // (0) the next panel's dot once more: when the ring slot was filled, Q panels ago, it may not have been written yet.
+        // The later load simply lands on top of the earlier one. It is the first request of the panel because it is the
+        // first to be used: the memory counter is in-order, so everything issued before a load is waited for with it.
+        if (Q >= 2) rg_d[(u + 1) % Q] = ld_sc1(&v.dsum[min(p + 1, np - 1) * P + t]);
         // (1) Gram rows of the next panel's hot markers: four 1-KiB pieces per wave travel during the rounds
         int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
         int plin0 = -1, plin1 = -1, plin2 = -1, plin3 = -1;
@@ -1033,9 +1037,6 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             rg_xx[u] = v.xpx[jq];
             rg_slot[u] = pv.slot_of[jq];
             rg_d[u] = ld_sc1(&v.dsum[jq]);
-            // the dot of panel p + Q may well not be there yet: ask again for the panel two ahead (the later load simply
-            // lands on top of the earlier one; nothing waits)
-            if (Q >= 4) rg_d[(u + 2) % Q] = ld_sc1(&v.dsum[min(p + 2, np - 1) * P + t]);
         }
 #pragma unroll
         for (int c = 0; c < K1; c++) {
