@@ -937,9 +937,18 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     }
     __syncthreads();
 
-    auto panel_body = [&](auto U, const int p) -> bool {
-        constexpr int u = decltype(U)::value;
-        constexpr int sa = u & 1, sb = sa ^ 1; // candidates' coefficient sets: this panel's, the next panel's
+    // The ring registers need static indices, everything else does not: only the three small ring accesses of a panel are
+    // instantiated Q times (a uniform switch on p mod Q picks the copy); the rest of the loop body exists once, which keeps
+    // the kernel inside the instruction cache.
+    auto ring_switch = [&](int pp, auto &&f) {
+        switch (pp & (Q - 1)) {
+        case 0: f(std::integral_constant<int, 0>{}); break;
+        case 1: f(std::integral_constant<int, 1 % Q>{}); break;
+        case 2: f(std::integral_constant<int, 2 % Q>{}); break;
+        default: f(std::integral_constant<int, 3 % Q>{}); break;
+        }
+    };
+    for (int p = 0; ok && p < np; p++) {
         const int j = p * P + t;
         const int cur = p & 1;
         int32_t *rowc = rowc0 + (size_t)cur * nslot * P;
@@ -948,7 +957,16 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         int *hl = hl0 + (size_t)cur * P, *s_nh = s_nh0 + cur, *wcnt = wcnt0 + (cur << 5);
         HB_STAMP(0);
         // ---- take over the prefetched panel ----
-        double dj = rg_d[u];
+        double dj = 0.0, gold = 0.0, xx = 0.0, thr0v = 0.0;
+        int myslot = -2;
+        ring_switch(p, [&](auto U) {
+            constexpr int u = decltype(U)::value;
+            dj = rg_d[u];
+            gold = rg_gold[u];
+            xx = rg_xx[u];
+            myslot = rg_slot[u];
+            thr0v = rg_thr0[u];
+        });
         bool aborted = false;
         {
             bool bad = __double_as_longlong(dj) == HB_SENT;
@@ -970,10 +988,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                 }
             }
         }
-        const double gold = rg_gold[u], xx = rg_xx[u];
-        const int myslot = rg_slot[u];
         double thr[K1], invv[K1], sdz[K1];
-        thr[0] = rg_thr0[u];
+        thr[0] = thr0v;
         double rhs = dj;
         if (gold != 0.0) rhs = fma(xx, gold, rhs);
         rhs -= corr[0];
@@ -997,14 +1013,17 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         __syncthreads(); // the panel's one fixed barrier: wcnt[], hl[], *s_nh staged; everybody is done with panel p-1
         int tot0 = 0;
         for (int w = 0; w < S; w++) tot0 += wcnt[w];
-        if (tot0 >> 16) return false; // a wave gave up waiting for its dots: the sweep is aborted
+        if (tot0 >> 16) { ok = false; break; } // a wave gave up waiting for its dots: the sweep is aborted
         if (have_next) n_nhot = *s_nh;
         const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
         // ---- prefetch: issued oldest-needed first, nothing waited for ----
         // (0) the next panel's dot once more: when the ring slot was filled, Q panels ago, it may not have been written yet.
         // The later load simply lands on top of the earlier one. It is the first request of the panel because it is the
         // first to be used: the memory counter is in-order, so everything issued before a load is waited for with it.
-        if (Q >= 2) rg_d[(u + 1) % Q] = ld_sc1(&v.dsum[min(p + 1, np - 1) * P + t]);
+        ring_switch(p, [&](auto U) {
+            constexpr int u = decltype(U)::value;
+            if (Q >= 2) rg_d[(u + 1) % Q] = ld_sc1(&v.dsum[min(p + 1, np - 1) * P + t]);
+        });
         // (1) Gram rows of the next panel's hot markers: four 1-KiB pieces per wave travel during the rounds
         int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
         int plin0 = -1, plin1 = -1, plin2 = -1, plin3 = -1;
@@ -1018,8 +1037,11 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             if (wave + 3 * S < n_items) { plin3 = min(((wave + 3 * S) << 8) + lane * 4, n_total - 4);
                 pre3 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin3 >> lgP] << lgP) + (plin3 & (P - 1))); }
         }
-        // (2) the next panel's candidate coefficients, (3) the hot-list two panels ahead, (4) ring slot u <- panel p + Q
-        {
+        // (2) the next panel's candidate coefficients, (3) the hot-list two panels ahead, (4) ring slot u <- panel p + Q;
+        // this panel's candidate coefficients arrived a panel ago
+        ring_switch(p, [&](auto U) {
+            constexpr int u = decltype(U)::value;
+            constexpr int sa = u & 1, sb = sa ^ 1;
             const int j1 = min(p + 1, np - 1) * P + t;
 #pragma unroll
             for (int c = 0; c < K1; c++) {
@@ -1037,13 +1059,13 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             rg_xx[u] = v.xpx[jq];
             rg_slot[u] = pv.slot_of[jq];
             rg_d[u] = ld_sc1(&v.dsum[jq]);
-        }
 #pragma unroll
-        for (int c = 0; c < K1; c++) {
-            if (c > 0) thr[c] = n_thr[sa][c];
-            invv[c] = n_invv[sa][c];
-            sdz[c] = n_sdz[sa][c];
-        }
+            for (int c = 0; c < K1; c++) {
+                if (c > 0) thr[c] = n_thr[sa][c];
+                invv[c] = n_invv[sa][c];
+                sdz[c] = n_sdz[sa][c];
+            }
+        });
         HB_STAMP(7);
 
         // ---- the serial chain, speculatively compacted ----
@@ -1278,13 +1300,6 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         HB_STAMP(6);
         // no closing barrier: the next panel's opening barrier separates every reuse of the LDS lists, the candidate
         // staging and the row-cache halves; what is written before it (wcnt, hl, s_nh) alternates by panel parity
-        return true;
-    };
-    for (int pb = 0; ok && pb < np; pb += Q) {
-        ok = panel_body(std::integral_constant<int, 0>{}, pb);
-        if (Q > 1 && ok && pb + 1 < np) ok = panel_body(std::integral_constant<int, 1 % Q>{}, pb + 1);
-        if (Q > 2 && ok && pb + 2 < np) ok = panel_body(std::integral_constant<int, 2 % Q>{}, pb + 2);
-        if (Q > 3 && ok && pb + 3 < np) ok = panel_body(std::integral_constant<int, 3 % Q>{}, pb + 3);
     }
 
     // ---- the last panel's moves: drain and publish ----
