@@ -768,6 +768,7 @@ struct persist_view {
 };
 
 #define HB_LBMAX 12
+#define HB_CROWD 8 /* candidates in a round from which their Gram entries are gathered up front */
 
 // Row-cache list of every panel, in marker order, capped at nslot rows: the markers that are certain to move
 // (polymorphic, g_old != 0) and the markers that are LIKELY to enter the model this sweep. Entry means q >= thr0
@@ -866,6 +867,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     int *cs_t = reinterpret_cast<int *>(res_g + 64);
     int *cs_slot = cs_t + 64;
     int *res_c = cs_slot + 64;
+    int *cg = res_c + 64; // Gram entries among one round's candidates: cg[k * 64 + c] = x_k . x_c for k < c
 
     const int model = pin->model_index;
     const int count_pip = pin->count_pip, store = pin->store;
@@ -1117,7 +1119,32 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                 __syncthreads();
                 if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(12);
                 const int t_hi = tot > 64 ? *s_thi : P;
+                // a crowded round (dense models): the candidates' mutual Gram entries are gathered by everybody first (from the
+                // row cache; a candidate without a slot costs one parallel global fetch here instead of a serial one inside
+                // the chain)
+                const bool crowded = ncr >= HB_CROWD; // uniform: below that the chain reads the row cache itself
+                for (int base = t; crowded && base < ncr * 64; base += 8 * P) { // eight entries per thread in flight
+                    int gval[8];
+#pragma unroll
+                    for (int u8 = 0; u8 < 8; u8++) {
+                        const int idx = base + u8 * P, k = idx >> 6, c = idx & 63;
+                        gval[u8] = 0;
+                        if (idx < ncr * 64 && k < c && c < ncr) {
+                            const int sk = cs_slot[k];
+                            gval[u8] = sk >= 0 ? rowc[(size_t)sk * P + cs_t[c]] : gp[(size_t)cs_t[k] * P + cs_t[c]];
+                        }
+                    }
+#pragma unroll
+                    for (int u8 = 0; u8 < 8; u8++) {
+                        const int idx = base + u8 * P;
+                        if (idx < ncr * 64) cg[idx] = gval[u8];
+                    }
+                }
+                if (crowded) __syncthreads(); // (uniform)
                 if (wave == 0) {
+                    // The exact serial chain over the round's candidates, one per lane in marker order: step k asks whether
+                    // lane k moves given everything before it (certain movers always do), broadcasts its change and applies
+                    // it to the later lanes with the Gram entries gathered above.
                     const bool lv = lane < ncr;
                     double crhs = cs_d[lane];
                     const double cgold = lv ? cs_d[64 + lane] : 0.0;
@@ -1131,20 +1158,15 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                     const int ct = lv ? cs_t[lane] : 0;
                     const int cslot = lv ? cs_slot[lane] : -1;
                     const unsigned long long vmask = __ballot(lv);
-                    unsigned long long hleft = __ballot(lv && cgold != 0.0);
+                    const unsigned long long hotm = __ballot(lv && cgold != 0.0);
+                    const unsigned long long noslot = __ballot(lv && cslot < 0);
                     int rc = 0;
                     double rg = 0.0;
-                    int cnt = nev0, lo = 0;
-                    for (;;) {
-                        const int knext = hleft ? (__ffsll((long long)hleft) - 1) : 0;
-                        const int snext = __builtin_amdgcn_readlane(cslot, knext);
-                        int gnext = 0;
-                        if (hleft && snext >= 0) gnext = rowc[(size_t)snext * P + ct];
+                    int cnt = nev0;
+                    for (int k = 0; k < ncr; k++) {
                         const double q = crhs * crhs;
-                        const unsigned long long live = ~0ull << lo;
-                        const unsigned long long mask = ((__ballot(q >= cthr[0]) & vmask) | hleft) & live;
-                        if (mask == 0ull) break;
-                        const int k = __ffsll((long long)mask) - 1;
+                        const unsigned long long mv = (__ballot(q >= cthr[0]) & vmask) | hotm;
+                        if (!((mv >> k) & 1ull)) continue; // uniform: lane k stays where it is
                         int cls = 0;
                         double iv = 0.0, sz = 0.0;
 #pragma unroll
@@ -1160,20 +1182,17 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                         if (lane == k) { rc = cls; rg = gn; }
                         const double dk = readlane_f64(delta, k);
                         if (dk != 0.0) {
-                            const int tk = __builtin_amdgcn_readlane(ct, k);
                             int gv;
-                            int slot = snext;
-                            if (!(hleft && k == knext)) slot = __builtin_amdgcn_readlane(cslot, k);
-                            if (hleft && k == knext && snext >= 0) gv = gnext;
-                            else if (slot >= 0) gv = rowc[(size_t)slot * P + ct];
-                            else { gv = gp[(size_t)tk * P + ct]; missacc++; }
+                            if (crowded) gv = cg[k * 64 + lane];
+                            else {
+                                const int sk = __builtin_amdgcn_readlane(cslot, k);
+                                gv = sk >= 0 ? rowc[(size_t)sk * P + ct] : gp[(size_t)__builtin_amdgcn_readlane(ct, k) * P + ct];
+                            }
                             if (lane > k) crhs = fma(-(double)gv, dk, crhs);
-                            if (lane == k) { ev_ix[cnt] = (slot << 16) | tk; ev_del[cnt] = dk; }
+                            if (lane == k) { ev_ix[cnt] = (cslot << 16) | ct; ev_del[cnt] = dk; }
+                            missacc += (int)((noslot >> k) & 1ull);
                             cnt++;
                         }
-                        lo = k + 1;
-                        if (lo >= 64) break;
-                        hleft &= ~((2ull << k) - 1ull);
                     }
                     res_c[lane] = rc;
                     res_g[lane] = rg;
@@ -1598,7 +1617,7 @@ static inline int kpad_for(int model, int n_fold)
 
 // LDS budget of k_chain: as many Gram rows as fit beside the event lists
 static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128 + 128 + 64)) / ((size_t)P * 4)); }
-#define HB_PERSIST_FIXED(P) ((size_t)(P) * 20 + 128 + 512 + 64 * (8 * (3 + 3 * 7) + 12))
+#define HB_PERSIST_FIXED(P) ((size_t)(P) * 20 + 128 + 512 + 64 * (8 * (3 + 3 * 7) + 12) + 64 * 64 * 4)
 static int persist_nslot(int P) { return std::min(P, std::min(160, (int)((160 * 1024 - HB_PERSIST_FIXED(P)) / ((size_t)P * 8)))); }
 // the whole 160 KiB: nothing that needs LDS (mat-vec, update) can then be co-scheduled on the chain's CU
 static size_t persist_smem(int) { return (size_t)160 * 1024; }

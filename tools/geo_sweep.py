@@ -42,10 +42,10 @@ if os.environ.get("STAMPS"):
     print("fine: 0->1 take %d, 1->7 issue+barrier %d, 7->2 rounds %d, 2->3 ticket %d, 3->6 results+fwd+landing %d; moves/panel %.2f; waited-for-matvec frac %.3f" % (
         (a[:, 1] - a[:, 0]).mean(), (a[:, 7] - a[:, 1]).mean(), (a[:, 2] - a[:, 7]).mean(), (a[:, 3] - a[:, 2]).mean(), (a[:, 6] - a[:, 3]).mean(), a[:, 10].mean(), a[:, 11].mean()))
     nm = a[:, 10]
-    one = nm == 1
-    if one.sum():
+    for label, one in (("1-move", nm == 1), ("16+-move", nm >= 16)):
+      if one.sum():
         o = a[one]
-        print("  1-move panels: take %d | issue+barrierA %d | to staged(B2) %d | chain %d | B3+apply %d | B4..end rounds %d | 2->3 %d | publish(3->4) %d | results(4->5) %d | fwd+landing(5->6) %d" % (
+        print("  " + label + " panels: take %d | issue+barrierA %d | to staged(B2) %d | chain %d | B3+apply %d | B4..end rounds %d | 2->3 %d | publish(3->4) %d | results(4->5) %d | fwd+landing(5->6) %d" % (
             (o[:,1]-o[:,0]).mean(), (o[:,7]-o[:,1]).mean(), (o[:,12]-o[:,7]).mean(), (o[:,13]-o[:,12]).mean(), (o[:,14]-o[:,13]).mean(), (o[:,2]-o[:,14]).mean(), (o[:,3]-o[:,2]).mean(), (o[:,4]-o[:,3]).mean(), (o[:,5]-o[:,4]).mean(), (o[:,6]-o[:,5]).mean()))
     for lo, hi in ((0, 0), (1, 1), (2, 3), (4, 7), (8, 15), (16, 1000)):
         sel = (nm >= lo) & (nm <= hi)
