@@ -33,9 +33,15 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--burnin", type=int, default=300,
+                    help="MCMC burn-in sweeps run as part of the set-up, before the warm-up steps: the chain starts with ~5 %% of the "
+                         "markers in the model and needs a few hundred sweeps to reach the regime a 20 000-iteration run spends its time in")
+    ap.add_argument("--burnin-secondary", type=int, default=30)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (gloo: development runs on one GPU)")
     ap.add_argument("--n", type=int, default=50000)
-    ap.add_argument("--m", type=int, default=500000)
+    ap.add_argument("--m", type=int, default=int(os.environ.get("HB_BENCH_M", "500000")),
+                    help="markers per GPU (under torch.distributed.run pass it as HB_BENCH_M: the launcher claims --m)")
     ap.add_argument("--model", default="BayesCpi", help="BASELINE.json north_star target: BayesCpi at n=50k, m=500k")
     ap.add_argument("--secondary", default="BayesR", help="second model measured on the same genotypes ('' = none)")
     ap.add_argument("--panel", type=int, default=0)
@@ -132,8 +138,8 @@ def prior(model):
     return [0.95, 0.05], None
 
 
-def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, m_global, comm, torch, note):
-    """W warm-up iterations, then exactly K iterations between barriers; returns the result dict pieces."""
+def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, m_global, comm, torch, note, burn=0):
+    """burn set-up sweeps, W warm-up iterations, then exactly K iterations between barriers; returns the result dict pieces."""
     from hibayes_amd._lib import BayesArgs, RunInfo, check
     n, m = args.n, args.m
     Pi, fold = prior(model)
@@ -147,7 +153,7 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
     if fold is not None:
         fv = np.array(fold)
         a.fold, a.n_fold = fv.ctypes.data, fv.size
-    a.niter, a.nburn, a.thin = W + K + 5, 0, 5  # every sweep counts PIP, every 5th is a stored record
+    a.niter, a.nburn, a.thin = burn + W + K + 5, 0, 5  # every sweep counts PIP, every 5th is a stored record
     a.outfreq, a.verbose = 0, 0
     a.seed, a.device, a.precise, a.store_alpha = args.seed, local_rank, args.precise, 0
     a.ctx = ctx.h
@@ -167,9 +173,15 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
             comm.barrier()
             torch.cuda.synchronize(local_rank)
 
+    if burn > 0:
+        check(L.hb_run_step(run, burn, ct.byref(fin)))
+        sync()
+        note("%s: burn-in done (%d sweeps)" % (model, burn))
     check(L.hb_run_step(run, W, ct.byref(fin)))
     sync()
     note("%s: warm-up done" % model)
+    info0 = RunInfo()
+    check(L.hb_run_state(run, ct.byref(info0)))
     t1 = time.perf_counter()
     check(L.hb_run_step(run, K, ct.byref(fin)))
     sync()
@@ -183,7 +195,9 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
     check(L.hb_run_state(run, ct.byref(info)))
     L.hb_run_destroy(run)
     del keep
-    return elapsed, info.mean_events, info.nnz, info.mean_misses
+    ev = (info.mean_events * info.iter - info0.mean_events * info0.iter) / max(1, K)   # over the timed sweeps only
+    ms = (info.mean_misses * info.iter - info0.mean_misses * info0.iter) / max(1, K)
+    return elapsed, ev, info.nnz, ms
 
 
 def main():
@@ -195,8 +209,12 @@ def main():
     import torch
     if world > 1:
         import torch.distributed as dist
+        local_rank = local_rank % max(1, torch.cuda.device_count())  # (several ranks on one GPU: --backend gloo only)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
         from hibayes_amd.dist import TorchComm
         comm = TorchComm(device=torch.device("cuda", local_rank))
     import hibayes_amd as H
@@ -224,7 +242,7 @@ def main():
 
     K, W = args.steps, args.warmup
     elapsed, mean_events, nnz, misses = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
-                                        m_global, comm, torch, note)
+                                        m_global, comm, torch, note, burn=args.burnin)
     # the dominant kernel on its own: the sweep's mat-vec launches, back to back, HIP events on their stream
     avg_ms, launches, cols = ctx.time_matvec(reps=3)
     alg_bytes = float(n) * cols  # one read of the launch's int8 genotypes (SURVEY.md §8 d: n*m per sweep)
@@ -253,6 +271,7 @@ def main():
                    "model": args.model, "n": n, "m_per_gpu": m, "m_global": m_global, "panel": ctx.panel,
                    "pipeline": {"persistent_chain": geo[0], "lookahead_groups": geo[1], "panels_per_matvec": geo[2]},
                    "sharding": "markers, contiguous ranges, one residual all-reduce per sweep" if world > 1 else "none",
+                   "mcmc_burn_in_sweeps_before_warmup": args.burnin,
                    "mean_changed_markers_per_sweep": mean_events, "row_cache_misses_per_sweep": misses, "NumNZSnp_last": nnz,
                    "setup_seconds": {"generate": gen_s, "gram": gram_s}},
         "achieved_GBps": value * n * m / 1e9, "achieved_frac_of_hbm_peak": value * n * m / 1e9 / (HBM_PEAK_GBPS * world),
@@ -266,10 +285,11 @@ def main():
         K2, W2 = max(10, K // 4), max(5, min(W, 30))
         y2 = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, args.secondary)
         el2, ev2, nnz2, miss2 = measure(H, L, ctx, y2, args.secondary, K2, W2, args, rank, local_rank, world, m_offset,
-                                 m_global, comm, torch, note)
+                                 m_global, comm, torch, note, burn=args.burnin_secondary)
         res["secondary"] = {"model": args.secondary, "value": K2 / el2, "unit": "sweeps/s", "steps": K2, "warmup": W2,
                             "ms_per_step": el2 / K2 * 1e3, "achieved_frac_of_hbm_peak": K2 / el2 * n * m / 1e9 / HBM_PEAK_GBPS,
-                            "mean_changed_markers_per_sweep": ev2, "row_cache_misses_per_sweep": miss2, "NumNZSnp_last": nnz2,
+                            "mcmc_burn_in_sweeps_before_warmup": args.burnin_secondary,
+                          "mean_changed_markers_per_sweep": ev2, "row_cache_misses_per_sweep": miss2, "NumNZSnp_last": nnz2,
                             "pipeline": {"persistent_chain": geo2[0], "lookahead_groups": geo2[1], "panels_per_matvec": geo2[2]}}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
