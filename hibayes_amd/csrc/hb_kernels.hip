@@ -779,12 +779,16 @@ struct persist_view {
 __global__ __launch_bounds__(512) void k_hotlist(const hb_sweep_in *__restrict__ pin, const double *__restrict__ vx,
                                                  const double *__restrict__ g, const double *__restrict__ thr0,
                                                  const double *__restrict__ xpx, double kappa, int P, int nslot,
-                                                 int *__restrict__ slot_of, int *__restrict__ hotlist, int *__restrict__ nhot)
+                                                 int *__restrict__ slot_of, int *__restrict__ hotlist, int *__restrict__ nhot,
+                                                 uint8_t *__restrict__ tracker)
 {
     __shared__ int wcnt[16];
     const int p = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63, S = P >> 6;
     const int j = p * P + t;
     const bool hot = vx[j] != 0.0 && (g[j] != 0.0 || thr0[j] <= kappa * xpx[j] * pin->vare);
+    // the chain only rewrites the class of markers that are or were in the model: a marker at zero is class 0 by
+    // definition, whatever state the caller may have installed
+    if (g[j] == 0.0) tracker[j] = 0;
     const unsigned long long hmask = __ballot(hot);
     if (lane == 0) wcnt[wave] = __popcll(hmask);
     __syncthreads();
@@ -1840,7 +1844,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     }
     const int ns = persist_nslot(c->P);
     hipLaunchKernelGGL(k_hotlist, dim3(np), dim3(c->P), 0, sA, c->d_in, c->vx, c->g, c->thr, c->xpx, c->kappa, c->P, ns, c->hot_slot,
-                       c->hot_list, c->hot_n);
+                       c->hot_list, c->hot_n, c->tracker);
     HB_HIP(hipEventRecord(c->ev_fork, sA));
     HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
     chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
