@@ -258,21 +258,27 @@ __global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64
     __shared__ acc_t red[4][8];
     const int ct = blockIdx.x, tid = threadIdx.x;
     int sp = blockIdx.y;
-    if (sy.red_ncols > 0) { // first grid row: add up the previous launch's partials
+    if (uq.p1 > uq.p0) {
+        // Pipeline launch: the FIRST grid row carries the residual update of an earlier group (its result is the version
+        // the NEXT launch reads), so there is no third stream and no cross-stream event. First, because workgroups are
+        // dispatched in grid order: these few start with the launch, wait for the chain workgroup while the tiles stream,
+        // and are done long before the launch ends (as the last row they only got a compute unit when the tiles were nearly
+        // through, and every launch ended with their wait, event fetch and column loads: +4 us on 23).
+        if (sp == 0) {
+            __shared__ int s_ix[512];
+            __shared__ double s_dl[512];
+            __shared__ int s_ok;
+            for (int blk = ct; (int64_t)blk * 1024 < ld; blk += gridDim.x) update_rows(ld, uq, blk, s_ix, s_dl, &s_ok);
+            return;
+        }
+        sp -= 1;
+    }
+    if (sy.red_ncols > 0) { // next row: add up the previous launch's partials
         if (sp == 0) {
             reduce_partials(sy, pstride, ct, tid);
             return;
         }
         sp -= 1;
-    }
-    if (uq.p1 > uq.p0 && blockIdx.y == gridDim.y - 1) {
-        // fused launch: the last grid row carries the residual update of an earlier group (its result is the
-        // version the NEXT launch reads), so the pipeline needs no third stream and no cross-stream events
-        __shared__ int s_ix[512];
-        __shared__ double s_dl[512];
-        __shared__ int s_ok;
-        for (int blk = ct; (int64_t)blk * 1024 < ld; blk += gridDim.x) update_rows(ld, uq, blk, s_ix, s_dl, &s_ok);
-        return;
     }
     const int8_t *xc = X + (int64_t)ct * 8 * ld;
     acc_t acc[8];
