@@ -173,8 +173,14 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
     }
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int total = 0;
+    int nevs[8]; // the group's event counts in one round trip (a group has at most 8 panels)
+#pragma unroll
+    for (int i = 0; i < 8; i++) nevs[i] = ld_sc1(q.ev_count + min(q.p0 + i, q.p1 - 1));
     for (int p = q.p0; p < q.p1; p++) {
-        const int nev = ld_sc1(q.ev_count + p);
+        int nev = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) nev = (p - q.p0 == i) ? nevs[i] : nev;
+        if (p - q.p0 >= 8) nev = ld_sc1(q.ev_count + p);
         if (nev == 0) continue; // uniform
         total += nev;
         __syncthreads();
