@@ -23,7 +23,7 @@ int hbk_f64_to_i8(hb_ctx *c, const double *dsrc, int64_t lds, int ncols, int8_t 
 int hbk_bed_decode(hb_ctx *c, const uint8_t *dbed, int64_t bpc, int nind, const int32_t *drows, int col0, int ncols);
 int hbk_generate(hb_ctx *c, uint64_t seed, int mono_every);
 int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out);
-int hbk_time_matvec(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us, int *launches);
+int hbk_time_matvec(hb_ctx *c, int D, int reps, int as_pipeline, double *avg_us, int *launches);
 
 static thread_local std::string g_err;
 

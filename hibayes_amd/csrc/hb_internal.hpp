@@ -39,7 +39,7 @@ struct hb_ctx {
     int D = 1;     // panels per mat-vec launch
     int NB = 1;    // residual versions kept = Lv + D
     int pipeline = 0;              // 0: serial kernels per panel; 1: persistent chain workgroup + flags
-    unsigned int *flags = nullptr; // [0] chain_done, [1] abort, [2] spare, [4 + g] mat-vec tickets of group g
+    unsigned int *flags = nullptr; // [0] chain_done (panels whose moves are published), [1] abort
     unsigned int *h_flags = nullptr;
     int *hot_slot = nullptr, *hot_list = nullptr, *hot_n = nullptr; // per-sweep hot-lists (k_hotlist)
     int64_t ld = 0; // bytes per genotype column on device (multiple of 256)

@@ -26,9 +26,7 @@
 // fence either (cdna_hip_programming.md §6 Guideline 16, forms R1 / "sc1 both sides").
 #define HB_FLAG_CHAIN_DONE 0
 #define HB_FLAG_ABORT 1
-#define HB_FLAG_TICKET0 64          /* 32 arrival counters, one per 256-byte line (64 words apart) */
-#define HB_NSUB 32
-#define HB_SUB_STRIDE 64
+#define HB_NFLAGS 64                /* words in the flag block */
 #define HB_TIMEOUT_TICKS 300000000ull /* wall_clock64() runs at 100 MHz: 3 s */
 
 __device__ __forceinline__ unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -765,9 +763,9 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
 
 // ---------------------------------------------------------------------------------------------
 // k_chain_persist: the same serial chain as k_chain, as ONE workgroup that lives for the whole sweep.
-// It walks the panels in order; panel p starts when the mat-vec group holding it has counted all its
-// workgroups into the ticket word, and ends by publishing the panel's moves (write-through) and
-// chain_done = p + 1, which the update kernel of panel p is waiting for.  Because the mat-vec of a later
+// It walks the panels in order; panel p starts when its reduced dots have been written (dsum[] is pre-filled with
+// a NaN pattern), and a group of panels ends by publishing its moves (write-through) and chain_done = last
+// panel + 1, which the update row of that group is waiting for.  Because the mat-vec of a later
 // panel q may have read a residual that does not contain panel p's moves yet (q's group read version
 // g(q) D - Lv - 1), each move is also folded forward into the per-thread correction registers corr[l]
 // of the next Lb panels through the band Gram blocks  G_l[q][k][t] = x_{pP+k} . x_{qP+t},  l = q - p.
@@ -1661,13 +1659,13 @@ static hipError_t launch_chain(hb_ctx *c, const chain_view &cv, int p, hipStream
 // residual version v (moves of panels <= v applied; v = -1: start of the sweep) lives in slot (v+1) mod NB
 static inline int ver_slot(const hb_ctx *c, int v) { return (v + 1) % c->NB; }
 
-static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, bool ticket = false,
+static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, bool pipeline = false,
                        const upd_view *upd = nullptr, int red_col0 = 0, int red_ncols = 0)
 {
     if (!st) st = c->stream;
     upd_view uq{};
     if (upd) uq = *upd;
-    if (!ticket) red_ncols = 0;
+    if (!pipeline) red_ncols = 0;
     const dim3 grid(ncols / 8, c->nsplit + (uq.p1 > uq.p0 ? 1 : 0) + (red_ncols > 0 ? 1 : 0)), block(256);
     const int8_t *Xp = c->X + (int64_t)col0 * c->ld;
     double *part = c->partial + col0;
@@ -1835,11 +1833,10 @@ static hipError_t launch_chain_persist(hb_ctx *c, const chain_view &cv, const pe
     return hipGetLastError();
 }
 
-// Persistent pipeline: stream A = mat-vec groups, stream B = ONE chain workgroup for the whole sweep,
-// stream C = residual updates.  Device-side hand-offs: mat-vec -> chain through the group's ticket word,
-// chain -> update through chain_done; update -> mat-vec stays a kernel-boundary dependency (graph edge),
-// and every update also has an edge from its own mat-vec group so that a spinning update kernel can never
-// sit in front of work the chain is waiting for.
+// Persistent pipeline: stream A = mat-vec launches (each also carrying an update row and a partial-sum row),
+// stream B = ONE chain workgroup for the whole sweep.  Device-side hand-offs: mat-vec -> chain through dsum[]
+// (NaN-prefilled, written through by the partial-sum row of the next launch); chain -> update through
+// chain_done; update -> mat-vec is a kernel boundary on stream A.
 static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
 {
     const int kp = kpad_for(model, n_fold);
@@ -1847,7 +1844,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     const int ngroups = (np + D - 1) / D;
     hipStream_t sA = c->stream, sB = c->s_chain;
     HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, sA));
-    HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * (HB_FLAG_TICKET0 + HB_NSUB * HB_SUB_STRIDE), sA));
+    HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * HB_NFLAGS, sA));
     HB_HIP(hipMemsetAsync(c->ev_count, 0, sizeof(int32_t) * (size_t)np, sA)); // quiet panels do not write theirs
     HB_HIP(hipMemsetAsync(c->dsum, 0xFF, sizeof(double) * (size_t)c->m_pad, sA)); // "not written yet": a NaN no sum can produce
     {
@@ -2065,25 +2062,25 @@ int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out)
     return HB_OK;
 }
 
-// hb_ctx_time_matvec: the panel mat-vec launches of one sweep, exactly as the pipeline issues them (same grouping,
-// same arrival counters), back to back on the context's stream between two HIP events
-int hbk_time_matvec(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us, int *launches)
+// hb_ctx_time_matvec: the panel mat-vec launches of one sweep, as the pipeline issues them (same grouping, same
+// partial-sum rows; no update row), back to back on the context's stream between two HIP events
+int hbk_time_matvec(hb_ctx *c, int D, int reps, int as_pipeline, double *avg_us, int *launches)
 {
     HB_HIP(hipSetDevice(c->device));
     hipEvent_t e0, e1;
     HB_HIP(hipEventCreate(&e0));
     HB_HIP(hipEventCreate(&e1));
     const int ngroups = (c->npanels + D - 1) / D;
-    HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * (HB_FLAG_TICKET0 + HB_NSUB * HB_SUB_STRIDE), c->stream));
+    HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * HB_NFLAGS, c->stream));
     for (int warm = 0; warm < 2; warm++) {
         if (warm) HB_HIP(hipEventRecord(e0, c->stream));
         for (int r = 0; r < (warm ? reps : 1); r++) {
             for (int g = 0; g < ngroups; g++) {
                 const int p0 = g * D, p1 = std::min(c->npanels, p0 + D);
-                launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, use_ticket != 0, nullptr,
+                launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, as_pipeline != 0, nullptr,
                            g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0);
             }
-            if (use_ticket) launch_reduce(c, (ngroups - 1) * D * c->P, (c->npanels - (ngroups - 1) * D) * c->P, c->stream);
+            if (as_pipeline) launch_reduce(c, (ngroups - 1) * D * c->P, (c->npanels - (ngroups - 1) * D) * c->P, c->stream);
         }
     }
     HB_HIP(hipEventRecord(e1, c->stream));
@@ -2097,7 +2094,7 @@ int hbk_time_matvec(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us, 
     return HB_OK;
 }
 
-extern "C" int hbk_dot_bench(hb_ctx *c, int D, int reps, int use_ticket, double *avg_us)
+extern "C" int hbk_dot_bench(hb_ctx *c, int D, int reps, int as_pipeline, double *avg_us)
 {
-    return hbk_time_matvec(c, D, reps, use_ticket, avg_us, nullptr);
+    return hbk_time_matvec(c, D, reps, as_pipeline, avg_us, nullptr);
 }
