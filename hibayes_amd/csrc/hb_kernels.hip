@@ -816,8 +816,11 @@ __global__ __launch_bounds__(512) void k_hotlist(const hb_sweep_in *__restrict__
 }
 
 // Forward corrections of one batch shape: FW moves x up to LB band blocks, all loads in flight together.
+// Panel q = p + l needs the correction iff its mat-vec group read a residual without panel p's moves:
+// q / D <= p / D + Lv, i.e. l <= (Lv + 1) D - 1 - p mod D — a contiguous range 1..lcount, computed once per panel by the
+// caller (no division here).
 template <int LB, int FW>
-__device__ __forceinline__ void fold_forward(double (&corr)[HB_LBMAX], const int32_t *__restrict__ gram, const persist_view &pv, int p, int np,
+__device__ __forceinline__ void fold_forward(double (&corr)[HB_LBMAX], const int32_t *__restrict__ gram, int Lb, int lcount, int p,
                                              int P, int t, int nev, const int *ev_ix, const double *ev_del)
 {
     for (int e0 = 0; e0 < nev; e0 += FW) {
@@ -832,20 +835,15 @@ __device__ __forceinline__ void fold_forward(double (&corr)[HB_LBMAX], const int
         }
 #pragma unroll
         for (int l = 1; l <= LB; l++) {
-            const int q = p + l;
-            // panel q's mat-vec group g = q / D read the residual with every panel < (g - Lv) * D applied
-            const bool need = l <= pv.Lb && q < np && p >= (q / pv.D - pv.Lv) * pv.D;
-            if (need) {
-                const int32_t *gx = gram + ((size_t)q * (pv.Lb + 1) + l) * P * P + t;
+            if (l <= lcount) { // uniform
+                const int32_t *gx = gram + ((size_t)(p + l) * (Lb + 1) + l) * P * P + t;
 #pragma unroll
                 for (int f = 0; f < FW; f++) gv[l - 1][f] = gx[(size_t)kk[f] * P];
             }
         }
 #pragma unroll
         for (int l = 1; l <= LB; l++) {
-            const int q = p + l;
-            const bool need = l <= pv.Lb && q < np && p >= (q / pv.D - pv.Lv) * pv.D;
-            if (need) {
+            if (l <= lcount) {
 #pragma unroll
                 for (int f = 0; f < FW; f++) corr[l - 1] = fma((double)gv[l - 1][f], dl[f], corr[l - 1]);
             }
@@ -964,7 +962,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         default: f(std::integral_constant<int, 3 % Q>{}); break;
         }
     };
+    int pmodD = -1; // p mod D, without a division per panel
     for (int p = 0; ok && p < np; p++) {
+        pmodD = (pmodD + 1 == pv.D) ? 0 : pmodD + 1;
         const int j = p * P + t;
         const int cur = p & 1;
         int32_t *rowc = rowc0 + (size_t)cur * nslot * P;
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         const bool active = myslot > -2;
         const bool hot = active && gold != 0.0;
         const bool have_next = p + 1 < np;
-        const bool group_end = have_next && (p + 1) % pv.D == 0;
+        const bool group_end = have_next && pmodD == pv.D - 1;
         const int32_t *gpn = gp + (size_t)(pv.Lb + 1) * P * P;
         {   // who can move at all: certain movers and markers near their entry threshold (first round of the chain)
             const unsigned long long cm0 = __ballot(active && (hot || rhs * rhs >= pv.candf * thr[0]));
@@ -1297,9 +1297,10 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             HB_STAMP(5);
             // ---- fold the moves forward into the corrections of the next Lb panels ----
             if (nev > 0) { // batch shape by band width: as many loads in flight as the registers allow
-                if (pv.Lb <= 2) fold_forward<2, 16>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
-                else if (pv.Lb <= 5) fold_forward<5, 8>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
-                else fold_forward<HB_LBMAX, 4>(corr, v.gram, pv, p, np, P, t, nev, ev_ix, ev_del);
+                const int lcount = min(min(pv.Lb, (pv.Lv + 1) * pv.D - 1 - pmodD), np - 1 - p); // panels that need the correction
+                if (pv.Lb <= 2) fold_forward<2, 16>(corr, v.gram, pv.Lb, lcount, p, P, t, nev, ev_ix, ev_del);
+                else if (pv.Lb <= 5) fold_forward<5, 8>(corr, v.gram, pv.Lb, lcount, p, P, t, nev, ev_ix, ev_del);
+                else fold_forward<HB_LBMAX, 2>(corr, v.gram, pv.Lb, lcount, p, P, t, nev, ev_ix, ev_del);
             }
         } else {
             cacc[0] += active ? 1 : 0; // a quiet panel: nothing moved, nothing to write
