@@ -1145,7 +1145,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                         gval[u8] = 0;
                         if (idx < ncr * 64 && k < c && c < ncr) {
                             const int sk = cs_slot[k];
-                            gval[u8] = sk >= 0 ? rowc[(size_t)sk * P + cs_t[c]] : gp[(size_t)cs_t[k] * P + cs_t[c]];
+                            gval[u8] = rowc[max(sk, 0) * P + cs_t[c]];
+                            if (sk < 0) gval[u8] = gp[(size_t)cs_t[k] * P + cs_t[c]];
                         }
                     }
 #pragma unroll
@@ -1196,11 +1197,20 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                         if (lane == k) { rc = cls; rg = gn; }
                         const double dk = readlane_f64(delta, k);
                         if (dk != 0.0) {
+                            // (the LDS read is unconditional on purpose: a select between an LDS and a global address becomes one
+                            // flat load, and a flat load waits for every outstanding vector-memory operation)
                             int gv;
-                            if (crowded) gv = cg[k * 64 + lane];
-                            else {
+                            if (crowded) {
+                                gv = cg[k * 64 + lane];
+                                asm volatile("" : "+v"(gv)); // (keeps the three loads apart)
+                            } else {
                                 const int sk = __builtin_amdgcn_readlane(cslot, k);
-                                gv = sk >= 0 ? rowc[(size_t)sk * P + ct] : gp[(size_t)__builtin_amdgcn_readlane(ct, k) * P + ct];
+                                gv = rowc[max(sk, 0) * P + ct];                                                // always: LDS
+                                asm volatile("" : "+v"(gv));
+                                if (sk < 0) {
+                                    gv = gp[(size_t)__builtin_amdgcn_readlane(ct, k) * P + ct];               // a miss: global
+                                    asm volatile("" : "+v"(gv));
+                                }
                             }
                             if (lane > k) crhs = fma(-(double)gv, dk, crhs);
                             if (lane == k) { ev_ix[cnt] = (cslot << 16) | ct; ev_del[cnt] = dk; }
@@ -1231,8 +1241,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                         for (int q8 = 0; q8 < 8; q8++) {
                             const int slot = __builtin_amdgcn_readfirstlane(rec[q8] >> 16);
                             const int k = __builtin_amdgcn_readfirstlane(rec[q8] & 0xffff);
-                            if (slot >= 0) gv[q8] = rowc[(size_t)slot * P + t];
-                            else gv[q8] = gp[(size_t)k * P + t];
+                            gv[q8] = rowc[max(slot, 0) * P + t];
+                            if (slot < 0) gv[q8] = gp[(size_t)k * P + t];
                         }
 #pragma unroll
                         for (int q8 = 0; q8 < 8; q8++) {
