@@ -262,7 +262,7 @@ def main():
     value = world * K / elapsed
     Pi, fold = prior(args.model)
     res = {
-        "metric": "Gibbs sweeps/sec (full m-marker pass), n=50k m=500k",
+        "metric": "Gibbs sweeps/sec (full m-marker pass) + achieved HBM GB/s, n=50k m=500k",
         "value": value, "unit": "sweeps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64" if args.precise else "f32", "data": "synthetic",
