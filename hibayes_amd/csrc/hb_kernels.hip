@@ -851,6 +851,13 @@ __device__ __forceinline__ void fold_forward(double (&corr)[HB_LBMAX], const int
     }
 }
 
+// the eight per-wave words of a small LDS array in two vector reads (a panel has at most 8 waves; absent waves' words are 0)
+__device__ __forceinline__ void hb_read8(const int *w, int (&o)[8])
+{
+    const int4 a = *reinterpret_cast<const int4 *>(w), b = *reinterpret_cast<const int4 *>(w + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
 // Software-pipelined version: everything panel p+1 needs that does not depend on panel p's outcome is fetched
 // while panel p's serial turns run — its per-marker coefficients, its mat-vec partials (if that mat-vec has
 // already finished) and the Gram rows of its hot markers (into the other half of a double-buffered LDS row
@@ -917,7 +924,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     int hl_reg = 0, nh_reg = 0;
 
     // ---- prologue: fill the ring ----
-    if (t < 128) cnts[t] = 0;
+    for (int i = t; i < 128; i += P) cnts[i] = 0; // (a 64-marker panel has 64 threads; absent waves' words must read 0)
 #pragma unroll
     for (int u = 0; u < Q; u++) {
         const int jq = min(u, np - 1) * P + t;
@@ -1028,7 +1035,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         HB_STAMP(1);
         __syncthreads(); // the panel's one fixed barrier: wcnt[], hl[], *s_nh staged; everybody is done with panel p-1
         int tot0 = 0;
-        for (int w = 0; w < S; w++) tot0 += wcnt[w];
+        {
+            int w8[8];
+            hb_read8(wcnt, w8);
+#pragma unroll
+            for (int w = 0; w < 8; w++) tot0 += w8[w];
+        }
         if (tot0 >> 16) { ok = false; break; } // a wave gave up waiting for its dots: the sweep is aborted
         if (have_next) n_nhot = *s_nh;
         const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
@@ -1108,10 +1120,15 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                 }
                 first = false;
                 int basec = 0, tot = 0;
-                for (int w = 0; w < S; w++) {
-                    const int c = wcnt[w];
-                    basec += (w < wave) ? c : 0;
-                    tot += c;
+                {
+                    int w8[8];
+                    hb_read8(wcnt, w8);
+#pragma unroll
+                    for (int w = 0; w < 8; w++) {
+                        const int c = w8[w] & 0xffff;
+                        basec += (w < wave) ? c : 0;
+                        tot += c;
+                    }
                 }
                 if (tot == 0) break; // nobody left can move
                 const int rank = basec + __popcll(cm & ((1ull << lane) - 1ull));
@@ -1257,7 +1274,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                 if (lane == 0) wviol[wave] = vm != 0ull;
                 __syncthreads();
                 bool anyv = false;
-                for (int w = 0; w < S; w++) anyv |= wviol[w] != 0;
+                {
+                    int w8[8];
+                    hb_read8(wviol, w8);
+#pragma unroll
+                    for (int w = 0; w < 8; w++) anyv |= w8[w] != 0;
+                }
                 if (anyv) { // roll the round back; the markers that crossed their threshold join the candidates
                     forced |= viol;
                     if (t == 0) cnts[0] = nev0;
