@@ -1192,14 +1192,10 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                     const unsigned long long vmask = __ballot(lv);
                     const unsigned long long hotm = __ballot(lv && cgold != 0.0);
                     const unsigned long long noslot = __ballot(lv && cslot < 0);
-                    int rc = 0;
-                    double rg = 0.0;
-                    int cnt = nev0;
-                    for (int k = 0; k < ncr; k++) {
-                        const double q = crhs * crhs;
-                        const unsigned long long mv = (__ballot(q >= cthr[0]) & vmask) | hotm;
-                        if (!((mv >> k) & 1ull)) continue; // uniform: lane k stays where it is
-                        int cls = 0;
+                    // what each lane draws from its current rhs: class, new effect, change (the lane's own step reads these)
+                    auto decide = [&](double rhsv, int &cls, double &gn) {
+                        const double q = rhsv * rhsv;
+                        cls = 0;
                         double iv = 0.0, sz = 0.0;
 #pragma unroll
                         for (int c = 0; c < K1; c++) {
@@ -1208,11 +1204,17 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                             iv = ge ? cinvv[c] : iv;
                             sz = ge ? csdz[c] : sz;
                         }
-                        double gn = (cls > 0) ? fma(crhs, iv, sz) : 0.0;
+                        gn = (cls > 0) ? fma(rhsv, iv, sz) : 0.0;
                         if (model == 5 && fabs(gn) < 1e-6) gn = 1e-6;
-                        const double delta = gn - cgold;
-                        if (lane == k) { rc = cls; rg = gn; }
-                        const double dk = readlane_f64(delta, k);
+                    };
+                    for (int k = 0; k < ncr; k++) {
+                        const double q = crhs * crhs;
+                        const unsigned long long mv = (__ballot(q >= cthr[0]) & vmask) | hotm;
+                        if (!((mv >> k) & 1ull)) continue; // uniform: lane k stays where it is
+                        int cls;
+                        double gn;
+                        decide(crhs, cls, gn);
+                        const double dk = readlane_f64(gn - cgold, k);
                         if (dk != 0.0) {
                             // (the LDS read is unconditional on purpose: a select between an LDS and a global address becomes one
                             // flat load, and a flat load waits for every outstanding vector-memory operation)
@@ -1230,14 +1232,29 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                                 }
                             }
                             if (lane > k) crhs = fma(-(double)gv, dk, crhs);
-                            if (lane == k) { ev_ix[cnt] = (cslot << 16) | ct; ev_del[cnt] = dk; }
-                            missacc += (int)((noslot >> k) & 1ull);
-                            cnt++;
                         }
                     }
-                    res_c[lane] = rc;
-                    res_g[lane] = rg;
-                    if (lane == 0) cnts[0] = cnt;
+                    // Lane k's rhs is not touched after its own step, so its outcome can be read off now, for all lanes at once:
+                    // the same decision from the same number, without per-step bookkeeping. Moves are listed in lane (= marker) order.
+                    {
+                        int cls;
+                        double gn;
+                        decide(crhs, cls, gn);
+                        const bool sel = lv && (cgold != 0.0 || crhs * crhs >= cthr[0]);
+                        const int rc = sel ? cls : 0;
+                        const double rg = sel ? gn : 0.0;
+                        const double dmine = rg - cgold;
+                        const unsigned long long moved = __ballot(lv && dmine != 0.0);
+                        if (lv && dmine != 0.0) {
+                            const int pos = nev0 + __popcll(moved & ((1ull << lane) - 1ull));
+                            ev_ix[pos] = (cslot << 16) | ct;
+                            ev_del[pos] = dmine;
+                        }
+                        missacc += __popcll(moved & noslot);
+                        res_c[lane] = rc;
+                        res_g[lane] = rg;
+                        if (lane == 0) cnts[0] = nev0 + __popcll(moved);
+                    }
                 }
                 if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(13);
                 __syncthreads();
