@@ -197,3 +197,21 @@ def test_invariants_at_baseline_size(model):
         assert np.array_equal(trk != 0, g != 0)
         assert s["sum_r2"] == pytest.approx((r * r).sum(), rel=1e-10)
         assert s["var_u"] == pytest.approx(u.var(ddof=1), rel=1e-9)
+
+
+@pytest.mark.parametrize("K", [2, 3, 6, 8])
+def test_bayesr_class_counts_draw_for_draw_against_the_oracle(K):
+    # BayesR with other numbers of mixture classes than the default four (the chain kernel is instantiated for 1, <=3 and
+    # <=7 non-null classes): the oracle is the checker, computed here under the same Philox counters
+    g = np.load(os.path.join(G, "small_all_models_philox.npz"))
+    fold = [0.0] + [10.0 ** e for e in np.linspace(-4, -1.5, K - 1)]
+    Pi = [1.0 - (K - 1) / 16.0] + [1.0 / 16.0] * (K - 1)   # dyadic: the reference compares sum(Pi) with 1 exactly
+    kw = dict(fold=fold, niter=16, nburn=6, thin=2, seed=424242)
+    ref = O.bayes(g["y"], g["X"], "BayesR", Pi, rng=O.RNG_PHILOX, store_alpha=True, **kw)
+    for panel in (64, 512):
+        r = H.Bayes(g["y"], g["X"], "BayesR", Pi, verbose=False, precise=True, panel=panel, **kw)
+        a, b = r["MCMCsamples"]["alpha"], ref["s_alpha"]
+        assert np.array_equal(a != 0, b != 0)
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(r["pi"], ref["pi"], rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"], r["mu"]], [ref["Vg"], ref["Ve"], ref["h2"], ref["mu"]], rtol=1e-9)
