@@ -215,3 +215,22 @@ def test_bayesr_class_counts_draw_for_draw_against_the_oracle(K):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(r["pi"], ref["pi"], rtol=1e-9, atol=1e-14)
         np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"], r["mu"]], [ref["Vg"], ref["Ve"], ref["h2"], ref["mu"]], rtol=1e-9)
+
+
+@pytest.mark.parametrize("n,m", [(37, 5), (257, 65), (64, 513)])
+def test_ragged_tiny_shapes_draw_for_draw_against_the_oracle(n, m):
+    # fewer markers than a panel, row counts that are not a multiple of anything, a panel boundary at m - 1, an all-constant column
+    rng = np.random.default_rng(n * 1000 + m)
+    p = rng.uniform(0.1, 0.5, m)
+    X = ((rng.random((n, m)) < p).astype(np.int8) + (rng.random((n, m)) < p).astype(np.int8))
+    X[:, m // 2] = 1
+    y = X[:, : min(m, 3)].astype(float) @ np.array([0.8, -0.5, 0.3])[: min(m, 3)] + rng.normal(0, 1, n)
+    for model, Pi, fold in (("BayesCpi", [0.75, 0.25], None), ("BayesR", [0.5, 0.25, 0.125, 0.125], [0, 1e-3, 1e-2, 1e-1])):
+        kw = dict(fold=fold, niter=12, nburn=4, thin=2, seed=7)
+        ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, **kw)
+        r = H.Bayes(y, np.asfortranarray(X), model, Pi, verbose=False, precise=True, **kw)
+        a, b = r["MCMCsamples"]["alpha"], ref["s_alpha"]
+        assert np.array_equal(a != 0, b != 0)
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
+        assert (a[m // 2] == 0).all()
+        np.testing.assert_allclose([r["Vg"], r["Ve"], r["mu"]], [ref["Vg"], ref["Ve"], ref["mu"]], rtol=1e-9)
