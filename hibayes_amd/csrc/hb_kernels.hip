@@ -767,7 +767,7 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
 // a NaN pattern), and a group of panels ends by publishing its moves (write-through) and chain_done = last
 // panel + 1, which the update row of that group is waiting for.  Because the mat-vec of a later
 // panel q may have read a residual that does not contain panel p's moves yet (q's group read version
-// g(q) D - Lv - 1), each move is also folded forward into the per-thread correction registers corr[l]
+// g(q) D - Lv - 1), each move is also folded forward into the per-marker corrections (an LDS ring, one slot per panel)
 // of the next Lb panels through the band Gram blocks  G_l[q][k][t] = x_{pP+k} . x_{qP+t},  l = q - p.
 // ---------------------------------------------------------------------------------------------
 struct persist_view {
@@ -820,8 +820,8 @@ __global__ __launch_bounds__(512) void k_hotlist(const hb_sweep_in *__restrict__
 // q / D <= p / D + Lv, i.e. l <= (Lv + 1) D - 1 - p mod D — a contiguous range 1..lcount, computed once per panel by the
 // caller (no division here).
 template <int LB, int FW>
-__device__ __forceinline__ void fold_forward(double (&corr)[HB_LBMAX], const int32_t *__restrict__ gram, int Lb, int lcount, int p,
-                                             int P, int t, int nev, const int *ev_ix, const double *ev_del)
+__device__ __forceinline__ void fold_forward(double *corrL, int R, const int32_t *__restrict__ gram, int Lb, int lcount, int pslot,
+                                             int P, int t, int nev, const int *ev_ix, const double *ev_del, int p)
 {
     for (int e0 = 0; e0 < nev; e0 += FW) {
         int gv[LB][FW];
@@ -841,11 +841,16 @@ __device__ __forceinline__ void fold_forward(double (&corr)[HB_LBMAX], const int
                 for (int f = 0; f < FW; f++) gv[l - 1][f] = gx[(size_t)kk[f] * P];
             }
         }
+        int slot = pslot; // ring slot of panel p + l
 #pragma unroll
         for (int l = 1; l <= LB; l++) {
+            slot = (slot + 1 == R) ? 0 : slot + 1;
             if (l <= lcount) {
+                double *cp = corrL + (size_t)slot * P + t; // this thread's own word: no synchronisation needed
+                double acc = *cp;
 #pragma unroll
-                for (int f = 0; f < FW; f++) corr[l - 1] = fma((double)gv[l - 1][f], dl[f], corr[l - 1]);
+                for (int f = 0; f < FW; f++) acc = fma((double)gv[l - 1][f], dl[f], acc);
+                *cp = acc;
             }
         }
     }
@@ -892,9 +897,12 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     const int count_pip = pin->count_pip, store = pin->store;
     const int lgP = 31 - __clz(P);
     const int np = pv.npanels;
-    double corr[HB_LBMAX];
-#pragma unroll
-    for (int l = 0; l < HB_LBMAX; l++) corr[l] = 0.0;
+    // corrections still owed to the next Lb panels: ring of Lb + 1 slots of P doubles in LDS, slot = panel mod ring size;
+    // every thread only ever touches its own column, so the ring needs no barrier
+    const int R = pv.Lb + 1;
+    double *corrL = reinterpret_cast<double *>(cg + 64 * 64);
+    for (int l = 0; l < R; l++) corrL[(size_t)l * P + t] = 0.0;
+    int pslot = -1; // p mod R
     double wacc = 0.0;
     int cacc[K1 + 1];
 #pragma unroll
@@ -972,6 +980,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     int pmodD = -1; // p mod D, without a division per panel
     for (int p = 0; ok && p < np; p++) {
         pmodD = (pmodD + 1 == pv.D) ? 0 : pmodD + 1;
+        pslot = (pslot + 1 == R) ? 0 : pslot + 1;
         const int j = p * P + t;
         const int cur = p & 1;
         int32_t *rowc = rowc0 + (size_t)cur * nslot * P;
@@ -1015,10 +1024,11 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         thr[0] = thr0v;
         double rhs = dj;
         if (gold != 0.0) rhs = fma(xx, gold, rhs);
-        rhs -= corr[0];
-#pragma unroll
-        for (int l = 0; l + 1 < HB_LBMAX; l++) corr[l] = corr[l + 1];
-        corr[HB_LBMAX - 1] = 0.0;
+        {
+            double *cp = corrL + (size_t)pslot * P + t;
+            rhs -= *cp;
+            *cp = 0.0; // the slot is panel p + R's from now on
+        }
         const bool active = myslot > -2;
         const bool hot = active && gold != 0.0;
         const bool have_next = p + 1 < np;
@@ -1347,9 +1357,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             // ---- fold the moves forward into the corrections of the next Lb panels ----
             if (nev > 0) { // batch shape by band width: as many loads in flight as the registers allow
                 const int lcount = min(min(pv.Lb, (pv.Lv + 1) * pv.D - 1 - pmodD), np - 1 - p); // panels that need the correction
-                if (pv.Lb <= 2) fold_forward<2, 16>(corr, v.gram, pv.Lb, lcount, p, P, t, nev, ev_ix, ev_del);
-                else if (pv.Lb <= 5) fold_forward<5, 8>(corr, v.gram, pv.Lb, lcount, p, P, t, nev, ev_ix, ev_del);
-                else fold_forward<HB_LBMAX, 2>(corr, v.gram, pv.Lb, lcount, p, P, t, nev, ev_ix, ev_del);
+                if (pv.Lb <= 2) fold_forward<2, 16>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                else if (pv.Lb <= 5) fold_forward<5, 8>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                else fold_forward<HB_LBMAX, 2>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
             }
         } else {
             cacc[0] += active ? 1 : 0; // a quiet panel: nothing moved, nothing to write
@@ -1681,8 +1691,8 @@ static inline int kpad_for(int model, int n_fold)
 
 // LDS budget of k_chain: as many Gram rows as fit beside the event lists
 static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128 + 128 + 64)) / ((size_t)P * 4)); }
-#define HB_PERSIST_FIXED(P) ((size_t)(P) * 20 + 128 + 512 + 64 * (8 * (3 + 3 * 7) + 12) + 64 * 64 * 4)
-static int persist_nslot(int P) { return std::min(P, std::min(160, (int)((160 * 1024 - HB_PERSIST_FIXED(P)) / ((size_t)P * 8)))); }
+#define HB_PERSIST_FIXED(P, LB) ((size_t)(P) * 20 + 128 + 512 + 64 * (8 * (3 + 3 * 7) + 12) + 64 * 64 * 4 + (size_t)((LB) + 1) * (P) * 8)
+static int persist_nslot(int P, int Lb) { return std::min(P, std::min(160, (int)((160 * 1024 - HB_PERSIST_FIXED(P, Lb)) / ((size_t)P * 8)))); }
 // the whole 160 KiB: nothing that needs LDS (mat-vec, update) can then be co-scheduled on the chain's CU
 static size_t persist_smem(int) { return (size_t)160 * 1024; }
 static size_t chain_smem(int P) { return (size_t)chain_nslot(P) * P * 4 + (size_t)P * 16 + 128 + 128 + 64; }
@@ -1879,7 +1889,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
 template <int K1>
 static hipError_t launch_chain_persist(hb_ctx *c, const chain_view &cv, const persist_view &pv, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_chain_persist<K1>, dim3(1), dim3(c->P), persist_smem(c->P), st, c->d_in, cv, pv, persist_nslot(c->P));
+    hipLaunchKernelGGL(k_chain_persist<K1>, dim3(1), dim3(c->P), persist_smem(c->P), st, c->d_in, cv, pv, persist_nslot(c->P, c->L));
     return hipGetLastError();
 }
 
@@ -1901,7 +1911,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
         pre_view pvw{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
         hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pvw);
     }
-    const int ns = persist_nslot(c->P);
+    const int ns = persist_nslot(c->P, c->L);
     hipLaunchKernelGGL(k_hotlist, dim3(np), dim3(c->P), 0, sA, c->d_in, c->vx, c->g, c->thr, c->xpx, c->kappa, c->P, ns, c->hot_slot,
                        c->hot_list, c->hot_n, c->tracker);
     HB_HIP(hipEventRecord(c->ev_fork, sA));
