@@ -48,7 +48,7 @@ static void hb_pipeline_geometry(hb_ctx *c)
     c->Lv = std::max(0, std::min(6, c->Lv));
     c->D = c->pipeline ? std::max(1, std::min(8, c->D)) : 1;
     // Lv counts mat-vec GROUPS of look-ahead; the Gram band then spans (Lv + 1) * D - 1 earlier panels
-    while ((c->Lv + 1) * c->D - 1 > 12) { // HB_LBMAX in hb_kernels.hip
+    while ((c->Lv + 1) * c->D - 1 > 20) { // HB_LBMAX in hb_kernels.hip
         if (c->Lv > 1) c->Lv--; else c->D--;
     }
     c->L = std::max((c->Lv + 1) * c->D - 1, c->Lv);
@@ -109,7 +109,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     // pipeline geometry; hb_ctx_set_pipeline() changes it later
     c->pipeline = 1;
     c->Lv = 2;
-    c->D = 4;
+    c->D = 6;
     if (const char *e = getenv("HB_PIPELINE")) c->pipeline = atoi(e) ? 1 : 0;
     if (const char *e = getenv("HB_LOOKAHEAD")) c->Lv = atoi(e);
     if (const char *e = getenv("HB_DOTGROUP")) c->D = atoi(e);

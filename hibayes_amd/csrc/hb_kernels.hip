@@ -777,7 +777,7 @@ struct persist_view {
     double candf;                        // a marker at zero is a chain candidate when q >= candf * thr0 (candf <= 1)
 };
 
-#define HB_LBMAX 12
+#define HB_LBMAX 20
 #define HB_CROWD 8 /* candidates in a round from which their Gram entries are gathered up front */
 
 // Row-cache list of every panel, in marker order, capped at nslot rows: the markers that are certain to move
@@ -1359,6 +1359,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                 const int lcount = min(min(pv.Lb, (pv.Lv + 1) * pv.D - 1 - pmodD), np - 1 - p); // panels that need the correction
                 if (pv.Lb <= 2) fold_forward<2, 16>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
                 else if (pv.Lb <= 5) fold_forward<5, 8>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                else if (pv.Lb <= 12) fold_forward<12, 2>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
                 else fold_forward<HB_LBMAX, 2>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
             }
         } else {
