@@ -823,6 +823,7 @@ template <int LB, int FW>
 __device__ __forceinline__ void fold_forward(double *corrL, int R, const int32_t *__restrict__ gram, int Lb, int lcount, int pslot,
                                              int P, int t, int nev, const int *ev_ix, const double *ev_del, int p)
 {
+    const size_t PP = (size_t)P * P, step = (size_t)(Lb + 2) * PP;
     for (int e0 = 0; e0 < nev; e0 += FW) {
         int gv[LB][FW];
         int kk[FW];
@@ -830,16 +831,18 @@ __device__ __forceinline__ void fold_forward(double *corrL, int R, const int32_t
 #pragma unroll
         for (int f = 0; f < FW; f++) {
             const int e = min(e0 + f, nev - 1);
-            kk[f] = ev_ix[e] & 0xffff;
+            kk[f] = __builtin_amdgcn_readfirstlane(ev_ix[e] & 0xffff); // wave-uniform: the row addresses below are scalar
             dl[f] = (e0 + f < nev) ? ev_del[e] : 0.0;
         }
+        // block l of panel p + l starts at ((p + l)(Lb + 1) + l) P P: consecutive l are (Lb + 2) P P apart
+        const int32_t *blk = gram + ((size_t)(p + 1) * (Lb + 1) + 1) * PP;
 #pragma unroll
         for (int l = 1; l <= LB; l++) {
             if (l <= lcount) { // uniform
-                const int32_t *gx = gram + ((size_t)(p + l) * (Lb + 1) + l) * P * P + t;
 #pragma unroll
-                for (int f = 0; f < FW; f++) gv[l - 1][f] = gx[(size_t)kk[f] * P];
+                for (int f = 0; f < FW; f++) gv[l - 1][f] = (blk + (size_t)kk[f] * P)[t];
             }
+            blk += step;
         }
         int slot = pslot; // ring slot of panel p + l
 #pragma unroll
