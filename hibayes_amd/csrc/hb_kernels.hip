@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         // first to be used: the memory counter is in-order, so everything issued before a load is waited for with it.
         ring_switch(p, [&](auto U) {
             constexpr int u = decltype(U)::value;
-            if (Q >= 2) rg_d[(u + 1) % Q] = ld_sc1(&v.dsum[min(p + 1, np - 1) * P + t]);
+            if (Q >= 2) rg_d[(u + 1) % Q] = ld_sc1(v.dsum + (size_t)min(p + 1, np - 1) * P + t);
         });
         // (1) Gram rows of the next panel's hot markers: four 1-KiB pieces per wave travel during the rounds
         int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
@@ -1083,23 +1083,25 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         ring_switch(p, [&](auto U) {
             constexpr int u = decltype(U)::value;
             constexpr int sa = u & 1, sb = sa ^ 1;
-            const int j1 = min(p + 1, np - 1) * P + t;
+            // (addresses as wave-uniform panel base + lane index: the scalar unit does the 64-bit part)
+            const size_t o1 = (size_t)min(p + 1, np - 1) * P;
 #pragma unroll
             for (int c = 0; c < K1; c++) {
-                if (c > 0) n_thr[sb][c] = v.thr[(size_t)c * v.m_pad + j1];
-                n_invv[sb][c] = v.invv[(size_t)c * v.m_pad + j1];
-                n_sdz[sb][c] = v.sdz[(size_t)c * v.m_pad + j1];
+                const size_t oc = (size_t)c * v.m_pad + o1;
+                if (c > 0) n_thr[sb][c] = (v.thr + oc)[t];
+                n_invv[sb][c] = (v.invv + oc)[t];
+                n_sdz[sb][c] = (v.sdz + oc)[t];
             }
             if (p + 2 < np) {
-                if (t < nslot) hl_reg = pv.hotlist[(size_t)(p + 2) * nslot + t];
+                if (t < nslot) hl_reg = (pv.hotlist + (size_t)(p + 2) * nslot)[t];
                 if (t == 0) nh_reg = pv.nhot[p + 2];
             }
-            const int jq = min(p + Q, np - 1) * P + t;
-            rg_thr0[u] = v.thr[jq];
-            rg_gold[u] = v.g[jq];
-            rg_xx[u] = v.xpx[jq];
-            rg_slot[u] = pv.slot_of[jq];
-            rg_d[u] = ld_sc1(&v.dsum[jq]);
+            const size_t oq = (size_t)min(p + Q, np - 1) * P;
+            rg_thr0[u] = (v.thr + oq)[t];
+            rg_gold[u] = (v.g + oq)[t];
+            rg_xx[u] = (v.xpx + oq)[t];
+            rg_slot[u] = (pv.slot_of + oq)[t];
+            rg_d[u] = ld_sc1(v.dsum + oq + t);
 #pragma unroll
             for (int c = 0; c < K1; c++) {
                 if (c > 0) thr[c] = n_thr[sa][c];
