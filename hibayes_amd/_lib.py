@@ -55,6 +55,7 @@ class BayesArgs(C.Structure):
         ("interrupt", INTERRUPT_FN), ("interrupt_user", C.c_void_p),
         ("log", LOG_FN), ("log_user", C.c_void_p),
         ("ctx", C.c_void_p),
+        ("g_init", C.c_void_p),
     ]
 
 
@@ -127,6 +128,7 @@ SYMBOLS = [
     "hb_ctx_residual_shift", "hb_ctx_set_covariates", "hb_ctx_cov_dot", "hb_ctx_cov_axpy", "hb_ctx_set_levels",
     "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_sweep", "hb_ctx_get_counters", "hb_ctx_set_windows",
     "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec",
+    "hb_ctx_download_gram_band", "hb_ctx_get_pipeline", "hb_ctx_get_events",
     "hb_run_create", "hb_run_step", "hb_run_state", "hb_run_ctx", "hb_run_finish", "hb_run_destroy",
 ]
 
@@ -161,6 +163,9 @@ def lib():
     L.hb_ctx_marker_stats.argtypes = [vp, vp, vp, C.POINTER(dbl), C.POINTER(i32)]
     L.hb_ctx_build_gram.argtypes = [vp, C.POINTER(dbl)]
     L.hb_ctx_download_gram.argtypes = [vp, i32, vp]
+    L.hb_ctx_download_gram_band.argtypes = [vp, i32, i32, vp]
+    L.hb_ctx_get_pipeline.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.hb_ctx_get_events.argtypes = [vp, vp, vp, vp]
     L.hb_ctx_set_residual.argtypes = [vp, vp, vp]
     L.hb_ctx_get_residual.argtypes = [vp, vp, vp]
     L.hb_ctx_set_effects.argtypes = [vp, vp, vp, vp]

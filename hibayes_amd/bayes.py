@@ -28,32 +28,45 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
           thin=5, epsl_y_J=None, epsl_Gi=None, epsl_index=None, dfvr=None, s2vr=None, vg=None,
           dfvg=None, s2vg=None, ve=None, dfve=None, s2ve=None, windindx=None, outfreq=100, threads=0,
           verbose=True, *, seed=666666, device=0, panel=0, precise=False, store_alpha=True,
-          comm=None, m_global=None, m_offset=0, log=None, C=None):
+          comm=None, m_global=None, m_offset=0, log=None, C=None, g_init=None, ctx=None):
     """Individual-level Gibbs sampler on one MI355X (or one marker shard of it when `comm` is given).
 
     X is n x m: int8 (fast path, no double blow-up) or any integer-valued float array in the
     reference's layout. Returns a dict with the fields of the reference's Rcpp::List.
+    `ctx` (an engine.Context with genotypes already resident) replaces X: one upload serves several fits;
+    the context's own pipeline geometry, seed addressing (m_offset) and panel are then used as they are.
     """
     if C is not None and C_ is None:
         C_ = C
     L = lib()
     y = _f64(y).ravel()
     n = y.size
-    X = np.asarray(X)
-    if X.ndim != 2 or X.shape[0] != n:
-        raise HibayesError(1, "Number of individuals not equals.")
-    m = X.shape[1]
     a = BayesArgs()
     keep = []
+    if ctx is not None:
+        if X is not None:
+            raise HibayesError(1, "give X or ctx, not both")
+        if ctx.n != n:
+            raise HibayesError(1, "Number of individuals not equals.")
+        m = ctx.m
+        a.ctx = ctx.h
+    else:
+        X = np.asarray(X)
+        if X.ndim != 2 or X.shape[0] != n:
+            raise HibayesError(1, "Number of individuals not equals.")
+        m = X.shape[1]
     a.n, a.m = n, m
     a.y = y.ctypes.data
-    if X.dtype == np.int8:
+    if ctx is not None:
+        pass
+    elif X.dtype == np.int8:
         Xa = np.asfortranarray(X)
         a.X_i8, a.ld_i8 = Xa.ctypes.data, Xa.strides[1]
     else:
         Xa = np.asfortranarray(X, dtype=np.float64)
         a.X_f64, a.ld_f64 = Xa.ctypes.data, Xa.strides[1] // 8
-    keep.append(Xa)
+    if ctx is None:
+        keep.append(Xa)
     a.model = str(model).encode()
     Pi = _f64(Pi).ravel()
     a.Pi, a.n_pi = Pi.ctypes.data, Pi.size
@@ -110,6 +123,12 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
         keep.append(cb)
         if nw:
             nw = comm.max_int(nw)
+    if g_init is not None:
+        gi = _f64(g_init).ravel()
+        if gi.size != m:
+            raise HibayesError(1, "g_init must have one entry per marker")
+        a.g_init = gi.ctypes.data
+        keep.append(gi)
     if log is not None:
         logcb = _lib.LOG_FN(lambda line, _u: log(line.decode("utf-8", "replace")))
         a.log = logcb

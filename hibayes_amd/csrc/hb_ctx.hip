@@ -426,6 +426,40 @@ int hb_ctx_download_gram(hb_ctx *c, int32_t panel_index, int32_t *G)
     return HB_OK;
 }
 
+int hb_ctx_download_gram_band(hb_ctx *c, int32_t panel_index, int32_t l, int32_t *G)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_download_gram_band");
+    if (rc) return rc;
+    if (!c->gram_ready) return hb_fail(HB_ERR_INVALID, "hb_ctx_download_gram_band: call hb_ctx_build_gram first");
+    if (panel_index < 0 || panel_index >= c->npanels || l < 0 || l > c->L)
+        return hb_fail(HB_ERR_INVALID, "hb_ctx_download_gram_band: bad panel or band index");
+    HB_HIP(hipStreamSynchronize(c->stream));
+    HB_HIP(hipMemcpy(G, c->gram + ((size_t)panel_index * (c->L + 1) + l) * c->P * c->P, sizeof(int32_t) * c->P * c->P,
+                     hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
+int hb_ctx_get_pipeline(const hb_ctx *c, int32_t *pipeline, int32_t *lookahead, int32_t *dotgroup, int32_t *band)
+{
+    if (!c) return hb_fail(HB_ERR_INVALID, "hb_ctx_get_pipeline: null context");
+    if (pipeline) *pipeline = c->pipeline;
+    if (lookahead) *lookahead = c->Lv;
+    if (dotgroup) *dotgroup = c->D;
+    if (band) *band = c->L;
+    return HB_OK;
+}
+
+int hb_ctx_get_events(hb_ctx *c, int32_t *ev_count, int32_t *ev_idx, double *ev_delta)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_get_events");
+    if (rc) return rc;
+    HB_HIP(hipStreamSynchronize(c->stream));
+    if (ev_count) HB_HIP(hipMemcpy(ev_count, c->ev_count, sizeof(int32_t) * (size_t)c->npanels, hipMemcpyDeviceToHost));
+    if (ev_idx) HB_HIP(hipMemcpy(ev_idx, c->ev_idx, sizeof(int32_t) * (size_t)c->m_pad, hipMemcpyDeviceToHost));
+    if (ev_delta) HB_HIP(hipMemcpy(ev_delta, c->ev_delta, sizeof(double) * (size_t)c->m_pad, hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
 int hb_ctx_set_residual(hb_ctx *c, const double *yadj, const double *u)
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_set_residual");

@@ -60,7 +60,7 @@ struct hb_run {
     // ---- arguments (deep copies: the caller's arrays need not outlive hb_run_create) ----
     hb_bayes_args a{};
     std::string model;
-    std::vector<double> y, Cmat, Pi, fold_;
+    std::vector<double> y, Cmat, Pi, fold_, g_init;
     std::vector<uint32_t> wind;
     int n = 0, m = 0, model_index = 0, n_pi = 0, n_fold = 0, nc = 0, nr = 0, world = 1;
     bool fixpi = false, always_in = false;
@@ -252,6 +252,12 @@ int hb_run::setup(const hb_bayes_args *args)
             if (!(fold_[k] > fold_[k - 1]))
                 return hb_fail(HB_ERR_UNSUPPORTED, "BayesR on the GPU path needs 'fold' in strictly increasing order");
     if (a.windindx) wind.assign(a.windindx, a.windindx + m);
+    if (a.g_init) {
+        g_init.assign(a.g_init, a.g_init + m);
+        for (double v : g_init)
+            if (!std::isfinite(v)) return hb_fail(HB_ERR_INVALID, "hb_bayes_run: g_init must be finite");
+        a.g_init = nullptr; // consumed
+    }
 
     // =========================== device set-up ===========================
     int rc;
@@ -259,7 +265,7 @@ int hb_run::setup(const hb_bayes_args *args)
         c = a.ctx;
         own_ctx = false;
         c->seed = a.seed;
-        c->m_offset = world > 1 ? a.m_offset : 0;
+        if (world > 1) c->m_offset = a.m_offset; // (a single-process run keeps the context's own marker addressing)
         c->precise = a.precise;
         c->graph_model = -1;
     } else {
@@ -300,7 +306,8 @@ int hb_run::setup(const hb_bayes_args *args)
     }
 
     // ---- marker statistics, :310-317 ----
-    rc = hb_ctx_marker_stats(c, nullptr, nullptr, &sumvx, &nvar0);
+    std::vector<double> vx_host(g_init.empty() ? 0 : m);
+    rc = hb_ctx_marker_stats(c, nullptr, g_init.empty() ? nullptr : vx_host.data(), &sumvx, &nvar0);
     if (rc) return rc;
     {
         double sv[2] = {sumvx, (double)nvar0};
@@ -385,6 +392,19 @@ int hb_run::setup(const hb_bayes_args *args)
     {
         std::vector<double> yadj(n), zero(n, 0.0);
         for (int i = 0; i < n; i++) yadj[i] = y[i] - mu;
+        if (!g_init.empty()) {
+            // warm start: monomorphic markers are never visited by the sweep (:589), so they start (and stay) at zero
+            std::vector<uint8_t> trk(m, 0);
+            for (int i = 0; i < m; i++) {
+                if (vx_host[i] == 0.0) g_init[i] = 0.0;
+                trk[i] = g_init[i] != 0.0;
+            }
+            rc = hb_ctx_set_effects(c, g_init.data(), trk.data(), nullptr);
+            if (rc) return rc;
+            rc = hb_ctx_matvec(c, g_init.data(), zero.data()); // u = X g
+            if (rc) return rc;
+            for (int i = 0; i < n; i++) yadj[i] -= zero[i];
+        }
         rc = hb_ctx_set_residual(c, yadj.data(), zero.data());
         if (rc) return rc;
     }

@@ -88,6 +88,27 @@ class Context:
         check(self.L.hb_ctx_download_gram(self.h, p, G.ctypes.data))
         return G
 
+    def gram_band(self, p, l):
+        P = self.panel
+        G = np.zeros((P, P), dtype=np.int32)
+        check(self.L.hb_ctx_download_gram_band(self.h, p, l, G.ctypes.data))
+        return G
+
+    def pipeline(self):
+        v = [C.c_int32() for _ in range(4)]
+        check(self.L.hb_ctx_get_pipeline(self.h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)   # (pipeline, lookahead groups, panels per mat-vec, band blocks)
+
+    def events(self):
+        """Move lists of the last sweep as [(panel-local marker indices, deltas)] per panel."""
+        P = self.panel
+        npan = (self.m + P - 1) // P
+        cnt = np.zeros(npan, dtype=np.int32)
+        idx = np.zeros(npan * P, dtype=np.int32)
+        dl = np.zeros(npan * P)
+        check(self.L.hb_ctx_get_events(self.h, cnt.ctypes.data, idx.ctypes.data, dl.ctypes.data))
+        return cnt, [(idx[p * P:p * P + cnt[p]].copy(), dl[p * P:p * P + cnt[p]].copy()) for p in range(npan)]
+
     # ---- state ----
     def set_residual(self, yadj=None, u=None):
         a = None if yadj is None else np.ascontiguousarray(yadj, dtype=np.float64)

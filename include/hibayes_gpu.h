@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 1
+#define HB_ABI_VERSION 2
 #define HB_MAX_FOLD 8
 
 typedef enum {
@@ -123,6 +123,9 @@ typedef struct hb_bayes_args {
     /* optional pre-loaded context: genotypes already resident on the device (then X_f64 and X_i8
      * must be NULL and n, m must match). Lets one upload serve several model fits.            */
     hb_ctx *ctx;
+    /* warm start (no reference counterpart; ABI 2): m effects the chain starts from instead of g = 0
+     * (src/Bayes.cpp:297). yadj = y - mu - X g_init, u = X g_init; classes restart as (g != 0). */
+    const double *g_init;
 } hb_bayes_args;
 
 /* number of doubles exchanged per sweep for n individuals */
@@ -235,6 +238,14 @@ int hb_ctx_set_pipeline(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t 
 int hb_ctx_build_gram(hb_ctx *c, double *seconds);
 /* rows x cols window of panel p's Gram (row-major int32, P x P) for exactness tests */
 int hb_ctx_download_gram(hb_ctx *c, int32_t panel_index, int32_t *G);
+/* band block l of panel p (row-major int32, P x P): G[k][t] = x_{(p-l)P+k} . x_{pP+t}, l = 0..band; the look-ahead
+ * pipeline folds the moves of panel p-l into panel p's right-hand sides with it */
+int hb_ctx_download_gram_band(hb_ctx *c, int32_t panel_index, int32_t l, int32_t *G);
+/* current geometry: pipeline flag, look-ahead groups, panels per mat-vec launch, band width (blocks l = 1..band) */
+int hb_ctx_get_pipeline(const hb_ctx *c, int32_t *pipeline, int32_t *lookahead, int32_t *dotgroup, int32_t *band);
+/* move lists of the last sweep: ev_count[npanels]; ev_idx / ev_delta are [npanels][P] with ev_count[p] valid entries
+ * (marker index inside the panel, change of its effect), in the order the chain applied them */
+int hb_ctx_get_events(hb_ctx *c, int32_t *ev_count, int32_t *ev_idx, double *ev_delta);
 
 /* residual yadj and u = Xg (n each) */
 int hb_ctx_set_residual(hb_ctx *c, const double *yadj, const double *u);

@@ -383,6 +383,15 @@ int hbo_bayes(const hbo_args *a, hbo_out *o)
     for (int i = 0; i < n; i++) yadj[i] = y[i] - mu;
     double *one = (double *)malloc(sizeof(double) * n);
     for (int i = 0; i < n; i++) one[i] = 1.0;
+    if (a->g_init) { /* warm start: g = g_init, u = X g, yadj = y - mu - X g */
+        for (int i = 0; i < m; i++) {
+            if (!vx[i] || a->g_init[i] == 0.0) continue;
+            g[i] = a->g_init[i];
+            if (snptracker) snptracker[i] = 1;
+            col_axpy(&X, i, g[i], u);
+        }
+        for (int i = 0; i < n; i++) yadj[i] -= u[i];
+    }
     double *r_RHS = n_levels ? (double *)malloc(sizeof(double) * n_levels) : NULL;
     double *estR_new = n_levels ? (double *)malloc(sizeof(double) * n_levels) : NULL;
 

@@ -8,16 +8,22 @@
  * library, and only as the checker / the reported CPU baseline.  The shipped product
  * (hibayes_amd/, libhibayes_gpu.so) never links, imports or calls it.
  *
- * PARITY PIN STATUS.  The reference has no test-suite and R/Rcpp/Armadillo are not
- * installed, so src/Bayes.cpp cannot be built here (it includes RcppArmadillo.h, R.h,
- * Rmath.h and links BLAS ddot_/daxpy_ — none present).  What pins this
- * restatement: (1) the .bed decode against the genotype corner printed at reference
- * README.md:81-86; (2) the derived initial-state facts for inst/extdata/demo.*
- * (n=300, var(y), sumvx, nvar0, xpx[0:5], varg, s2varg_, vare_, lambda2) recorded in
- * SURVEY.md §4 from the formulas at src/Bayes.cpp:310-363; (3) R's published outputs for
- * set.seed()/runif()/rnorm() and the Random123 Philox vectors for the RNG layer; (4) the
- * README.md:159-167 posterior band as a soft sanity check.  Chain-level output of real
- * hibayes is NOT available => the sampler itself is "parity unpinned" at bit level.
+ * PARITY PIN STATUS: PINNED against a real hibayes run.  The reference has no test-suite and R/Rcpp/Armadillo
+ * are not installed, so src/Bayes.cpp cannot be built here (it includes RcppArmadillo.h, R.h, Rmath.h and links
+ * BLAS ddot_/daxpy_ — none present), but the reference's README.md:130-172 prints summary() of
+ * ibrm(T1 ~ season + bwt + (1|loc) + (1|dam), BayesCpi, Pi = c(0.98, 0.02), 20000/16000/5, seed = 666666) on
+ * inst/extdata/demo.*.  This restatement, drawing from R's stream (set.seed() Mersenne-Twister, inversion
+ * normals, Ahrens-Dieter rgamma/exp_rand: hbo_rng.c), reproduces EVERY printed digit of that summary after
+ * 20 000 iterations — Vg 52.10097 (SD 13.084), h2 0.35748, pi 0.92683, Ve 30.77, Vr 8.10 / 54.29, the four
+ * fixed effects and their SDs, the intercept, the residual and marker-effect quantiles
+ * (tests/test_oracle_sampler.py::test_oracle_reproduces_the_fit_printed_in_the_reference_readme).  A chain of
+ * 20 000 x ~1 400 sequential draws only does that if every draw is consumed in the reference's order and every
+ * conditional is restated exactly.  That run exercises BayesCpi, the intercept / covariate / random-effect
+ * blocks, the variance and pi draws and the posterior assembly; the other five sweeps (RR, A, B, L, R) share
+ * the scalar samplers and loop skeleton it pins and are restated line by line from src/Bayes.cpp:587-815.
+ * Further pins: the .bed decode against README.md:81-86; the initial-state facts derived from
+ * src/Bayes.cpp:310-363; R's published set.seed()/runif()/rnorm()/rexp() outputs and the
+ * Random123 Philox vectors for the RNG layer.
  */
 #ifndef HB_ORACLE_H
 #define HB_ORACLE_H
@@ -61,6 +67,9 @@ typedef struct {
     double *trace_rhs;
     int32_t *trace_cls;
     double *trace_g;
+    /* warm start (mirrors hb_bayes_args.g_init of the GPU library; not in the reference): m effects the chain
+     * starts from; entries of monomorphic markers are taken as 0 */
+    const double *g_init;
 } hbo_args;
 
 typedef struct {

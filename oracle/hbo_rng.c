@@ -199,12 +199,133 @@ double hbo_norm(hbo_stream_t *s)
     return hbo_philox_normal(s->seed, s->sub, s->blk++);
 }
 
-/* Marsaglia & Tsang (2000), "A simple method for generating gamma variables".
- * Stands in for R::rgamma at reference src/stats.cpp:13-15 (see header). One attempt
- * consumes one normal then one uniform; shape < 1 uses the boost g(a+1) * U^(1/a) with
- * the extra uniform drawn after the accepted attempt. */
+/* ------------------------------------------------------------------------------------
+ * R's exp_rand() and rgamma().  Third-party algorithms (R is not under /root/reference; DESCRIPTION:35 pins
+ * "R (>= 3.3.0)"; the files below have not changed their arithmetic since R 2.x):
+ *   R src/nmath/sexp.c    Ahrens & Dieter (1972), "Computer methods for sampling from the exponential and
+ *                         normal distributions", CACM 15: algorithm SA, q[k] = sum_{i<=k} ln(2)^i / i!
+ *   R src/nmath/rgamma.c  a >= 1: Ahrens & Dieter (1982), "Generating gamma variates by a modified rejection
+ *                         technique", CACM 25: algorithm GD (with R's expm1 in step 11);
+ *                         a <  1: Ahrens & Dieter (1974), "Computer methods for sampling from gamma, beta, Poisson
+ *                         and binomial distributions", Computing 12: algorithm GS.
+ * Call sites in the reference: R::rgamma at src/stats.cpp:13-15 (gamma_sample), R::rchisq at :22-24
+ * (= rgamma(df/2, 2.0), R src/nmath/rchisq.c).  Draw order matters for stream parity: GD consumes
+ * norm_rand, [unif_rand, [exp_rand, unif_rand]*]; GS consumes [unif_rand, exp_rand]*.
+ * Pinned by: set.seed(1); rexp(3) = 0.7551818 1.1816428 0.1457067 (R documentation) for exp_rand, the
+ * immediate-acceptance identity rgamma = (sqrt(a - 1/2) + norm_rand/2)^2 on a seed whose first normal is
+ * positive, and Kolmogorov-Smirnov tests against scipy's gamma CDF (tests/test_oracle_rng.py).
+ * ------------------------------------------------------------------------------------ */
+double hbo_mt_exp_rand(hbo_mt_t *s)
+{
+    static const double q[] = {0.6931471805599453, 0.9333736875190459, 0.9888777961838675, 0.9984589039328340,
+                               0.9998292811061389, 0.9999833164100727, 0.9999985691438767, 0.9999998906925558,
+                               0.9999999924734159, 0.9999999995283275, 0.9999999999728814, 0.9999999999985598,
+                               0.9999999999999289, 0.9999999999999968, 0.9999999999999999, 1.0000000000000000};
+    double a = 0.0;
+    double u = hbo_mt_unif_rand(s);
+    while (u <= 0.0 || u >= 1.0) u = hbo_mt_unif_rand(s);
+    for (;;) {
+        u += u;
+        if (u > 1.0) break;
+        a += q[0];
+    }
+    u -= 1.0;
+    if (u <= q[0]) return a + u;
+    int i = 0;
+    double ustar = hbo_mt_unif_rand(s), umin = ustar;
+    do {
+        ustar = hbo_mt_unif_rand(s);
+        if (umin > ustar) umin = ustar;
+        i++;
+    } while (u > q[i]);
+    return a + umin * q[0];
+}
+
+double hbo_mt_rgamma(hbo_mt_t *st, double a, double scale)
+{
+    const double sqrt32 = 5.656854, exp_m1 = 0.36787944117144233;
+    const double q1 = 0.04166669, q2 = 0.02083148, q3 = 0.00801191, q4 = 0.00144121, q5 = -7.388e-5,
+                 q6 = 2.4511e-4, q7 = 2.424e-4;
+    const double a1 = 0.3333333, a2 = -0.250003, a3 = 0.2000062, a4 = -0.1662921, a5 = 0.1423657,
+                 a6 = -0.1367177, a7 = 0.1233795;
+    double e, p, q, r, t, u, v, w, x, ret_val;
+    if (!(a > 0.0) || !(scale > 0.0)) return (a == 0.0 || scale == 0.0) ? 0.0 : NAN;
+    if (a < 1.0) { /* GS */
+        e = 1.0 + exp_m1 * a;
+        for (;;) {
+            p = e * hbo_mt_unif_rand(st);
+            if (p >= 1.0) {
+                x = -log((e - p) / a);
+                if (hbo_mt_exp_rand(st) >= (1.0 - a) * log(x)) break;
+            } else {
+                x = exp(log(p) / a);
+                if (hbo_mt_exp_rand(st) >= x) break;
+            }
+        }
+        return scale * x;
+    }
+    /* GD. (R caches s2, s, d, q0, b, si, c between calls with the same a; recomputing gives the same numbers.) */
+    const double s2 = a - 0.5, s = sqrt(s2), d = sqrt32 - s * 12.0;
+    t = hbo_mt_norm_rand(st);               /* step 2: immediate acceptance */
+    x = s + 0.5 * t;
+    ret_val = x * x;
+    if (t >= 0.0) return scale * ret_val;
+    u = hbo_mt_unif_rand(st);               /* step 3: squeeze acceptance */
+    if (d * u <= t * t * t) return scale * ret_val;
+    r = 1.0 / a;                            /* step 4 */
+    const double q0 = ((((((q7 * r + q6) * r + q5) * r + q4) * r + q3) * r + q2) * r + q1) * r;
+    double b, si, c;
+    if (a <= 3.686) {
+        b = 0.463 + s + 0.178 * s2;
+        si = 1.235;
+        c = 0.195 / s - 0.079 + 0.16 * s;
+    } else if (a <= 13.022) {
+        b = 1.654 + 0.0076 * s2;
+        si = 1.68 / s + 0.275;
+        c = 0.062 / s + 0.024;
+    } else {
+        b = 1.77;
+        si = 0.75;
+        c = 0.1515 / s;
+    }
+    if (x > 0.0) {                          /* steps 5-7: quotient acceptance */
+        v = t / (s + s);
+        if (fabs(v) <= 0.25)
+            q = q0 + 0.5 * t * t * ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v + a1) * v;
+        else
+            q = q0 - s * t + 0.25 * t * t + (s2 + s2) * log(1.0 + v);
+        if (log(1.0 - u) <= q) return scale * ret_val;
+    }
+    for (;;) {                              /* steps 8-11: double-exponential hat */
+        e = hbo_mt_exp_rand(st);
+        u = hbo_mt_unif_rand(st);
+        u = u + u - 1.0;
+        t = (u < 0.0) ? b - si * e : b + si * e;
+        if (t >= -0.71874483771719) {
+            v = t / (s + s);
+            if (fabs(v) <= 0.25)
+                q = q0 + 0.5 * t * t * ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v + a1) * v;
+            else
+                q = q0 - s * t + 0.25 * t * t + (s2 + s2) * log(1.0 + v);
+            if (q > 0.0) {
+                w = expm1(q);
+                if (c * fabs(u) <= w * exp(e - 0.5 * t * t)) break;
+            }
+        }
+    }
+    x = s + 0.5 * t;
+    return scale * x * x;
+}
+
+/* Gamma deviates of the unified stream.
+ * R kind:      R's own rgamma (above) on the Mersenne-Twister stream — what R::rgamma at reference
+ *              src/stats.cpp:13-15 consumes, draw for draw.
+ * Philox kind: Marsaglia & Tsang (2000), "A simple method for generating gamma variables" — the contract shared with
+ *              the device path (hb_rng.hpp): one attempt consumes one normal then one uniform; shape < 1 uses the
+ *              boost g(a+1) * U^(1/a) with the extra uniform drawn after the accepted attempt. */
 double hbo_gamma(hbo_stream_t *s, double shape, double scale)
 {
+    if (s->kind == HBO_RNG_R) return hbo_mt_rgamma(&s->mt, shape, scale);
     double a = shape < 1.0 ? shape + 1.0 : shape;
     double d = a - 1.0 / 3.0;
     double c = 1.0 / sqrt(9.0 * d);

@@ -17,9 +17,10 @@
  *                 u = unif_rand(); u = (int)(2^27 u) + unif_rand(); qnorm5(u / 2^27)),
  *                 with qnorm5 = Wichura's AS241 PPND16.  Pinned by the published R outputs
  *                 set.seed(1); runif(3) and set.seed(123); rnorm(5) (tests/test_oracle_rng.py).
- *                 R::rgamma (Ahrens-Dieter GD/GS) is NOT restated: gamma deviates use
- *                 Marsaglia-Tsang (2000) on top of the same uniform/normal stream, so the
- *                 distribution is identical but the stream is not R's bit for bit.
+ *                 Gamma deviates are R's own rgamma (Ahrens-Dieter GD for a >= 1, GS for a < 1, with
+ *                 R's exp_rand, R src/nmath/{rgamma,sexp,rchisq}.c), so this mode consumes the stream
+ *                 exactly as R::rgamma / R::rchisq at reference src/stats.cpp:13-24 do; pinned by
+ *                 set.seed(1); rexp(3) and distribution tests.
  *
  *  HBO_RNG_PHILOX counter-based Philox4x32-10 (Salmon et al., SC'11), the generator the
  *                 device path uses through rocRAND (rocrand_philox4x32_10.h: key = seed,
@@ -63,6 +64,8 @@ void   hbo_mt_set_seed(hbo_mt_t *s, uint32_t seed);   /* == R's set.seed(seed), 
 double hbo_mt_unif_rand(hbo_mt_t *s);                  /* == R's unif_rand()                   */
 double hbo_mt_norm_rand(hbo_mt_t *s);                  /* == R's norm_rand(), INVERSION        */
 double hbo_qnorm(double p);                            /* Wichura AS241 PPND16                 */
+double hbo_mt_exp_rand(hbo_mt_t *s);                   /* == R's exp_rand()  (sexp.c)          */
+double hbo_mt_rgamma(hbo_mt_t *s, double a, double scale); /* == R's rgamma() (Ahrens-Dieter)  */
 
 /* ---- Philox4x32-10 ---- */
 void   hbo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
@@ -84,7 +87,7 @@ void   hbo_stream_init_r(hbo_stream_t *s, uint32_t seed);
 void   hbo_stream_init_philox(hbo_stream_t *s, uint64_t seed, uint64_t sub, uint64_t blk0);
 double hbo_unif(hbo_stream_t *s);
 double hbo_norm(hbo_stream_t *s);
-double hbo_gamma(hbo_stream_t *s, double shape, double scale);  /* Marsaglia-Tsang */
+double hbo_gamma(hbo_stream_t *s, double shape, double scale);  /* R kind: R's rgamma; Philox kind: Marsaglia-Tsang */
 double hbo_chisq(hbo_stream_t *s, double df);                    /* gamma(df/2, 2)  */
 double hbo_invgauss(hbo_stream_t *s, double mu, double lambda);  /* stats.cpp:55-67 */
 

@@ -33,6 +33,7 @@ class _Args(C.Structure):
         ("rng_kind", C.c_int32), ("seed", C.c_uint64), ("marker_offset", C.c_int64),
         ("trace_iter", C.c_int32),
         ("trace_rhs", C.c_void_p), ("trace_cls", C.c_void_p), ("trace_g", C.c_void_p),
+        ("g_init", C.c_void_p),
     ]
 
 
@@ -80,6 +81,10 @@ def lib():
         L.hbo_mt_unif_rand.restype = C.c_double
         L.hbo_mt_norm_rand.argtypes = [C.c_void_p]
         L.hbo_mt_norm_rand.restype = C.c_double
+        L.hbo_mt_exp_rand.argtypes = [C.c_void_p]
+        L.hbo_mt_exp_rand.restype = C.c_double
+        L.hbo_mt_rgamma.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.hbo_mt_rgamma.restype = C.c_double
         L.hbo_qnorm.argtypes = [C.c_double]
         L.hbo_qnorm.restype = C.c_double
         L.hbo_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -114,6 +119,12 @@ class MT:
 
     def norm(self):
         return lib().hbo_mt_norm_rand(self._buf)
+
+    def exp(self):
+        return lib().hbo_mt_exp_rand(self._buf)
+
+    def gamma(self, shape, scale=1.0):
+        return lib().hbo_mt_rgamma(self._buf, shape, scale)
 
 
 class Stream:
@@ -172,7 +183,7 @@ def _nan(v):
 def bayes(y, X, model, Pi, fold=None, Cmat=None, R=None, niter=50000, nburn=20000, thin=5,
           dfvr=None, s2vr=None, vg=None, dfvg=None, s2vg=None, ve=None, dfve=None, s2ve=None,
           windindx=None, threads=1, rng=RNG_PHILOX, seed=666666, marker_offset=0,
-          store_alpha=False, trace_iter=None):
+          store_alpha=False, trace_iter=None, g_init=None):
     """Mirror of reference Bayes() (src/Bayes.cpp:60-88). X: n x m, float64 or int8."""
     L = lib()
     y = np.ascontiguousarray(y, dtype=np.float64)
@@ -223,6 +234,11 @@ def bayes(y, X, model, Pi, fold=None, Cmat=None, R=None, niter=50000, nburn=2000
         nw = int(w.max())
         keep.append(w)
     a.threads = threads
+    if g_init is not None:
+        gi = np.ascontiguousarray(g_init, dtype=np.float64)
+        assert gi.size == m
+        a.g_init = gi.ctypes.data
+        keep.append(gi)
     a.rng_kind, a.seed, a.marker_offset = rng, seed, marker_offset
     nrec = max((niter - nburn) // thin, 0)
     o = _Out()

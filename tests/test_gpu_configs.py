@@ -1,0 +1,185 @@
+"""BASELINE.json's configs at (or at the per-GPU shard shape of) their stated sizes, on one MI355X.
+
+config 2  BayesCpi n=10k  m=100k            : the whole sampler, pipeline vs serial kernels + invariants
+config 3  n=50k m=500k (BayesCpi and BayesR): pipeline (default geometry) vs serial kernels, precise 1 and 0,
+          and draw-for-draw against the LIVE oracle run on the same 25 GB of genotypes (2 sweeps from cold)
+config 4  BayesCpi n=50k  m=2M / 8 GPUs     : one shard (m=250k, global marker offset) pipeline vs serial + invariants
+config 5  BayesB   n=200k m=1M / 8 GPUs     : one shard (m=125k) draw-for-draw against the live oracle
+Sizes the oracle cannot finish in seconds are covered by the size-independent properties of the sweep:
+yadj + u conserved, u = X g, class counts, monomorphic markers untouched. Reference: src/Bayes.cpp:586-823."""
+import os
+
+import numpy as np
+import pytest
+
+import hibayes_amd as H
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def host_free_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def synth_y(c, n, m, seed, m_offset=0, m_global=None):
+    """y = X beta + e, h2 = 0.5, 0.1 % causal (SURVEY.md §8 d) from the device-resident genotypes."""
+    rng = np.random.default_rng(seed)
+    nc = max(1, m // 1000)
+    beta = np.zeros(m)
+    beta[rng.choice(m, nc, replace=False)] = rng.normal(0, 1, nc)
+    xb = np.zeros(n)
+    H._lib.check(c.L.hb_ctx_matvec(c.h, beta.ctypes.data, xb.ctypes.data))
+    xb -= xb.mean()
+    xb *= np.sqrt(0.5 / xb.var())
+    return xb + rng.normal(0, np.sqrt(0.5), n)
+
+
+def invariants(c, y, r):
+    """What must hold after any number of sweeps, whatever moved."""
+    n, m = c.n, c.m
+    ra, u = c.get_residual()
+    g, trk, _ = c.get_effects()
+    xpx, vx, sumvx, nvar0 = c.marker_stats()
+    xg = np.zeros(n)
+    H._lib.check(c.L.hb_ctx_matvec(c.h, g.ctypes.data, xg.ctypes.data))
+    np.testing.assert_allclose(u, xg, rtol=0, atol=1e-8 * max(1.0, np.abs(xg).max()))        # u = X g
+    mu_last = r["MCMCsamples"]["mu"][0, -1]
+    np.testing.assert_allclose(ra + u, y - mu_last, rtol=0, atol=1e-8 * np.abs(y).max())     # yadj = y - mu - X g
+    assert not g[vx == 0].any() and not trk[vx == 0].any()
+    assert np.array_equal(trk != 0, g != 0)
+    np.testing.assert_allclose(u, r["g"], rtol=0, atol=0)                                     # results["g"] = final u (:1023)
+
+
+def run_both_geometries(c, y, model, Pi, fold, geo, niter, precise, nburn=0, thin=1, seed=31337):
+    out = []
+    for g in (geo, (0, 0, 1)):
+        c.set_pipeline(*g)
+        assert c.pipeline()[:3] == g
+        r = H.Bayes(y, None, model, Pi, fold=fold, niter=niter, nburn=nburn, thin=thin, seed=seed, verbose=False,
+                    precise=precise, ctx=c, store_alpha=(c.m <= 300000))
+        out.append(r)
+        if g == geo:
+            invariants(c, y, r)
+    return out
+
+
+def same_chain(a, b, tol, what):
+    np.testing.assert_allclose(a["alpha"], b["alpha"], rtol=tol, atol=1e-13, err_msg=what)
+    assert np.array_equal(a["pip"], b["pip"]), what
+    for k in ("Vg", "Ve", "h2", "mu"):
+        assert a[k] == pytest.approx(b[k], rel=tol), (what, k)
+    np.testing.assert_allclose(a["pi"], b["pi"], rtol=tol, atol=1e-14)
+    np.testing.assert_allclose(a["e"], b["e"], rtol=0, atol=1e-7)
+
+
+def test_config2_bayescpi_n10k_m100k_pipeline_vs_serial():
+    n, m = 10000, 100000
+    with H.Context(n, m, seed=2) as c:
+        c.generate(20240901, mono_every=1000)
+        y = synth_y(c, n, m, 11)
+        a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 6), niter=50, precise=True, nburn=10, thin=2)
+        same_chain(a, b, 1e-9, "config 2: pipeline (1,2,6) vs serial kernels")
+        assert a["timing"]["mean_events"] > 100
+
+
+def test_config4_shard_shape_bayescpi_n50k_m250k_pipeline_vs_serial():
+    # rank 3 of 8 of config 4: global markers [750000, 1000000) of m_global = 2M (RNG addressed by global index)
+    n, m = 50000, 250000
+    with H.Context(n, m, seed=4, m_offset=750000) as c:
+        c.generate(20240901, mono_every=1000)
+        y = synth_y(c, n, m, 13)
+        a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 6), niter=6, precise=True)
+        same_chain(a, b, 1e-9, "config 4 shard: pipeline vs serial")
+
+
+def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2):
+    need = n * m / 1e9 + 8
+    if host_free_gb() < need:
+        pytest.skip("host has %.0f GB available, the live oracle needs %.0f GB for the int8 genotypes" % (host_free_gb(), need))
+    kw = dict(fold=fold, niter=niter, nburn=0, thin=1, seed=20240901)
+    with H.Context(n, m, seed=20240901, m_offset=m_offset, precise=True) as c:
+        c.generate(20240901, mono_every=1000)
+        y = synth_y(c, n, m, 17)
+        c.set_pipeline(*geo)
+        r = H.Bayes(y, None, model, Pi, verbose=False, precise=True, ctx=c, store_alpha=False, **kw)
+        invariants(c, y, r)
+        g_gpu, trk, _ = c.get_effects()
+        X = c.download()
+    ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, marker_offset=m_offset, **kw)
+    g_ref = ref["s_alpha"][:, -1]
+    assert np.array_equal(g_gpu != 0, g_ref != 0), "%d of %d inclusion decisions differ" % (((g_gpu != 0) != (g_ref != 0)).sum(), m)
+    np.testing.assert_allclose(g_gpu, g_ref, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(r["alpha"], ref["alpha"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"], r["mu"]], [ref["Vg"], ref["Ve"], ref["h2"], ref["mu"]], rtol=1e-8)
+    np.testing.assert_allclose(r["pi"], ref["pi"], rtol=1e-8)
+    np.testing.assert_allclose(r["g"], ref["g"], rtol=1e-7, atol=1e-8)
+    assert (g_ref != 0).sum() > 0
+
+
+def test_config3_bayescpi_n50k_m500k_draw_for_draw_against_live_oracle():
+    _full_size_vs_oracle(50000, 500000, "BayesCpi", [0.95, 0.05], None, (1, 2, 6), 0)
+
+
+def test_config5_shard_shape_bayesb_n200k_m125k_draw_for_draw_against_live_oracle():
+    # rank 5 of 8 of config 5 (BayesB, n = 200k, m_global = 1M)
+    _full_size_vs_oracle(200000, 125000, "BayesB", [0.95, 0.05], None, (1, 2, 6), 625000)
+
+
+@pytest.mark.parametrize("model,Pi,fold,geo", [("BayesCpi", [0.95, 0.05], None, (1, 2, 6)),
+                                                ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1))])
+def test_config3_pipeline_vs_serial_kernels_precise_and_fast(model, Pi, fold, geo):
+    """n=50k, m=500k, 3 sweeps from cold. fp64 mat-vec: the pipeline and the serial per-panel kernels must give the same
+    chain (identical decisions and move lists; effects and residual to 1e-9 — the two differ only in the order the band
+    corrections are added to a right-hand side). fp32 mat-vec image (precise=0): decisions may flip where q sits within
+    ~1e-6 of its threshold; the flip rate is measured and bounded."""
+    n, m = 50000, 500000
+    res = {}
+    for precise in (True, False):
+        with H.Context(n, m, seed=99, precise=precise) as c:
+            c.generate(20240901, mono_every=1000)
+            if precise:
+                y = synth_y(c, n, m, 19)
+            xpx, vx, sumvx, nvar0 = c.marker_stats()
+            vare, varg = 0.5, 0.5 / (0.05 * sumvx)
+            logpi = np.log(Pi)
+            fo = fold if fold is not None else [0, 0]
+            for g in (geo, (0, 0, 1)):
+                c.set_pipeline(*g)
+                c.set_effects(np.zeros(m), np.zeros(m, dtype=np.uint8))
+                c.set_residual(y - y.mean(), np.zeros(n))
+                evs = []
+                for it in range(3):
+                    s = c.sweep(model, it, vare, varg, logpi=logpi, fold=fo)
+                    assert s["class_count"].sum() == m - nvar0
+                    cnt, lists = c.events()
+                    evs.append((cnt, np.concatenate([l[0] for l in lists]), np.concatenate([l[1] for l in lists])))
+                gg, trk, _ = c.get_effects()
+                r, u = c.get_residual()
+                res[(precise, g == geo)] = (gg, trk, r, u, evs)
+    # fp64: pipeline == serial
+    (g1, t1, r1, u1, e1), (g0, t0, r0, u0, e0) = res[(True, True)], res[(True, False)]
+    assert np.array_equal(t1, t0)
+    for (c1, i1, d1), (c0, i0, d0) in zip(e1, e0):
+        assert np.array_equal(c1, c0) and np.array_equal(i1, i0)           # same markers moved, in the same order
+        np.testing.assert_allclose(d1, d0, rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(r1, r0, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(u1, u0, rtol=0, atol=1e-10)
+    # fp32 image: pipeline vs serial, and fast vs precise
+    (f1, ft1, fr1, fu1, _), (f0, ft0, _, _, _) = res[(False, True)], res[(False, False)]
+    decisions = 3.0 * (m - nvar0)
+    flips_geo = int((ft1 != ft0).sum())
+    flips_prec = int((ft1 != t1).sum())
+    print("%s n=50k m=500k: class differences after 3 sweeps — fp32 pipeline vs fp32 serial %d, fp32 vs fp64 %d (of %.0f decisions); "
+          "max |g32 - g64| = %.3g" % (model, flips_geo, flips_prec, decisions, np.abs(f1 - g1).max()))
+    assert flips_geo <= 1e-4 * decisions and flips_prec <= 1e-4 * decisions
+    same = ft1 == t1
+    np.testing.assert_allclose(f1[same], g1[same], rtol=0, atol=2e-3 * max(1e-12, np.abs(g1).max()))
+    np.testing.assert_allclose(fr1 + fu1, y - y.mean(), rtol=0, atol=1e-9)  # the f64 master residual stays exact in both modes

@@ -1,0 +1,123 @@
+"""Parity where the bench runs: the DEFAULT pipeline geometries at pipeline depth.
+
+The round-1 goldens (m <= 1000) give at most two mat-vec groups, so the fused update row, the residual version
+ping-pong, the wrap of the LDS correction ring and the band blocks l >= 2 never ran under an oracle comparison.
+Here: >= 11 mat-vec groups at D = 6 (64 panels of 512, and 64 panels of 64), draw-for-draw against the live oracle
+under the same Philox counters, from a cold start and from a dense installed state; every band Gram block against
+int64 numpy; pipeline vs serial kernels at the BASELINE size. Reference loop: src/Bayes.cpp:627-717, :743-815."""
+import numpy as np
+import pytest
+
+import hibayes_amd as H
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def geno(rng, n, m):
+    p = rng.uniform(0.05, 0.5, m)
+    X = np.empty((n, m), dtype=np.int8, order="F")
+    for j0 in range(0, m, 4096):
+        pj = p[j0:j0 + 4096]
+        X[:, j0:j0 + 4096] = (rng.random((n, pj.size)) < pj).astype(np.int8) + (rng.random((n, pj.size)) < pj).astype(np.int8)
+    X[:, 7::997] = 1                      # monomorphic markers: skipped by the sweep (src/Bayes.cpp:589)
+    return X
+
+
+def pheno(rng, X, ncausal=40):
+    n, m = X.shape
+    idx = rng.choice(m, ncausal, replace=False)
+    xb = X[:, idx].astype(np.float64) @ rng.normal(0, 1, ncausal)
+    xb *= np.sqrt(0.5 / xb.var())
+    return xb + rng.normal(0, np.sqrt(0.5), n)
+
+
+CASES = [  # model, Pi, fold, expected default geometry (pipeline, look-ahead groups, panels per mat-vec)
+    ("BayesCpi", [0.95, 0.05], None, (1, 2, 6)),
+    ("BayesB", [0.8, 0.2], None, (1, 2, 6)),
+    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1)),
+    ("BayesRR", [0.95, 0.05], None, (1, 1, 1)),
+]
+
+
+@pytest.fixture(scope="module")
+def big():
+    rng = np.random.default_rng(20250929)
+    n, m = 2048, 32768
+    X = geno(rng, n, m)
+    return {"X": X, "y": pheno(rng, X), "rng_state": rng.bit_generator.state}
+
+
+def _compare(r, ref, tol=1e-9):
+    a, b = r["MCMCsamples"]["alpha"], ref["s_alpha"]
+    assert np.array_equal(a != 0, b != 0), "inclusion pattern differs in %d entries" % int(((a != 0) != (b != 0)).sum())
+    np.testing.assert_allclose(a, b, rtol=tol, atol=1e-13)
+    np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"], r["mu"]], [ref["Vg"], ref["Ve"], ref["h2"], ref["mu"]], rtol=tol)
+    np.testing.assert_allclose(r["pi"], ref["pi"], rtol=tol, atol=1e-14)
+    np.testing.assert_allclose(r["pip"], ref["pip"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r["g"], ref["g"], rtol=1e-8, atol=1e-9)     # final-iteration u = X g (src/Bayes.cpp:1023)
+    np.testing.assert_allclose(r["e"], ref["e"], rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("model,Pi,fold,geo", CASES)
+@pytest.mark.parametrize("panel,mcols", [(512, 32768), (64, 4096)])
+@pytest.mark.parametrize("start", ["cold", "dense"])
+def test_default_geometry_draw_for_draw_at_pipeline_depth(big, model, Pi, fold, geo, panel, mcols, start):
+    X, y = big["X"][:, :mcols], big["y"]
+    if model == "BayesRR":
+        if panel == 512:
+            panel = 0          # every marker moves: the library's own default panel for RR/A/L (128)
+        X = X[:, :min(mcols, 8192)]
+    m = X.shape[1]
+    g0 = None
+    if start == "dense":       # 30 % of the markers in the model before the first sweep: crowded panels from the start
+        rng = np.random.default_rng(5 + m)
+        g0 = np.where(rng.random(m) < 0.3, rng.normal(0, 0.03, m), 0.0)
+    kw = dict(fold=fold, niter=8, nburn=0, thin=1, seed=97531)
+    ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, g_init=g0, **kw)
+    with H.Context(X.shape[0], m, panel=panel, precise=True, seed=97531) as c:
+        c.upload(X)
+        # the geometry hb_bayes_run() itself chooses for this model (hb_run.hip: setup)
+        c.set_pipeline(*geo)
+        assert c.pipeline()[:3] == geo
+        if geo == (1, 2, 6):
+            assert (m + c.panel - 1) // c.panel >= 11 * 6 - 5     # >= 11 mat-vec groups
+        r = H.Bayes(y, None, model, Pi, verbose=False, precise=True, g_init=g0, ctx=c, **kw)
+        ev = r["timing"]["mean_events"]
+    _compare(r, ref)
+    if start == "dense" and model != "BayesRR":
+        assert ev > 0.03 * m                                       # it really was a dense chain
+    # and through the one-call boundary, which picks the geometry by itself (no context): same chain
+    if panel in (0, 512) and start == "cold":
+        r2 = H.Bayes(y, X, model, Pi, verbose=False, precise=True, panel=panel, **kw)
+        _compare(r2, ref)
+
+
+@pytest.mark.parametrize("panel,geo", [(64, (1, 2, 6)), (512, (1, 2, 6)), (128, (1, 2, 1)), (256, (1, 1, 8)), (64, (0, 3, 1))])
+def test_every_band_gram_block_exact(panel, geo):
+    rng = np.random.default_rng(panel + geo[2])
+    n, m = 311, panel * 21 + 9
+    X = geno(rng, n, m)
+    if panel == 128:
+        X = (X - 1).astype(np.int8)           # signed codes (-1/0/1)
+    X = np.asfortranarray(X)
+    with H.Context(n, m, panel=panel) as c:
+        c.upload(X)
+        c.set_pipeline(*geo)
+        c.build_gram()
+        pipe, Lv, D, band = c.pipeline()
+        assert band == max((Lv + 1) * D - 1, Lv) if pipe else band == Lv
+        npan = (m + panel - 1) // panel
+        Xp = np.zeros((n, npan * panel))          # float64 BLAS products of small integers are exact (|G| <= 4 n << 2^53)
+        Xp[:, :m] = X
+        checked = 0
+        for p in range(npan):
+            cols = Xp[:, p * panel:(p + 1) * panel]
+            for l in range(0, band + 1):
+                if p - l < 0:
+                    continue
+                rows = Xp[:, (p - l) * panel:(p - l + 1) * panel]
+                G = c.gram_band(p, l)
+                assert np.array_equal(G, (rows.T @ cols).astype(np.int64)), "band block p=%d l=%d" % (p, l)   # int32, bit-exact
+                checked += 1
+        assert checked >= npan * (band + 1) - (band + 1) * (band + 2) // 2

@@ -65,6 +65,30 @@ def test_ibrm_full_formula_with_covariates_and_random_effects(demo):
     np.testing.assert_allclose(fit["g"]["gebv"], pl["geno"].astype(float) @ fit["alpha"], rtol=1e-10, atol=1e-12)
 
 
+def test_readme_fit_on_the_gpu_inside_the_printed_posterior(demo):
+    """reference README.md:130-172 (real hibayes, R's RNG): Vg 52.10 +- 13.08, h2 0.357 +- 0.081, pi1 0.927 +- 0.039,
+    Ve 30.77 +- 6.32, Vr(loc) 8.10 +- 4.79, Vr(dam) 54.29 +- 10.10, fixed effects -21.919 -11.484 -11.576 2.399.
+    tests/test_oracle_sampler.py reproduces that printout digit for digit with the oracle on R's stream; the GPU draws
+    from Philox, so its chains are other draws from the same posterior: each of 4 seeds must land inside the printed
+    mean +- 2 posterior SD (a chain's own Monte-Carlo error is ~SD/10), their average inside +- 1 SD, and the
+    data-determined fixed effects within 0.5 of the printed values."""
+    pl, phe = demo["plink"], demo["phe"]
+    fits = [H.ibrm("T1 ~ season + bwt + (1 | loc) + (1 | dam)", data=phe, M=pl["geno"], M_id=demo["ids"], method="BayesCpi",
+                   Pi=[0.98, 0.02], niter=20000, nburn=16000, thin=5, seed=s, verbose=False, store_alpha=False)
+            for s in (666666, 1, 2, 3)]
+    band = {"Vg": (52.10097, 13.084), "h2": (0.35748, 0.081), "Ve": (30.77, 6.323)}
+    for k, (mean, sd) in band.items():
+        v = np.array([f[k] for f in fits])
+        assert (np.abs(v - mean) < 2 * sd).all() and abs(v.mean() - mean) < sd, (k, v)
+    pi1 = np.array([f["pi"][0] for f in fits])
+    assert (np.abs(pi1 - 0.92683) < 2 * 0.039).all() and abs(pi1.mean() - 0.92683) < 0.039
+    vr = np.array([f["Vr"] for f in fits])
+    assert (np.abs(vr - [8.10, 54.29]) < 2 * np.array([4.785, 10.096])).all()
+    beta = np.array([f["beta"] for f in fits])
+    assert (np.abs(beta - [-21.919, -11.484, -11.576, 2.399]) < 0.5).all(), beta
+    assert fits[0]["n_records"] == 800 and len(fits[0]["g"]["gebv"]) == 600
+
+
 def test_gwas_windows_wppa(demo):
     chrom = np.array([int(c) for c in demo["plink"]["map"]["Chr"]])
     wind = H.cutwind_by_num(chrom, demo["plink"]["map"]["Pos"], 50)

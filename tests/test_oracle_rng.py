@@ -66,3 +66,26 @@ def test_gamma_chisq_invgauss_moments(kind):
     ig = np.array([s.invgauss(1.5, 4.0) for _ in range(20000)])
     assert abs(ig.mean() - 1.5) < 0.05  # E = mu, Var = mu^3/lambda
     assert abs(ig.var() / (1.5 ** 3 / 4.0) - 1) < 0.15
+
+
+def test_r_exp_rand_known_values():
+    # R: set.seed(1); rexp(3)  ->  0.7551818 1.1816428 0.1457067   (R documentation; rexp(n) = exp_rand() at rate 1)
+    mt = O.MT(1)
+    assert [round(mt.exp(), 7) for _ in range(3)] == [0.7551818, 1.1816428, 0.1457067]
+
+
+def test_r_rgamma_ahrens_dieter():
+    from scipy import stats
+    # GD step 2 (immediate acceptance): when the first normal deviate t is >= 0 the result is (sqrt(a - 1/2) + t/2)^2.
+    # R: set.seed(42); rnorm(1) -> 1.37095845 (published), so set.seed(42); rgamma(1, 2) = (sqrt(1.5) + 0.685479)^2
+    z = O.MT(42).norm()
+    assert round(z, 8) == 1.37095845
+    assert O.MT(42).gamma(2.0) == pytest.approx((np.sqrt(1.5) + 0.5 * z) ** 2, rel=1e-15)
+    # distribution: GS (a < 1), GD in each of its three parameter regimes (a <= 3.686, <= 13.022, above), scale
+    for a in (0.3, 1.0, 2.5, 9.0, 40.0, 150.5):
+        mt = O.MT(7)
+        x = np.array([mt.gamma(a, 2.0) for _ in range(40000)])
+        assert stats.kstest(x, "gamma", args=(a, 0, 2.0)).pvalue > 1e-3
+    # the unified stream uses it for the R kind (R::rgamma / R::rchisq at reference src/stats.cpp:13-24)
+    s, mt = O.Stream(O.RNG_R, 99), O.MT(99)
+    assert [s.gamma(3.5, 1.0), s.chisq(298.0)] == [mt.gamma(3.5, 1.0), mt.gamma(149.0, 2.0)]

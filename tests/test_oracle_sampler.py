@@ -146,3 +146,38 @@ def test_full_formula_fixture(demo):
     np.testing.assert_allclose(r["Vr"], g["Vr"], rtol=1e-9)
     np.testing.assert_allclose(r["r"], g["r"], rtol=1e-8, atol=1e-10)
     assert r["n_levels"] == g["r"].size
+
+
+def test_oracle_reproduces_the_fit_printed_in_the_reference_readme(demo):
+    """THE pin of the sampler restatement. reference README.md:130-172 prints summary() of
+        ibrm(T1 ~ season + bwt + (1 | loc) + (1 | dam), ..., method = "BayesCpi", Pi = c(0.98, 0.02),
+             niter = 20000, nburn = 16000, thin = 5, seed = 666666)
+    run by real hibayes under R. The oracle in R-stream mode (set.seed()'s Mersenne-Twister, inversion normals,
+    Ahrens-Dieter rgamma / exp_rand: oracle/hbo_rng.c) consumes the same stream draw for draw, so after 20 000
+    iterations of the whole loop (intercept, 4 covariates, 2 random-effect terms, 1000-marker BayesCpi sweep,
+    variance and pi draws: src/Bayes.cpp:477-917) every printed digit of that summary must come out — a single
+    misplaced draw or a mis-restated formula anywhere in the loop would decorrelate the chain completely."""
+    g = np.load(os.path.join(G, "demo_full_formula_philox.npz"), allow_pickle=True)
+    r = O.bayes(demo["y"], demo["M"], "BayesCpi", [0.98, 0.02], Cmat=g["C"], R=g["R"], niter=20000, nburn=16000,
+                thin=5, rng=O.RNG_R, seed=666666, store_alpha=True)
+    sd = lambda a, **k: np.std(a, ddof=1, **k)
+    assert r["n_records"] == 800
+    # Genetic random effects (README.md:162-166): Estimate, SD
+    assert round(r["Vg"], 5) == 52.10097 and round(sd(r["s_Vg"]), 3) == 13.084
+    assert round(r["h2"], 5) == 0.35748 and round(sd(r["s_h2"]), 3) == 0.081
+    assert [round(v, 5) for v in r["pi"]] == [0.92683, 0.07317]
+    assert [round(v, 3) for v in sd(r["s_pi"], axis=1)] == [0.039, 0.039]
+    # Environmental random effects (:155-159): loc, dam, Residual
+    assert [round(v, 2) for v in r["Vr"]] == [8.10, 54.29]
+    assert [round(v, 3) for v in sd(r["s_Vr"], axis=1)] == [4.785, 10.096]
+    assert round(r["Ve"], 2) == 30.78 or round(r["Ve"] - 5e-4, 2) == 30.77     # printed 30.77 (R prints 4 significant digits of 30.7753)
+    assert round(sd(r["s_Ve"]), 3) == 6.323
+    # Fixed effects (:147-153): (Intercept), seasonSpring, seasonSummer, seasonWinter, bwt
+    assert round(r["mu"], 3) == 32.992 and round(sd(r["s_mu"]), 3) == 6.609
+    assert [round(v, 3) for v in r["beta"]] == [-21.919, -11.484, -11.576, 2.399]
+    assert [round(v, 3) for v in sd(r["s_beta"], axis=1)] == [1.437, 1.410, 1.549, 0.792]
+    # Residuals (:143-145) and Marker effects (:169-171): R's quantile() type 7 == numpy's default, 5 significant digits
+    sig = lambda v, d: [float("%.*g" % (d, x)) for x in v]                   # R prints summary() quantiles to d significant digits
+    assert sig(np.quantile(r["e"], [0, .25, .5, .75, 1]), 5) == [-8.6113, -2.2907, 0.17169, 2.3326, 9.7695]
+    assert sig(np.quantile(r["alpha"], [0, .25, .5, .75, 1]), 6) == [-1.98438, -0.0242465, 0.0, 0.0253073, 1.9202]
+    assert len(r["r"]) == 50 + 150 and r["alpha"].size == 1000              # "group: loc, 50; dam, 150", "Number of markers: 1000"
