@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# arithmetic of the dominant kernel (everything else — chain, residual, updates — is f64 in every mode)
+DTYPE = {0: "f32", 1: "f64", 2: "fx56 (exact: f64 residual as 7 int8 digit planes, i8 x i8 -> i32 dot4; error below an f64 ddot's)"}
 
 
 def parse():
@@ -45,7 +47,9 @@ def parse():
     ap.add_argument("--model", default="BayesCpi", help="BASELINE.json north_star target: BayesCpi at n=50k, m=500k")
     ap.add_argument("--secondary", default="BayesR", help="second model measured on the same genotypes ('' = none)")
     ap.add_argument("--panel", type=int, default=0)
-    ap.add_argument("--precise", type=int, default=0)
+    ap.add_argument("--precise", type=int, default=2,
+                    help="panel mat-vec arithmetic: 2 = exact fixed point (7 int8 digit planes of the fp64 residual, int32 dot4 "
+                         "accumulation; fp64-grade, the library default), 1 = fp64 FMA, 0 = fp32 image of the residual")
     ap.add_argument("--seed", type=int, default=20240901)
     ap.add_argument("--cpu-m", type=int, default=8000, help="markers of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-sweeps", type=int, default=4)
@@ -228,7 +232,7 @@ def main():
             print("[bench %.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
 
     t_start = t0 = time.time()
-    ctx = H.Context(n, m, device=local_rank, panel=args.panel, precise=bool(args.precise), m_offset=m_offset,
+    ctx = H.Context(n, m, device=local_rank, panel=args.panel, precise=args.precise, m_offset=m_offset,
                     seed=args.seed)
     ctx.generate(args.seed, mono_every=1000)
     gen_s = time.time() - t0
@@ -265,7 +269,7 @@ def main():
         "metric": "Gibbs sweeps/sec (full m-marker pass) + achieved HBM GB/s, n=50k m=500k",
         "value": value, "unit": "sweeps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64" if args.precise else "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPE[args.precise], "data": "synthetic",
         "config": {"workload": "%s marker sweep, n=%d individuals x m=%d int8 markers per GPU (m_global=%d), "
                                "panel=%d, pipeline=%s" % (args.model, n, m, m_global, ctx.panel, (geo,)),
                    "model": args.model, "n": n, "m_per_gpu": m, "m_global": m_global, "panel": ctx.panel,

@@ -27,12 +27,15 @@ def _f64(a):
 def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, niter=50000, nburn=20000,
           thin=5, epsl_y_J=None, epsl_Gi=None, epsl_index=None, dfvr=None, s2vr=None, vg=None,
           dfvg=None, s2vg=None, ve=None, dfve=None, s2ve=None, windindx=None, outfreq=100, threads=0,
-          verbose=True, *, seed=666666, device=0, panel=0, precise=False, store_alpha=True,
+          verbose=True, *, seed=666666, device=0, panel=0, precise=2, store_alpha=True,
           comm=None, m_global=None, m_offset=0, log=None, C=None, g_init=None, ctx=None):
     """Individual-level Gibbs sampler on one MI355X (or one marker shard of it when `comm` is given).
 
     X is n x m: int8 (fast path, no double blow-up) or any integer-valued float array in the
     reference's layout. Returns a dict with the fields of the reference's Rcpp::List.
+    `precise` selects the arithmetic of the panel mat-vec x_j . yadj (everything else is fp64 in every mode):
+    2 (default) exact fixed point — the fp64 residual as 7 int8 digit planes, int8 x int8 -> int32 dot products, error below
+    an fp64 ddot's own rounding and independent of the launch geometry; 1 fp64 FMA; 0 the fp32 image of the residual.
     `ctx` (an engine.Context with genotypes already resident) replaces X: one upload serves several fits;
     the context's own pipeline geometry, seed addressing (m_offset) and panel are then used as they are.
     """
@@ -110,7 +113,7 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
         nw = int(w.max())
         keep.append(w)
     a.outfreq, a.threads, a.verbose = int(outfreq), int(threads), int(bool(verbose))
-    a.seed, a.device, a.panel, a.precise = int(seed), int(device), int(panel), int(bool(precise))
+    a.seed, a.device, a.panel, a.precise = int(seed), int(device), int(panel), int(precise)
     nrec = max((int(niter) - int(nburn)) // max(int(thin), 1), 0)
     a.store_alpha = int(bool(store_alpha))
     if comm is not None and comm.world > 1:
@@ -254,7 +257,7 @@ def _model_matrix(cols, names, rows):
 def ibrm(formula, data=None, M=None, M_id=None, method="BayesCpi", map=None, Pi=None, fold=None,
          niter=None, nburn=None, thin=5, windsize=None, windnum=None, dfvr=None, s2vr=None, vg=None,
          dfvg=None, s2vg=None, ve=None, dfve=None, s2ve=None, printfreq=100, seed=666666,
-         threads=4, verbose=True, *, windindx=None, device=0, panel=0, precise=False,
+         threads=4, verbose=True, *, windindx=None, device=0, panel=0, precise=2,
          store_alpha=True, comm=None):
     """Mirror of ibrm() (reference R/bayes.r:121-320). `formula` is a string such as
     "T1 ~ 1" or "T1 ~ season + bwt + (1 | loc) + (1 | dam)"; `data` a dict of columns or a

@@ -166,6 +166,11 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->r, (size_t)c->ld * 8));          // up to 8 versions; slot 0 is the residual between sweeps
     TRY(dev_alloc(&c->u, (size_t)c->ld));
     TRY(dev_alloc(&c->r32, (size_t)c->ld * 8));
+    TRY(dev_alloc(&c->rq, (size_t)c->ld * 8 * HB_ND));
+    TRY(dev_alloc(&c->vexp, 8));
+    TRY(dev_alloc(&c->gexp, (size_t)c->npanels + 1));
+    TRY(dev_alloc(&c->mb, (size_t)c->npanels + 2));
+    TRY(dev_alloc(&c->accq, (size_t)HB_ND * mp));
     TRY(dev_alloc(&c->xinfo, 2));
     TRY(dev_alloc(&c->thr, mp * (HB_MAX_FOLD - 1)));
     TRY(dev_alloc(&c->invv, mp * (HB_MAX_FOLD - 1)));
@@ -214,7 +219,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
     void *ptrs[] = {c->X, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
-                    c->r32, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->dots, c->ev_count, c->ev_idx,
+                    c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->dots, c->ev_count, c->ev_idx,
                     c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

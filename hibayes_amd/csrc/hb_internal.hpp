@@ -18,6 +18,8 @@ int hb_fail(int status, const std::string &msg);
     } while (0)
 
 // layout of the per-sweep scalar block the kernels accumulate into / the host reads back
+#define HB_ND 7 /* int8 digits of the fixed-point residual: 55 bits + sign */
+
 enum {
     HB_ACC_SUMG2 = 0,
     HB_ACC_COUNT0 = 1, // .. +HB_MAX_FOLD
@@ -59,6 +61,13 @@ struct hb_ctx {
     uint32_t *nzrate = nullptr;
     double *r = nullptr, *u = nullptr;
     float *r32 = nullptr;
+    // precise == 2: exact fixed-point mat-vec. Residual version slot s is also kept as HB_ND balanced
+    // base-256 digit planes rq[s][k][ld] (int8) of q = rint(yadj * 2^vexp[s]), |q| <= 2^54.
+    int8_t *rq = nullptr;
+    int *vexp = nullptr;          // [8] exponent of the digits in each residual slot
+    int *gexp = nullptr;          // [npanels + 1] exponent the mat-vec launch of each group / panel used (for its finalize)
+    double *mb = nullptr;         // [npanels + 2]: mb[0] = max |yadj| at sweep start, mb[1 + h] = bound on max |yadj| after group / panel h
+    long long *accq = nullptr;    // [HB_ND][m_pad] exact digit-plane sums of the current sweep's mat-vecs
     int32_t *gram = nullptr;
     size_t gram_cap = 0; // ints allocated
     bool env_pinned = false;

@@ -148,7 +148,38 @@ struct upd_view {
     double *r, *u;               // ... after (distinct buffers under look-ahead); u updated in place
     float *r32;
     unsigned *flags;             // non-null: wait for chain_done >= p1 first (persistent pipeline)
+    // fixed-point path (precise == 2): the new version is also written as HB_ND digit planes of rint(yadj * 2^E);
+    // E comes from the bound on max |yadj| the chain publishes with these moves, so |q| <= 2^54 is guaranteed
+    int8_t *rq;                  // digit planes of the output slot (null: other paths)
+    const double *mbv;           // bound on max |yadj| after these moves
+    int *vexp_out;               // exponent of the output slot
 };
+
+// exponent E with bound * 2^E < 2^54 (0 for an all-zero or non-finite bound)
+__device__ __forceinline__ int hb_fix_exp(double bound)
+{
+    if (!(bound > 0.0) || !(bound < 1e300)) return 0;
+    const int e = min(max(53 - ilogb(bound), -900), 900);
+    return e;
+}
+
+// balanced base-256 digits of four fixed-point values, packed per plane (byte b = row b)
+__device__ __forceinline__ void hb_store_digits(int8_t *rq, int64_t ld, int64_t row0, int E, double r0, double r1, double r2, double r3)
+{
+    long long q[4] = {__double2ll_rn(ldexp(r0, E)), __double2ll_rn(ldexp(r1, E)), __double2ll_rn(ldexp(r2, E)),
+                      __double2ll_rn(ldexp(r3, E))};
+#pragma unroll
+    for (int k = 0; k < HB_ND; k++) {
+        unsigned w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int d = (k == HB_ND - 1) ? (int)q[b] : (int)(int8_t)(q[b] & 0xff);
+            q[b] = (q[b] - d) >> 8;
+            w |= ((unsigned)d & 0xffu) << (8 * b);
+        }
+        *reinterpret_cast<unsigned *>(rq + (int64_t)k * ld + row0) = w;
+    }
+}
 
 // rows [row0, row0 + 4) of the residual: yadj -= sum_e x_e D_e, u += the same, r32 = (float)yadj
 __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int blk, int *s_ix,
@@ -168,6 +199,14 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
         if (threadIdx.x == 0) *s_ok = wait_ge(q.flags, HB_FLAG_CHAIN_DONE, (unsigned)q.p1) ? 1 : 0;
         __syncthreads();
         if (!*s_ok) return;
+    }
+    int fixE = 0;
+    if (q.rq) { // (uniform) exponent of the new version, the same number in every workgroup
+        __syncthreads();
+        if (threadIdx.x == 0) s_ok[1] = hb_fix_exp(ld_sc1(q.mbv));
+        __syncthreads();
+        fixE = s_ok[1];
+        if (blk == 0 && threadIdx.x == 0) *q.vexp_out = fixE;
     }
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int total = 0;
@@ -208,6 +247,7 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
     *reinterpret_cast<double2 *>(q.r + row0) = r01;
     *reinterpret_cast<double2 *>(q.r + row0 + 2) = r23;
     *reinterpret_cast<float4 *>(q.r32 + row0) = make_float4((float)r01.x, (float)r01.y, (float)r23.x, (float)r23.y);
+    if (q.rq) hb_store_digits(q.rq, ld, row0, fixE, r01.x, r01.y, r23.x, r23.y);
     if (total) {
         u01.x += a0; u01.y += a1; u23.x += a2; u23.y += a3;
         *reinterpret_cast<double2 *>(q.u + row0) = u01;
@@ -271,8 +311,8 @@ __global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64
         if (sp == 0) {
             __shared__ int s_ix[512];
             __shared__ double s_dl[512];
-            __shared__ int s_ok;
-            for (int blk = ct; (int64_t)blk * 1024 < ld; blk += gridDim.x) update_rows(ld, uq, blk, s_ix, s_dl, &s_ok);
+            __shared__ int s_ok[2];
+            for (int blk = ct; (int64_t)blk * 1024 < ld; blk += gridDim.x) update_rows(ld, uq, blk, s_ix, s_dl, s_ok);
             return;
         }
         sp -= 1;
@@ -339,6 +379,171 @@ __global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64
         const acc_t s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         partial[(int64_t)sp * pstride + ct * 8 + tid] = (double)s;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dotq: the exact fixed-point mat-vec (precise == 2).  d_j = x_j . yadj is computed as
+//     sum_k 256^k (x_j . D_k) * 2^-E,   D_k = digit plane k of q = rint(yadj * 2^E)  (balanced base-256 digits, int8)
+// with every x_j . D_k an exact int8 x int8 -> int32 dot product (v_dot4_i32_i8, 4 multiply-adds per lane and
+// instruction: 7 instructions per 4 genotypes against 8 for the fp32 path). Integer sums are order-independent, so the
+// row splits combine through 64-bit atomics and the result does not depend on the launch geometry at all; its error is
+// the quantisation of yadj alone (<= 2^-55 max|yadj| per element: below the rounding error of an fp64 ddot).
+// One wave = 64 columns x NS stages of 128 rows, lane = column: the genotype tile AND the stage's digit planes arrive by
+// LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, double-buffered, counted vmcnt — nothing else is in the
+// vector-memory queue); a lane reads its own column with ds_read_b128 and the digits with wave-uniform (broadcast)
+// ds_read_b128. No cross-lane reduction anywhere. The slot stride of 1040 bytes rotates the LDS banks between the
+// eight DMA pieces of a stage.
+// Block roles by index: [0, nupd) residual update of an earlier group (its digits included), [nupd, nupd + nfin)
+// finalize the previous launch's columns into dsum[], then the tiles.
+// ---------------------------------------------------------------------------------------------
+typedef int hb_v4i __attribute__((ext_vector_type(4)));
+#define HBQ_RS 128                       /* rows per stage */
+#define HBQ_SLOT 1040
+#define HBQ_NX 8                         /* DMA pieces per stage for the genotype tile (8 columns x 128 rows each) */
+#define HBQ_XB (HBQ_NX * HBQ_SLOT)
+#define HBQ_BUF (HBQ_XB + 1024)          /* + one piece for the 7 digit planes */
+#define HBQ_PER (HBQ_NX + 1)
+#define HBQ_LDS (2 * HBQ_BUF)
+
+struct dq_view {
+    const int8_t *X;       // first column of this launch
+    int64_t ld;
+    const int8_t *rq;      // digit planes of the residual slot read
+    const int *vexp_in;    // their exponent ...
+    int *gexp_out;         // ... recorded for this launch's finalize
+    long long *accq;       // [HB_ND][accstride], at this launch's first column
+    int64_t accstride;
+    int nstages, NS, ncg;
+    int nupd, nfin;
+    const long long *fin_acc; // finalize: digit-plane sums of the earlier launch's columns
+    double *fin_out;
+    const int *fin_exp;
+    int fin_ncols;
+};
+
+template <bool NT>
+__device__ __forceinline__ void hbq_dma16(unsigned voff, const int8_t *sbase, unsigned lds_dst)
+{
+    unsigned keep; // M0 (the LDS destination base) is compiler-reserved: set and restored inside the statement
+    if (NT) // genotypes are streamed once: non-temporal, so that the digit planes and the chain's working set stay in L2
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst)
+                     : "memory");
+}
+
+__device__ __forceinline__ void hbq_finalize(const long long *acc, int64_t stride, int col, int E, double *out)
+{
+    double a = 0.0;
+#pragma unroll
+    for (int k = HB_ND - 1; k >= 0; k--) a = fma(a, 256.0, (double)acc[(int64_t)k * stride + col]);
+    st_sc1(out + col, ldexp(a, -E));
+}
+
+__global__ __launch_bounds__(64) void k_dotq_fin(const long long *__restrict__ acc, int64_t stride, int ncols,
+                                                 const int *__restrict__ pexp, double *__restrict__ out)
+{
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col < ncols) hbq_finalize(acc, stride, col, *pexp, out);
+}
+
+__global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    int b = blockIdx.x;
+    if (b < v.nupd) { // residual update of an earlier group: 256 rows per block, lists staged in the (unused) tile buffers
+        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048),
+                    reinterpret_cast<int *>(smem + 2048 + 4096));
+        return;
+    }
+    b -= v.nupd;
+    if (b < v.nfin) {
+        const int col = b * 64 + lane;
+        if (col < v.fin_ncols) hbq_finalize(v.fin_acc, v.accstride, col, *v.fin_exp, v.fin_out);
+        return;
+    }
+    b -= v.nfin;
+    const int cg = b % v.ncg, sp = b / v.ncg;
+    if (b == 0 && lane == 0) *v.gexp_out = *v.vexp_in;
+    const int st0 = sp * v.NS, st1 = min(v.nstages, st0 + v.NS);
+    if (st0 >= st1) return;
+    const int64_t ld = v.ld;
+    const int8_t *xg = v.X + (int64_t)cg * 64 * ld;
+    const unsigned voff = (unsigned)((lane >> 3) * ld + (lane & 7) * 16);                    // piece i: columns 8i .. 8i+7
+    const unsigned doff = (unsigned)(min(lane >> 3, HB_ND - 1) * ld + (lane & 7) * 16);    // digit piece: plane lane/8
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    int acc[HB_ND];
+#pragma unroll
+    for (int k = 0; k < HB_ND; k++) acc[k] = 0;
+    auto issue = [&](int st, int buf) {
+        const int8_t *base = xg + (int64_t)st * HBQ_RS;
+        const unsigned dst = lds0 + (unsigned)buf * HBQ_BUF;
+#pragma unroll
+        for (int i = 0; i < HBQ_NX; i++) hbq_dma16<true>(voff, base + (int64_t)(8 * i) * ld, dst + i * HBQ_SLOT);
+        hbq_dma16<false>(doff, v.rq + (int64_t)st * HBQ_RS, dst + HBQ_XB);
+    };
+    issue(st0, 0);
+    int buf = 0;
+    for (int st = st0; st < st1; ++st) {
+        if (st + 1 < st1) {
+            issue(st + 1, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(HBQ_PER) : "memory"); // everything but the stage just requested has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char *bp = smem + buf * HBQ_BUF;
+        const hb_v4i *px = reinterpret_cast<const hb_v4i *>(bp + (lane >> 3) * HBQ_SLOT + (lane & 7) * HBQ_RS);
+        const char *pd = bp + HBQ_XB;
+#pragma unroll
+        for (int s = 0; s < HBQ_RS / 16; s++) {
+            const hb_v4i x = px[s];
+#pragma unroll
+            for (int k = 0; k < HB_ND; k++) {
+                const hb_v4i d = *reinterpret_cast<const hb_v4i *>(pd + k * HBQ_RS + s * 16);
+                acc[k] = __builtin_amdgcn_sdot4(x.x, d.x, acc[k], false);
+                acc[k] = __builtin_amdgcn_sdot4(x.y, d.y, acc[k], false);
+                acc[k] = __builtin_amdgcn_sdot4(x.z, d.z, acc[k], false);
+                acc[k] = __builtin_amdgcn_sdot4(x.w, d.w, acc[k], false);
+            }
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int k = 0; k < HB_ND; k++)
+        __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * 64 + lane, (long long)acc[k], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Sweep start of the fixed-point path: max |yadj| -> mb[0] and the exponent of slot 0, then slot 0's digit planes.
+// One workgroup (n is a few hundred KB).
+__global__ __launch_bounds__(1024) void k_quant0(const double *__restrict__ r, int64_t ld, int8_t *__restrict__ rq,
+                                                 double *__restrict__ mb, int *__restrict__ vexp)
+{
+    __shared__ double red[16];
+    __shared__ double s_max;
+    double mx = 0.0;
+    for (int64_t i = threadIdx.x; i < ld; i += blockDim.x) mx = fmax(mx, fabs(r[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m2 = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) m2 = fmax(m2, red[i]);
+        s_max = m2;
+        mb[0] = m2;
+        vexp[0] = hb_fix_exp(m2);
+    }
+    __syncthreads();
+    const int E = hb_fix_exp(s_max);
+    for (int64_t row0 = (int64_t)threadIdx.x * 4; row0 < ld; row0 += (int64_t)blockDim.x * 4)
+        hb_store_digits(rq, ld, row0, E, r[row0], r[row0 + 1], r[row0 + 2], r[row0 + 3]);
 }
 
 __global__ void k_sum_partials(const double *__restrict__ partial, int pstride, int nsplit, int ncols,
@@ -511,6 +716,10 @@ struct chain_view {
     const uint32_t *wind;
     uint8_t *wflag;
     long long *dbg; // optional: 32 cycle stamps per panel (tools/chain_timeline.py)
+    // fixed-point path: running bound on max |yadj| (mb[0] at sweep start, mb[1 + h] after group / panel h) — each move D of a
+    // marker raises it by at most xabs * |D|; the update derives the digits' exponent from it (null: other paths)
+    double *mb;
+    double xabs;
 };
 
 #define HB_STAMP(i) do { if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + (i)] = clock64(); } while (0)
@@ -748,9 +957,15 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
         if (lane == 0 && mk) atomicAdd(&cnts[1 + c], __popcll(mk));
     }
     const double wsum = block_sum(w, red); // two barriers: also publishes the class counts
+    double absd = 0.0;
     for (int e = t; e < nev; e += P) {
         v.ev_idx[(size_t)p * P + e] = ev_ix[e] & 0xffff;
         v.ev_delta[(size_t)p * P + e] = ev_del[e];
+        absd += fabs(ev_del[e]);
+    }
+    if (v.mb) { // (uniform)
+        absd = block_sum(absd, red);
+        if (t == 0) v.mb[1 + p] = fma(v.xabs, absd, v.mb[p]);
     }
     if (t == 0) {
         v.ev_count[p] = nev;
@@ -911,6 +1126,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
 #pragma unroll
     for (int c = 0; c <= K1; c++) cacc[c] = 0;
     int evacc = 0, missacc = 0, redoacc = 0;
+    double mbr = v.mb ? v.mb[0] : 0.0; // running bound on max |yadj| (kept by the publishing wave)
+    int gcount = 0;                     // mat-vec groups published so far
 
     // ---- prefetch registers ----
     // What the opening of a panel needs (its reduced dot, entry threshold, old effect, x'x, row-cache slot) is kept in
@@ -1335,11 +1552,14 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             // that no wave of the chain ever waits for a store to reach memory. A quiet panel keeps the zero count
             // the sweep started with. ----
             if (wave == S - 1 && nev > 0) {
+                double absd = 0.0;
                 for (int e = lane; e < nev; e += 64) {
                     st_sc1(&v.ev_idx[(size_t)p * P + e], ev_ix[e] & 0xffff);
                     st_sc1(&v.ev_delta[(size_t)p * P + e], ev_del[e]);
+                    absd += fabs(ev_del[e]);
                 }
                 if (lane == 0) st_sc1(&v.ev_count[p], nev);
+                if (v.mb) mbr = fma(v.xabs, wave_sum(absd), mbr);
             }
             HB_STAMP(4);
             if (!active) { cls_f = 0; g_f = 0.0; }
@@ -1393,6 +1613,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         if (wave == S - 1 && group_end) {
             // last panel of its mat-vec group: the update of this group is waiting for exactly these moves, and the
             // next panel's take may itself have to wait for a later launch — publish now rather than at that take
+            if (lane == 0 && v.mb) st_sc1(&v.mb[1 + gcount], mbr);
+            gcount++;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(p + 1));
         }
@@ -1403,6 +1625,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
 
     // ---- the last panel's moves: drain and publish ----
     if (wave == S - 1 && ok) {
+        if (lane == 0 && v.mb) st_sc1(&v.mb[1 + gcount], mbr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)np);
     }
@@ -1438,8 +1661,8 @@ __global__ __launch_bounds__(256) void k_update(int64_t ld, upd_view q)
 {
     __shared__ int s_ix[512];
     __shared__ double s_dl[512];
-    __shared__ int s_ok;
-    update_rows(ld, q, blockIdx.x, s_ix, s_dl, &s_ok);
+    __shared__ int s_ok[2];
+    update_rows(ld, q, blockIdx.x, s_ix, s_dl, s_ok);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1725,13 +1948,57 @@ static hipError_t launch_chain(hb_ctx *c, const chain_view &cv, int p, hipStream
 // residual version v (moves of panels <= v applied; v = -1: start of the sweep) lives in slot (v+1) mod NB
 static inline int ver_slot(const hb_ctx *c, int v) { return (v + 1) % c->NB; }
 
+// tiles of one k_dotq launch: about three waves per compute unit, each a long run of stages (measured: fewer, longer
+// waves stream better than many short ones; tools/dotq_bench.hip)
+static void dotq_geometry(const hb_ctx *c, int ncols, int *ncg, int *NS, int *nsplit)
+{
+    const int nst = (int)(c->ld / HBQ_RS);
+    *ncg = ncols / 64;
+    int target = 768;
+    if (const char *e = getenv("HB_DOTQ_TILES")) target = std::max(1, atoi(e));
+    int ns = std::max(1, std::min(nst, (int)((double)target / *ncg + 0.5)));
+    *NS = std::min(1024, (nst + ns - 1) / ns); // (int32 accumulators: NS * 128 rows * 127 * 128 < 2^31)
+    *nsplit = (nst + *NS - 1) / *NS;
+}
+
+static void launch_dotq(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st, int gidx, const upd_view *upd, int fin_col0,
+                        int fin_ncols, int fin_gidx)
+{
+    int ncg, NS, nsplit;
+    dotq_geometry(c, ncols, &ncg, &NS, &nsplit);
+    upd_view uq{};
+    if (upd) uq = *upd;
+    dq_view v{};
+    v.X = c->X + (int64_t)col0 * c->ld;
+    v.ld = c->ld;
+    v.rq = c->rq + (size_t)slot * HB_ND * c->ld;
+    v.vexp_in = c->vexp + slot;
+    v.gexp_out = c->gexp + gidx;
+    v.accq = c->accq + col0;
+    v.accstride = c->m_pad;
+    v.nstages = (int)(c->ld / HBQ_RS);
+    v.NS = NS;
+    v.ncg = ncg;
+    v.nupd = (uq.p1 > uq.p0) ? (int)(c->ld / 256) : 0;
+    v.nfin = fin_ncols > 0 ? (fin_ncols + 63) / 64 : 0;
+    v.fin_acc = c->accq + fin_col0;
+    v.fin_out = c->dsum + fin_col0;
+    v.fin_exp = c->gexp + fin_gidx;
+    v.fin_ncols = fin_ncols;
+    hipLaunchKernelGGL(k_dotq, dim3(v.nupd + v.nfin + ncg * nsplit), dim3(64), HBQ_LDS, st, v, uq);
+}
+
 static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, bool pipeline = false,
-                       const upd_view *upd = nullptr, int red_col0 = 0, int red_ncols = 0)
+                       const upd_view *upd = nullptr, int red_col0 = 0, int red_ncols = 0, int gidx = 0)
 {
     if (!st) st = c->stream;
     upd_view uq{};
     if (upd) uq = *upd;
     if (!pipeline) red_ncols = 0;
+    if (c->precise == 2) {
+        launch_dotq(c, col0, ncols, slot, st, gidx, upd, red_col0, red_ncols, gidx - 1);
+        return;
+    }
     const dim3 grid(ncols / 8, c->nsplit + (uq.p1 > uq.p0 ? 1 : 0) + (red_ncols > 0 ? 1 : 0)), block(256);
     const int8_t *Xp = c->X + (int64_t)col0 * c->ld;
     double *part = c->partial + col0;
@@ -1748,17 +2015,37 @@ static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t
     }
 }
 
-// the reduction of the last launch's partials (there is no next launch to carry it)
-static void launch_reduce(hb_ctx *c, int col0, int ncols, hipStream_t st)
+// digit-plane sums of [col0, col0 + ncols) -> doubles at out (the finalize that has no later launch to ride on)
+static void launch_dotq_fin(hb_ctx *c, int col0, int ncols, int gidx, double *out, hipStream_t st)
 {
+    hipLaunchKernelGGL(k_dotq_fin, dim3((ncols + 63) / 64), dim3(64), 0, st, c->accq + col0, (int64_t)c->m_pad, ncols, c->gexp + gidx, out);
+}
+
+// sweep start of the fixed-point path: digits of residual slot 0, bound mb[0], zeroed plane sums
+static void launch_quant0(hb_ctx *c, hipStream_t st)
+{
+    (void)hipMemsetAsync(c->accq, 0, sizeof(long long) * (size_t)HB_ND * c->m_pad, st);
+    hipLaunchKernelGGL(k_quant0, dim3(1), dim3(1024), 0, st, c->r, c->ld, c->rq, c->mb, c->vexp);
+}
+
+// the reduction of the last launch's partials (there is no next launch to carry it)
+static void launch_reduce(hb_ctx *c, int col0, int ncols, hipStream_t st, int gidx = 0)
+{
+    if (c->precise == 2) {
+        launch_dotq_fin(c, col0, ncols, gidx, c->dsum + col0, st);
+        return;
+    }
     dot_sync sy{c->partial + col0, c->dsum + col0, ncols, c->nsplit};
     hipLaunchKernelGGL(k_reduce_partials, dim3((ncols + 255) / 256), dim3(256), 0, st, sy, c->m_pad);
 }
 
-static upd_view make_upd(hb_ctx *c, int p0, int p1, int sin, int sout, unsigned *flags)
+// mbi: index of the group (pipeline) or panel (serial kernels) whose moves are applied — addresses the chain's bound mb[1 + mbi]
+static upd_view make_upd(hb_ctx *c, int p0, int p1, int sin, int sout, unsigned *flags, int mbi)
 {
+    const bool fx = c->precise == 2;
     return upd_view{c->X, c->P, p0, p1, c->ev_count, c->ev_idx, c->ev_delta, c->r + (size_t)sin * c->ld,
-                    c->r + (size_t)sout * c->ld, c->u, c->r32 + (size_t)sout * c->ld, flags};
+                    c->r + (size_t)sout * c->ld, c->u, c->r32 + (size_t)sout * c->ld, flags,
+                    fx ? c->rq + (size_t)sout * HB_ND * c->ld : nullptr, c->mb + 1 + mbi, c->vexp + sout};
 }
 
 struct phase_timer {
@@ -1808,6 +2095,8 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
     const int L = c->Lv, np = c->npanels; // per-panel launches: lag Lv with one panel per mat-vec
     hipStream_t sA = c->stream, sB = timed ? c->stream : c->s_chain, sC = timed ? c->stream : c->s_upd;
     HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, sA));
+    const bool fx = c->precise == 2;
+    if (fx) launch_quant0(c, sA);
     hipEvent_t t_all = tm.begin();
     {
         hipEvent_t b = tm.begin();
@@ -1820,9 +2109,10 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
         HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
         HB_HIP(hipStreamWaitEvent(sC, c->ev_fork, 0));
     }
-    chain_view cv{c->m_pad, c->P, c->nsplit, L, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
+    const double xabs = std::max(std::abs((double)c->xmin), std::abs((double)c->xmax));
+    chain_view cv{c->m_pad, c->P, fx ? 1 : c->nsplit, L, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
-                  c->wind, c->wflag, c->dbg};
+                  c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
     // software pipeline in issue order: mat-vec runs L panels ahead of chain/update in program order too,
     // so that a plain in-order replay of the captured graph is still dependency-correct
@@ -1833,7 +2123,8 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
             hipEvent_t b = tm.begin();
             const int vread = pd - L - 1;
             if (!timed && vread >= 0) HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[vread], 0));
-            launch_dot(c, pd * c->P, c->P, ver_slot(c, vread < -1 ? -1 : vread), sA);
+            launch_dot(c, pd * c->P, c->P, ver_slot(c, vread < -1 ? -1 : vread), sA, false, nullptr, 0, 0, pd);
+            if (fx) launch_dotq_fin(c, pd * c->P, c->P, pd, c->partial + (size_t)pd * c->P, sA); // the chain sums one "split"
             if (!timed) HB_HIP(hipEventRecord(c->ev_dot[pd], sA));
             tm.end(0, b);
         }
@@ -1847,7 +2138,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
             b = tm.begin();
             if (!timed) HB_HIP(hipStreamWaitEvent(sC, c->ev_chain[pc], 0));
             const int sin = ver_slot(c, pc - 1), sout = ver_slot(c, pc);
-            hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sC, c->ld, make_upd(c, pc, pc + 1, sin, sout, nullptr));
+            hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sC, c->ld, make_upd(c, pc, pc + 1, sin, sout, nullptr, pc));
             if (!timed) HB_HIP(hipEventRecord(c->ev_upd[pc], sC));
             tm.end(2, b);
         }
@@ -1913,6 +2204,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * HB_NFLAGS, sA));
     HB_HIP(hipMemsetAsync(c->ev_count, 0, sizeof(int32_t) * (size_t)np, sA)); // quiet panels do not write theirs
     HB_HIP(hipMemsetAsync(c->dsum, 0xFF, sizeof(double) * (size_t)c->m_pad, sA)); // "not written yet": a NaN no sum can produce
+    const bool fx = c->precise == 2;
+    if (fx) launch_quant0(c, sA);
     {
         pre_view pvw{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
         hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pvw);
@@ -1922,9 +2215,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
                        c->hot_list, c->hot_n, c->tracker);
     HB_HIP(hipEventRecord(c->ev_fork, sA));
     HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
+    const double xabs = std::max(std::abs((double)c->xmin), std::abs((double)c->xmax));
     chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
-                  c->wind, c->wflag, c->dbg};
+                  c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
     const int last_panels = np - (ngroups - 1) * D;
     persist_view pv{np, D, Lv, c->L, c->flags,
                     c->hot_slot, c->hot_list, c->hot_n, c->candf};
@@ -1942,14 +2236,14 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
         const int p0 = g * D, p1 = std::min(np, p0 + D);
         const int h = g - Lv;
         upd_view uq{};
-        if (h >= 0) uq = make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags);
+        if (h >= 0) uq = make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags, h);
         launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, true, h >= 0 ? &uq : nullptr,
-                   g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0);
+                   g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0, g);
     }
-    launch_reduce(c, (ngroups - 1) * D * c->P, last_panels * c->P, sA);
+    launch_reduce(c, (ngroups - 1) * D * c->P, last_panels * c->P, sA, ngroups - 1);
     for (int h = std::max(0, ngroups - Lv); h < ngroups; h++) // the updates that had no later mat-vec to ride on
         hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sA, c->ld,
-                           make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags));
+                           make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags, h));
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
     const int sfin = slot2(ngroups - 1);
@@ -2010,6 +2304,13 @@ int hbk_stats(hb_ctx *c)
 
 int hbk_dot_all(hb_ctx *c)
 {
+    if (c->precise == 2) {
+        launch_quant0(c, c->stream);
+        for (int p = 0; p < c->npanels; p++) launch_dot(c, p * c->P, c->P);
+        launch_dotq_fin(c, 0, c->m_pad, 0, c->dots, c->stream);
+        HB_HIP(hipGetLastError());
+        return HB_OK;
+    }
     for (int p = 0; p < c->npanels; p++) launch_dot(c, p * c->P, c->P);
     hipLaunchKernelGGL(k_sum_partials, dim3((c->m_pad + 255) / 256), dim3(256), 0, c->stream, c->partial, c->m_pad,
                        c->nsplit, c->m_pad, c->dots);
@@ -2138,15 +2439,16 @@ int hbk_time_matvec(hb_ctx *c, int D, int reps, int as_pipeline, double *avg_us,
     HB_HIP(hipEventCreate(&e1));
     const int ngroups = (c->npanels + D - 1) / D;
     HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * HB_NFLAGS, c->stream));
+    if (c->precise == 2) launch_quant0(c, c->stream);
     for (int warm = 0; warm < 2; warm++) {
         if (warm) HB_HIP(hipEventRecord(e0, c->stream));
         for (int r = 0; r < (warm ? reps : 1); r++) {
             for (int g = 0; g < ngroups; g++) {
                 const int p0 = g * D, p1 = std::min(c->npanels, p0 + D);
                 launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, as_pipeline != 0, nullptr,
-                           g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0);
+                           g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0, g);
             }
-            if (as_pipeline) launch_reduce(c, (ngroups - 1) * D * c->P, (c->npanels - (ngroups - 1) * D) * c->P, c->stream);
+            if (as_pipeline) launch_reduce(c, (ngroups - 1) * D * c->P, (c->npanels - (ngroups - 1) * D) * c->P, c->stream, ngroups - 1);
         }
     }
     HB_HIP(hipEventRecord(e1, c->stream));

@@ -11,7 +11,7 @@ MODEL_INDEX = {"BayesRR": 1, "BayesA": 2, "BayesB": 3, "BayesBpi": 3, "BayesC": 
 
 
 class Context:
-    def __init__(self, n, m, device=0, panel=0, precise=False, m_offset=0, seed=666666):
+    def __init__(self, n, m, device=0, panel=0, precise=2, m_offset=0, seed=666666):
         self.L = lib()
         p = CtxParams(device=device, n=n, m=m, panel=panel, precise=int(precise), m_offset=m_offset, seed=seed)
         h = C.c_void_p()

@@ -107,7 +107,8 @@ typedef struct hb_bayes_args {
     uint64_t seed;            /* replaces R's global RNG state (set.seed(), R/bayes.r:151)  */
     int32_t device;           /* HIP device ordinal                                         */
     int32_t panel;            /* markers per block-Gibbs panel: 0 = auto, else 64..1024     */
-    int32_t precise;          /* 1: fp64 accumulation in the panel mat-vec                  */
+    int32_t precise;          /* arithmetic of the panel mat-vec x_j . yadj: 2 exact fixed point (fp64 residual as
+                                 7 int8 digit planes, int8 x int8 -> int32; recommended), 1 fp64 FMA, 0 fp32 image */
     int32_t store_alpha;      /* keep MCMCsamples$alpha (m x n_records) — see hb_bayes_out  */
     /* marker sharding: this process owns global columns [m_offset, m_offset + m)           */
     int32_t rank, world;

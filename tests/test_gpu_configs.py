@@ -84,7 +84,7 @@ def test_config2_bayescpi_n10k_m100k_pipeline_vs_serial():
     with H.Context(n, m, seed=2) as c:
         c.generate(20240901, mono_every=1000)
         y = synth_y(c, n, m, 11)
-        a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 6), niter=50, precise=True, nburn=10, thin=2)
+        a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 6), niter=50, precise=2, nburn=10, thin=2)
         same_chain(a, b, 1e-9, "config 2: pipeline (1,2,6) vs serial kernels")
         assert a["timing"]["mean_events"] > 100
 
@@ -95,20 +95,20 @@ def test_config4_shard_shape_bayescpi_n50k_m250k_pipeline_vs_serial():
     with H.Context(n, m, seed=4, m_offset=750000) as c:
         c.generate(20240901, mono_every=1000)
         y = synth_y(c, n, m, 13)
-        a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 6), niter=6, precise=True)
+        a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 6), niter=6, precise=2)
         same_chain(a, b, 1e-9, "config 4 shard: pipeline vs serial")
 
 
-def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2):
+def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=2):
     need = n * m / 1e9 + 8
     if host_free_gb() < need:
         pytest.skip("host has %.0f GB available, the live oracle needs %.0f GB for the int8 genotypes" % (host_free_gb(), need))
     kw = dict(fold=fold, niter=niter, nburn=0, thin=1, seed=20240901)
-    with H.Context(n, m, seed=20240901, m_offset=m_offset, precise=True) as c:
+    with H.Context(n, m, seed=20240901, m_offset=m_offset, precise=precise) as c:
         c.generate(20240901, mono_every=1000)
         y = synth_y(c, n, m, 17)
         c.set_pipeline(*geo)
-        r = H.Bayes(y, None, model, Pi, verbose=False, precise=True, ctx=c, store_alpha=False, **kw)
+        r = H.Bayes(y, None, model, Pi, verbose=False, precise=precise, ctx=c, store_alpha=False, **kw)
         invariants(c, y, r)
         g_gpu, trk, _ = c.get_effects()
         X = c.download()
@@ -141,10 +141,11 @@ def test_config3_pipeline_vs_serial_kernels_precise_and_fast(model, Pi, fold, ge
     ~1e-6 of its threshold; the flip rate is measured and bounded."""
     n, m = 50000, 500000
     res = {}
-    for precise in (True, False):
+    y = None
+    for precise in (2, 1, 0):
         with H.Context(n, m, seed=99, precise=precise) as c:
             c.generate(20240901, mono_every=1000)
-            if precise:
+            if y is None:
                 y = synth_y(c, n, m, 19)
             xpx, vx, sumvx, nvar0 = c.marker_stats()
             vare, varg = 0.5, 0.5 / (0.05 * sumvx)
@@ -163,17 +164,21 @@ def test_config3_pipeline_vs_serial_kernels_precise_and_fast(model, Pi, fold, ge
                 gg, trk, _ = c.get_effects()
                 r, u = c.get_residual()
                 res[(precise, g == geo)] = (gg, trk, r, u, evs)
-    # fp64: pipeline == serial
-    (g1, t1, r1, u1, e1), (g0, t0, r0, u0, e0) = res[(True, True)], res[(True, False)]
-    assert np.array_equal(t1, t0)
-    for (c1, i1, d1), (c0, i0, d0) in zip(e1, e0):
-        assert np.array_equal(c1, c0) and np.array_equal(i1, i0)           # same markers moved, in the same order
-        np.testing.assert_allclose(d1, d0, rtol=1e-9, atol=1e-14)
-    np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-14)
-    np.testing.assert_allclose(r1, r0, rtol=0, atol=1e-10)
-    np.testing.assert_allclose(u1, u0, rtol=0, atol=1e-10)
-    # fp32 image: pipeline vs serial, and fast vs precise
-    (f1, ft1, fr1, fu1, _), (f0, ft0, _, _, _) = res[(False, True)], res[(False, False)]
+    # exact fixed point (2) and fp64 FMA (1): pipeline == serial kernels, and the two arithmetics give the same chain
+    for pr in (2, 1):
+        (g1, t1, r1, u1, e1), (g0, t0, r0, u0, e0) = res[(pr, True)], res[(pr, False)]
+        assert np.array_equal(t1, t0)
+        for (c1, i1, d1), (c0, i0, d0) in zip(e1, e0):
+            assert np.array_equal(c1, c0) and np.array_equal(i1, i0)       # same markers moved, in the same order
+            np.testing.assert_allclose(d1, d0, rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose(r1, r0, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(u1, u0, rtol=0, atol=1e-10)
+    assert np.array_equal(res[(2, True)][1], res[(1, True)][1])
+    np.testing.assert_allclose(res[(2, True)][0], res[(1, True)][0], rtol=1e-9, atol=1e-14)
+    g1, t1 = res[(2, True)][0], res[(2, True)][1]
+    # fp32 image: pipeline vs serial, and fast vs exact
+    (f1, ft1, fr1, fu1, _), (f0, ft0, _, _, _) = res[(0, True)], res[(0, False)]
     decisions = 3.0 * (m - nvar0)
     flips_geo = int((ft1 != ft0).sum())
     flips_prec = int((ft1 != t1).sum())

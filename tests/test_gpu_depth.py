@@ -62,7 +62,8 @@ def _compare(r, ref, tol=1e-9):
 @pytest.mark.parametrize("model,Pi,fold,geo", CASES)
 @pytest.mark.parametrize("panel,mcols", [(512, 32768), (64, 4096)])
 @pytest.mark.parametrize("start", ["cold", "dense"])
-def test_default_geometry_draw_for_draw_at_pipeline_depth(big, model, Pi, fold, geo, panel, mcols, start):
+@pytest.mark.parametrize("precise", [2, 1])   # 2: exact fixed-point mat-vec (library default); 1: fp64 FMA mat-vec
+def test_default_geometry_draw_for_draw_at_pipeline_depth(big, model, Pi, fold, geo, panel, mcols, start, precise):
     X, y = big["X"][:, :mcols], big["y"]
     if model == "BayesRR":
         if panel == 512:
@@ -75,21 +76,21 @@ def test_default_geometry_draw_for_draw_at_pipeline_depth(big, model, Pi, fold, 
         g0 = np.where(rng.random(m) < 0.3, rng.normal(0, 0.03, m), 0.0)
     kw = dict(fold=fold, niter=8, nburn=0, thin=1, seed=97531)
     ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, g_init=g0, **kw)
-    with H.Context(X.shape[0], m, panel=panel, precise=True, seed=97531) as c:
+    with H.Context(X.shape[0], m, panel=panel, precise=precise, seed=97531) as c:
         c.upload(X)
         # the geometry hb_bayes_run() itself chooses for this model (hb_run.hip: setup)
         c.set_pipeline(*geo)
         assert c.pipeline()[:3] == geo
         if geo == (1, 2, 6):
             assert (m + c.panel - 1) // c.panel >= 11 * 6 - 5     # >= 11 mat-vec groups
-        r = H.Bayes(y, None, model, Pi, verbose=False, precise=True, g_init=g0, ctx=c, **kw)
+        r = H.Bayes(y, None, model, Pi, verbose=False, precise=precise, g_init=g0, ctx=c, **kw)
         ev = r["timing"]["mean_events"]
     _compare(r, ref)
     if start == "dense" and model != "BayesRR":
         assert ev > 0.03 * m                                       # it really was a dense chain
     # and through the one-call boundary, which picks the geometry by itself (no context): same chain
     if panel in (0, 512) and start == "cold":
-        r2 = H.Bayes(y, X, model, Pi, verbose=False, precise=True, panel=panel, **kw)
+        r2 = H.Bayes(y, X, model, Pi, verbose=False, precise=precise, panel=panel, **kw)
         _compare(r2, ref)
 
 

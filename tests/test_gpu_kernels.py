@@ -73,6 +73,17 @@ def test_panel_matvec_against_fp64(signed):
         c.set_residual(r, np.zeros(n))
         d = c.dot()
     assert np.max(np.abs(d - ref) / scale) < 1e-13                      # fp64 accumulation
+    with H.Context(n, m, precise=2) as c:                               # exact fixed-point digits: error = quantisation of r only
+        c.upload(X)
+        c.set_residual(r, np.zeros(n))
+        dq = c.dot()
+    assert np.max(np.abs(dq - ref) / scale) < 1e-13
+    # ... and it is exactly the dot product with the quantised residual: q = rint(r * 2^E), 2^E * max|r| < 2^54
+    E = 53 - int(np.floor(np.log2(np.abs(r).max())))
+    q = np.rint(np.ldexp(r, E))
+    exact = np.array([int(v) for v in (X.astype(object).T @ q.astype(np.int64).astype(object))], dtype=object)
+    want = np.array([float(v) * 2.0 ** -E for v in exact])
+    assert np.array_equal(dq, want)                                     # bit for bit, whatever the launch geometry
     with H.Context(n, m, precise=False) as c:
         c.upload(X)
         c.set_residual(r, np.zeros(n))

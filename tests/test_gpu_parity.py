@@ -20,10 +20,11 @@ MODELS = [("BayesCpi", [0.95, 0.05], None), ("BayesC", [0.9, 0.1], None), ("Baye
 
 @pytest.mark.parametrize("model,Pi,fold", MODELS)
 @pytest.mark.parametrize("panel", [0, 64, 512])
-def test_draw_for_draw_against_golden(model, Pi, fold, panel):
+@pytest.mark.parametrize("precise", [1, 2])   # 1: fp64 FMA mat-vec; 2: exact fixed-point digits (the default of Bayes())
+def test_draw_for_draw_against_golden(model, Pi, fold, panel, precise):
     g = np.load(os.path.join(G, "small_all_models_philox.npz"))
     r = H.Bayes(g["y"], g["X"], model, Pi, fold=fold, niter=16, nburn=6, thin=2, seed=424242, verbose=False,
-                precise=True, panel=panel)
+                precise=precise, panel=panel)
     tol = 1e-6 if model == "BayesL" else 1e-9   # BayesL's inverse-Gaussian draw amplifies last-bit differences
     a, b = r["MCMCsamples"]["alpha"], g[model + "_alpha"]
     assert np.array_equal(a != 0, b != 0)                                # identical inclusion pattern
