@@ -251,14 +251,16 @@ def main():
     avg_ms, launches, cols = ctx.time_matvec(reps=3)
     alg_bytes = float(n) * cols  # one read of the launch's int8 genotypes (SURVEY.md §8 d: n*m per sweep)
     ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-    traffic = None  # HBM bytes per launch from the PMC pass kept under profiles/ (same n, panel and launch width only)
+    # HBM bytes per launch: from the separate rocprofv3 --pmc FETCH_SIZE pass kept under profiles/ (counters cannot be read
+    # from inside this process); reported only when this run has the same n, panel and launch width as that pass
+    traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_k_dot.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_k_dotq.json" if args.precise == 2 else "r01_pmc_k_dot.json")))
         if pm["n"] == n and pm["panel"] * pm["panels_per_launch"] == cols:
             traffic = pm["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
-    roof = {"bound": "hbm", "kernel": "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": "k_dotq" if args.precise == 2 else "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": alg_bytes,
             "avg_launch_ms": avg_ms, "launches_per_sweep": launches, "columns_per_launch": cols}
     note("mat-vec timing pass done")

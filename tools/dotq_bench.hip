@@ -23,7 +23,16 @@ __device__ __forceinline__ void dma16(unsigned voff, const int8_t *sbase, unsign
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+                 : "memory");
+}
+
+__device__ __forceinline__ void dma16nt(unsigned voff, const int8_t *sbase, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
                  : "memory");
 }
 
@@ -120,35 +129,38 @@ __global__ __launch_bounds__(64) void k_dotq(const int8_t *__restrict__ X, long 
 
 // ---- variant C: X tile AND the stage's digit planes arrive by LDS-DMA; digits are read back with wave-uniform
 // (broadcast) ds_read_b128, the X column of each lane with a per-lane ds_read_b128. Nothing but DMA in the vmcnt queue. ----
-template <int RSX, int NBUF>
+template <int RSX, int NBUF, int CPL, int PAD>
 __global__ __launch_bounds__(64) void k_dotq_l(const int8_t *__restrict__ X, long ld, const int8_t *__restrict__ dig, int nstages,
                                                int NS, long long *__restrict__ acc64, long accstride)
 {
     constexpr int LPC = RSX / 16;          // lanes per column in one DMA instruction
     constexpr int CPI = 64 / LPC;          // columns (or digit planes) per DMA instruction
-    constexpr int NX = 64 / CPI;           // DMA instructions for the 64-column X tile
+    constexpr int NX = 64 * CPL / CPI;     // DMA instructions for the X tile (64 * CPL columns)
     constexpr int NDG = (ND + CPI - 1) / CPI; // DMA instructions for the digit planes
-    constexpr int XB = NX * SLOT, BUF = XB + NDG * 1024, PER = NX + NDG, STEPS = RSX / 16;
+    constexpr int SL = 1024 + PAD;
+    constexpr int XB = NX * SL, BUF = XB + NDG * 1024, PER = NX + NDG, STEPS = RSX / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int cg = blockIdx.x;
     const int st0 = blockIdx.y * NS, st1 = min(nstages, st0 + NS);
     if (st0 >= st1) return;
-    const int8_t *xg = X + (long)cg * 64 * ld;
+    const int8_t *xg = X + (long)cg * 64 * CPL * ld;
     const unsigned voff = (unsigned)((lane / LPC) * ld + (lane % LPC) * 16);
     unsigned doff[NDG];
 #pragma unroll
     for (int i = 0; i < NDG; i++) doff[i] = (unsigned)(min(i * CPI + lane / LPC, ND - 1) * ld + (lane % LPC) * 16);
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
-    int acc[ND];
+    int acc[CPL][ND];
 #pragma unroll
-    for (int k = 0; k < ND; k++) acc[k] = 0;
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (int k = 0; k < ND; k++) acc[c][k] = 0;
 
     auto issue = [&](int st, int b) {
         const int8_t *base = xg + (long)st * RSX;
         const unsigned dst = lds0 + (unsigned)b * BUF;
 #pragma unroll
-        for (int i = 0; i < NX; i++) dma16(voff, base + (long)(CPI * i) * ld, dst + i * SLOT);
+        for (int i = 0; i < NX; i++) dma16nt(voff, base + (long)(CPI * i) * ld, dst + i * SL);
 #pragma unroll
         for (int i = 0; i < NDG; i++) dma16(doff[i], dig + (long)st * RSX, dst + XB + i * 1024);
     };
@@ -165,25 +177,35 @@ __global__ __launch_bounds__(64) void k_dotq_l(const int8_t *__restrict__ X, lon
         else if (later == 2) wait_vm<2 * PER>();
         else wait_vm<3 * PER>();
         const char *bp = smem + b * BUF;
-        const v4i *px = reinterpret_cast<const v4i *>(bp + (lane / CPI) * SLOT + (lane % CPI) * RSX);
         const char *pd = bp + XB;
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
-            const v4i x = px[s];
+            v4i x[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; c++) { // lane's c-th column = 64 c + lane
+                const int col = 64 * c + lane;
+                x[c] = *reinterpret_cast<const v4i *>(bp + (col / CPI) * SL + (col % CPI) * RSX + s * 16);
+            }
 #pragma unroll
             for (int k = 0; k < ND; k++) {
                 const v4i d = *reinterpret_cast<const v4i *>(pd + (k / CPI) * 1024 + (k % CPI) * RSX + s * 16);
-                acc[k] = __builtin_amdgcn_sdot4(x.x, d.x, acc[k], false);
-                acc[k] = __builtin_amdgcn_sdot4(x.y, d.y, acc[k], false);
-                acc[k] = __builtin_amdgcn_sdot4(x.z, d.z, acc[k], false);
-                acc[k] = __builtin_amdgcn_sdot4(x.w, d.w, acc[k], false);
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    acc[c][k] = __builtin_amdgcn_sdot4(x[c].x, d.x, acc[c][k], false);
+                    acc[c][k] = __builtin_amdgcn_sdot4(x[c].y, d.y, acc[c][k], false);
+                    acc[c][k] = __builtin_amdgcn_sdot4(x[c].z, d.z, acc[c][k], false);
+                    acc[c][k] = __builtin_amdgcn_sdot4(x[c].w, d.w, acc[c][k], false);
+                }
             }
         }
         b = (b + 1 == NBUF) ? 0 : b + 1;
     }
 #pragma unroll
-    for (int k = 0; k < ND; k++)
-        __hip_atomic_fetch_add(acc64 + (long)k * accstride + cg * 64 + lane, (long long)acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int c = 0; c < CPL; c++)
+#pragma unroll
+        for (int k = 0; k < ND; k++)
+            __hip_atomic_fetch_add(acc64 + (long)k * accstride + cg * 64 * CPL + 64 * c + lane, (long long)acc[c][k], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void k_fill(int8_t *X, size_t nbytes, unsigned seed, int lim)
@@ -241,14 +263,16 @@ int main(int argc, char **argv)
     CHECK(hipDeviceSynchronize());
     const int nsplit = (nstages + NS - 1) / NS;
     typedef void (*kfn)(const int8_t *, long, const int8_t *, int, int, long long *, long);
-    kfn kern = k_dotq<2>;
-    size_t lds = 2 * STAGE;
-    if (rsx == 256 && nbuf == 2) { kern = k_dotq_l<256, 2>; lds = 2 * (16 * SLOT + 2048); }
-    if (rsx == 256 && nbuf == 3) { kern = k_dotq_l<256, 3>; lds = 3 * (16 * SLOT + 2048); }
-    if (rsx == 128 && nbuf == 2) { kern = k_dotq_l<128, 2>; lds = 2 * (8 * SLOT + 1024); }
-    if (rsx == 128 && nbuf == 3) { kern = k_dotq_l<128, 3>; lds = 3 * (8 * SLOT + 1024); }
-    if (rsx == 128 && nbuf == 4) { kern = k_dotq_l<128, 4>; lds = 4 * (8 * SLOT + 1024); }
-    if (nbuf == 9) { kern = k_dotq<2>; lds = 2 * STAGE; }
+    const int cplane = argc > 7 ? atoi(argv[7]) : 1;
+    const int pad = argc > 8 ? atoi(argv[8]) : 16;
+    kfn kern = nullptr;
+    size_t lds = 0;
+#define SEL(R, B, C, P) if (rsx == R && nbuf == B && cplane == C && pad == P) { kern = k_dotq_l<R, B, C, P>; \
+        lds = (size_t)B * ((64 * C / (1024 / R)) * (1024 + P) + ((ND + 1024 / R - 1) / (1024 / R)) * 1024); }
+    SEL(128, 2, 1, 16) SEL(128, 3, 1, 16) SEL(128, 2, 2, 16) SEL(128, 2, 1, 0) SEL(128, 2, 1, 32) SEL(128, 2, 1, 64)
+    SEL(256, 2, 1, 16) SEL(128, 2, 2, 32) SEL(128, 3, 2, 16) SEL(64, 2, 2, 16) SEL(64, 3, 2, 16) SEL(64, 4, 1, 16) SEL(64, 2, 1, 16)
+    if (!kern) { printf("no such variant\n"); return 2; }
+    const int colsper = 64 * cplane;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nlaunch = m_pad / cpl;
     hipEvent_t e0, e1;
@@ -258,14 +282,14 @@ int main(int argc, char **argv)
         CHECK(hipMemset(acc, 0, sizeof(long long) * ND * (size_t)m_pad));
         CHECK(hipEventRecord(e0, 0));
         for (int g = 0; g < nlaunch; g++)
-            hipLaunchKernelGGL(kern, dim3(cpl / 64, nsplit), dim3(64), lds, 0, X + (size_t)g * cpl * ld, ld, dig, nstages, NS,
+            hipLaunchKernelGGL(kern, dim3(cpl / colsper, nsplit), dim3(64), lds, 0, X + (size_t)g * cpl * ld, ld, dig, nstages, NS,
                                acc + (size_t)g * cpl, (long)m_pad);
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipDeviceSynchronize());
         float ms;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
-        printf("rep %d: %d launches of %d cols (grid %d x %d, NS=%d, nbuf=%d, RS=%d): %.2f us/launch, %.3f TB/s (n*cols bytes)\n", rep, nlaunch,
-               cpl, cpl / 64, nsplit, NS, nbuf, rsx, ms * 1e3 / nlaunch, (double)n * m_pad / (ms * 1e-3) / 1e12);
+        printf("rep %d: %d launches of %d cols (grid %d x %d, NS=%d, nbuf=%d, RS=%d, cols/lane=%d, pad=%d): %.2f us/launch, %.3f TB/s (n*cols bytes)\n", rep, nlaunch,
+               cpl, cpl / colsper, nsplit, NS, nbuf, rsx, cplane, pad, ms * 1e3 / nlaunch, (double)n * m_pad / (ms * 1e-3) / 1e12);
     }
     // check: first 256 and last 256 columns
     std::vector<long long> hacc((size_t)ND * m_pad), href((size_t)ND * 512);

@@ -16,8 +16,10 @@ tot = sum(r[5] for r in rows)
 print("%-86s %8s %12s %10s %12s %10s %6s" % ("kernel", "calls", "avg_ns", "min_ns", "max_ns", "total_ms", "%"))
 for r in rows:
     nm = r[0]
-    if "k_dot" in nm:
+    if "k_dot<" in nm:
         nm = "k_dot" + nm[nm.index("<"):nm.index(">") + 1] + nm[nm.rindex(" grid="):]
+    elif "k_dotq" in nm:
+        nm = nm[:nm.index("(")] + nm[nm.rindex(" grid="):]
     print("%-86s %8d %12.1f %10d %12d %10.2f %6.2f" % (nm[:86], r[1], r[2], r[3], r[4], r[5] / 1e6, 100.0 * r[5] / tot))
 try:
     cols = [d[1] for d in cur.execute("pragma table_info(pmc_events)")]
