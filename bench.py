@@ -44,6 +44,13 @@ def parse():
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--m", type=int, default=int(os.environ.get("HB_BENCH_M", "500000")),
                     help="markers per GPU (under torch.distributed.run pass it as HB_BENCH_M: the launcher claims --m)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --m markers per GPU (m_global = N * m); strong: --m-global markers over all GPUs "
+                         "(BASELINE.json configs[3]: 2 000 000 over 8)")
+    ap.add_argument("--m-global", type=int, default=int(os.environ.get("HB_BENCH_M_GLOBAL", "2000000")))
+    ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
+                    help="per-sweep residual all-reduce: rccl = ncclAllReduce enqueued by the library itself on the sweep stream "
+                         "(hb_comm_*); torch = torch.distributed callback (host-synchronous; also the fall-back)")
     ap.add_argument("--model", default="BayesCpi", help="BASELINE.json north_star target: BayesCpi at n=50k, m=500k")
     ap.add_argument("--secondary", default="BayesR", help="second model measured on the same genotypes ('' = none)")
     ap.add_argument("--panel", type=int, default=0)
@@ -164,9 +171,12 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
     keep = []
     if comm is not None:
         a.rank, a.world, a.m_global, a.m_offset = rank, world, m_global, m_offset
-        cb, ptr = comm.make_callback(L.hb_exchange_count(n))
-        a.allreduce, a.exchange_buf = cb, ptr
-        keep.append(cb)
+        if getattr(comm, "rccl", None) is not None:
+            a.comm = comm.rccl.handle
+        else:
+            cb, ptr = comm.make_callback(L.hb_exchange_count(n))
+            a.allreduce, a.exchange_buf = cb, ptr
+            keep.append(cb)
     run = ct.c_void_p()
     check(L.hb_run_create(ct.byref(a), ct.byref(run)))
     fin = ct.c_int32()
@@ -219,13 +229,29 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.backend)
-        from hibayes_amd.dist import TorchComm
+        from hibayes_amd.dist import TorchComm, RcclComm
         comm = TorchComm(device=torch.device("cuda", local_rank))
+        comm.rccl, comm.rccl_note = None, "torch.distributed all_reduce through the library's callback"
+        if args.collective == "rccl" and args.backend == "nccl":
+            try:   # the library's own communicator; torch.distributed only ships rank 0's RCCL id
+                comm.rccl = RcclComm.from_torch(local_rank)
+                comm.rccl_note = "ncclAllReduce inside libhibayes_gpu on the sweep stream, %d ranks" % comm.rccl.L.hb_comm_world(comm.rccl.handle)
+            except Exception as e:
+                comm.rccl_note += " (in-library RCCL unavailable: %r)" % (e,)
+            ok = comm.max_int(0 if comm.rccl is not None else 1)   # all ranks or none
+            if ok != 0 and comm.rccl is not None:
+                comm.rccl.close()
+                comm.rccl = None
     import hibayes_amd as H
     L = H.lib()
 
     n, m = args.n, args.m
     m_global, m_offset = m * world, m * rank
+    if args.scaling == "strong" and world > 1:
+        from hibayes_amd.dist import shard_range
+        m_global = args.m_global
+        m_offset, hi = shard_range(m_global, rank, world)
+        m = args.m = hi - m_offset
 
     def note(msg):
         if rank == 0:
@@ -265,22 +291,25 @@ def main():
             "avg_launch_ms": avg_ms, "launches_per_sweep": launches, "columns_per_launch": cols}
     note("mat-vec timing pass done")
 
-    value = world * K / elapsed
+    # one unit = one pass over m_ref markers (the metric's m = 500k); all ranks together pass over m_global markers per step
+    m_ref = float(os.environ.get("HB_BENCH_M", "500000")) if args.scaling == "weak" else 500000.0
+    value = (K / elapsed) * (m_global / (float(m) if args.scaling == "weak" else m_ref))
     Pi, fold = prior(args.model)
     res = {
         "metric": "Gibbs sweeps/sec (full m-marker pass) + achieved HBM GB/s, n=50k m=500k",
         "value": value, "unit": "sweeps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
         "vs_baseline": None, "dtype": DTYPE[args.precise], "data": "synthetic",
         "config": {"workload": "%s marker sweep, n=%d individuals x m=%d int8 markers per GPU (m_global=%d), "
                                "panel=%d, pipeline=%s" % (args.model, n, m, m_global, ctx.panel, (geo,)),
                    "model": args.model, "n": n, "m_per_gpu": m, "m_global": m_global, "panel": ctx.panel,
                    "pipeline": {"persistent_chain": geo[0], "lookahead_groups": geo[1], "panels_per_matvec": geo[2]},
                    "sharding": "markers, contiguous ranges, one residual all-reduce per sweep" if world > 1 else "none",
+                   "collective": comm.rccl_note if comm is not None else "none",
                    "mcmc_burn_in_sweeps_before_warmup": args.burnin,
                    "mean_changed_markers_per_sweep": mean_events, "row_cache_misses_per_sweep": misses, "NumNZSnp_last": nnz,
                    "setup_seconds": {"generate": gen_s, "gram": gram_s}},
-        "achieved_GBps": value * n * m / 1e9, "achieved_frac_of_hbm_peak": value * n * m / 1e9 / (HBM_PEAK_GBPS * world),
+        "achieved_GBps": (K / elapsed) * n * m_global / 1e9, "achieved_frac_of_hbm_peak": (K / elapsed) * n * m_global / 1e9 / (HBM_PEAK_GBPS * world),
         "roofline": roof,
     }
     if args.secondary and args.secondary != args.model and world == 1:

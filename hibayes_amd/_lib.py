@@ -56,6 +56,7 @@ class BayesArgs(C.Structure):
         ("log", LOG_FN), ("log_user", C.c_void_p),
         ("ctx", C.c_void_p),
         ("g_init", C.c_void_p),
+        ("comm", C.c_void_p),
     ]
 
 
@@ -128,7 +129,8 @@ SYMBOLS = [
     "hb_ctx_residual_shift", "hb_ctx_set_covariates", "hb_ctx_cov_dot", "hb_ctx_cov_axpy", "hb_ctx_set_levels",
     "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_sweep", "hb_ctx_get_counters", "hb_ctx_set_windows",
     "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec",
-    "hb_ctx_download_gram_band", "hb_ctx_get_pipeline", "hb_ctx_get_events",
+    "hb_ctx_download_gram_band", "hb_ctx_get_pipeline", "hb_ctx_get_events", "hb_ctx_pipeline_note", "hb_ctx_matmul",
+    "hb_comm_unique_id", "hb_comm_init", "hb_comm_world", "hb_comm_rank", "hb_comm_destroy",
     "hb_run_create", "hb_run_step", "hb_run_state", "hb_run_ctx", "hb_run_finish", "hb_run_destroy",
 ]
 
@@ -166,6 +168,15 @@ def lib():
     L.hb_ctx_download_gram_band.argtypes = [vp, i32, i32, vp]
     L.hb_ctx_get_pipeline.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.hb_ctx_get_events.argtypes = [vp, vp, vp, vp]
+    L.hb_ctx_matmul.argtypes = [vp, vp, i64, i32, vp, i64]
+    L.hb_comm_unique_id.argtypes = [vp]
+    L.hb_comm_init.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
+    L.hb_comm_world.argtypes = [vp]
+    L.hb_comm_rank.argtypes = [vp]
+    L.hb_comm_destroy.argtypes = [vp]
+    L.hb_comm_destroy.restype = None
+    L.hb_ctx_pipeline_note.argtypes = [vp]
+    L.hb_ctx_pipeline_note.restype = C.c_char_p
     L.hb_ctx_set_residual.argtypes = [vp, vp, vp]
     L.hb_ctx_get_residual.argtypes = [vp, vp, vp]
     L.hb_ctx_set_effects.argtypes = [vp, vp, vp, vp]

@@ -116,14 +116,19 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
     a.seed, a.device, a.panel, a.precise = int(seed), int(device), int(panel), int(precise)
     nrec = max((int(niter) - int(nburn)) // max(int(thin), 1), 0)
     a.store_alpha = int(bool(store_alpha))
-    if comm is not None and comm.world > 1:
+    if comm is not None and (comm.world > 1 or hasattr(comm, "handle")):
+        if comm.world > 1 and m_global is None:
+            raise HibayesError(1, "a sharded run needs m_global (markers over all ranks) and m_offset (first global marker of this shard)")
         a.rank, a.world = comm.rank, comm.world
         a.m_global = int(m_global if m_global is not None else m)
         a.m_offset = int(m_offset)
-        cb, xbuf_ptr = comm.make_callback(L.hb_exchange_count(n))
-        a.allreduce = cb
-        a.exchange_buf = xbuf_ptr
-        keep.append(cb)
+        if hasattr(comm, "handle"):      # RcclComm: the collective runs inside the library
+            a.comm = comm.handle
+        else:                            # TorchComm: the library calls back for every exchange
+            cb, xbuf_ptr = comm.make_callback(L.hb_exchange_count(n))
+            a.allreduce = cb
+            a.exchange_buf = xbuf_ptr
+            keep.append(cb)
         if nw:
             nw = comm.max_int(nw)
     if g_init is not None:
@@ -254,15 +259,70 @@ def _model_matrix(cols, names, rows):
     return np.asfortranarray(Xm[:, keepc]), [labels[j] for j in keepc]
 
 
+def _map_columns(map):
+    """Chromosome and position of the `map` argument of ibrm(), validated as R/bayes.r:217-246 does: columns 2 and 3 of a
+    table (SNP, chr, pos), or the dict read_plink() returns (keys Chr/Pos or chr/pos). Non-numeric chromosome labels
+    (X, Y, MT ...) are numbered after the largest numeric one, in order of appearance."""
+    if map is None:
+        raise ValueError("map information must be provided.")
+    if isinstance(map, dict):
+        ck = next((k for k in ("Chr", "chr", "CHROM", "chrom") if k in map), None)
+        pk = next((k for k in ("Pos_text", "Pos", "pos", "POS") if k in map), None)
+        if ck is None or pk is None:
+            raise ValueError("At least 3 columns in map.")
+        chr_raw, pos_raw = list(map[ck]), list(map[pk])
+    else:
+        arr = np.asarray(map, dtype=object)
+        if arr.ndim != 2 or arr.shape[1] < 3:
+            raise ValueError("At least 3 columns in map.")
+        chr_raw, pos_raw = list(arr[:, 1]), list(arr[:, 2])
+
+    def isna(v):
+        return v is None or (isinstance(v, float) and np.isnan(v)) or (isinstance(v, str) and v in ("NA", ""))
+
+    def tonum(v):
+        try:
+            return float(v)
+        except (TypeError, ValueError):
+            return None
+
+    if any(isna(v) for v in chr_raw):
+        raise ValueError("NAs are not allowed in chromosome.")
+    if any(tonum(v) == 0 for v in chr_raw):
+        raise ValueError("0 is not allowed in chromosome.")
+    if any(isna(v) for v in pos_raw):
+        raise ValueError("NAs are not allowed in physical position.")
+    if any(tonum(v) == 0 for v in pos_raw):
+        raise ValueError("0 is not allowed in physical position.")
+    pos = [tonum(v) for v in pos_raw]
+    if any(v is None for v in pos):
+        raise ValueError("Characters are not allowed in physical position.")
+    cnum = [tonum(v) for v in chr_raw]
+    known = [v for v in cnum if v is not None]
+    max_chr = max(known) if known else 0
+    extra = {}
+    for v, c in zip(chr_raw, cnum):   # :237-243: labels outside 0..max.chr get max.chr + 1, + 2, ... by first appearance
+        if c is None or c != int(c) or c < 0:
+            if str(v) not in extra:
+                extra[str(v)] = max_chr + len(extra) + 1
+    chrom = np.array([extra[str(v)] if str(v) in extra else c for v, c in zip(chr_raw, cnum)], dtype=np.float64)
+    return chrom, np.array(pos, dtype=np.float64)
+
+
 def ibrm(formula, data=None, M=None, M_id=None, method="BayesCpi", map=None, Pi=None, fold=None,
          niter=None, nburn=None, thin=5, windsize=None, windnum=None, dfvr=None, s2vr=None, vg=None,
          dfvg=None, s2vg=None, ve=None, dfve=None, s2ve=None, printfreq=100, seed=666666,
          threads=4, verbose=True, *, windindx=None, device=0, panel=0, precise=2,
-         store_alpha=True, comm=None):
+         store_alpha=True, comm=None, m_global=None, m_offset=0, gebv_samples=None):
     """Mirror of ibrm() (reference R/bayes.r:121-320). `formula` is a string such as
     "T1 ~ 1" or "T1 ~ season + bwt + (1 | loc) + (1 | dam)"; `data` a dict of columns or a
     pandas DataFrame whose first column holds the individual ids; `M` the n_all x m genotype
-    matrix (int8 preferred) with row ids `M_id`."""
+    matrix (int8 preferred) with row ids `M_id`.
+    Sharded runs (`comm` with world > 1): M holds this rank's contiguous marker range [m_offset, m_offset + M.shape[1]) of
+    m_global markers (hibayes_amd.dist.shard_range); `map` / `windindx` likewise cover the local markers only, and the GEBV
+    partial products of the shards are summed over the ranks.
+    `gebv_samples` (default: store_alpha): also return MCMCsamples["g"] = M %*% MCMCsamples$alpha (n_all x n_records,
+    R/bayes.r:303-305), computed on the device."""
     if data is None:
         raise ValueError("no data assigned.")
     if M is None:
@@ -332,28 +392,44 @@ def ibrm(formula, data=None, M=None, M_id=None, method="BayesCpi", map=None, Pi=
     if (windsize is not None or windnum is not None) and windindx is None:
         if method in ("BayesA", "BayesRR", "BayesL"):
             raise ValueError("can not implement GWAS analysis for the method: " + method)
-        if map is None:
-            raise ValueError("map information must be provided.")
+        chrom, bp = _map_columns(map)          # R/bayes.r:216-246
         from .windows import cutwind_by_bp, cutwind_by_num
-        chrom = np.asarray(map["chr"] if isinstance(map, dict) else map[:, 1])
-        bp = np.asarray(map["pos"] if isinstance(map, dict) else map[:, 2], dtype=np.float64)
-        windindx = cutwind_by_num(chrom, bp, windnum) if windnum is not None else cutwind_by_bp(chrom, bp, windsize)
+        if windnum is not None:
+            if len(chrom) < windnum:
+                raise ValueError("Number of markers specified in a window is larger than the total number of markers.")
+            windindx = cutwind_by_num(chrom, bp, windnum)
+        else:
+            if bp.max() < windsize:
+                raise ValueError("Maximum of physical position is smaller than wind size.")
+            windindx = cutwind_by_bp(chrom, bp, windsize)
     y = np.array([float(cols[lhs][i]) for i in rows])
     Mfit = M[rows, :]
     res = Bayes(y=y, X=Mfit, model=method, Pi=Pi, fold=fold, C_=Xfix, R=R, niter=niter, nburn=nburn,
                 thin=thin, windindx=windindx, dfvr=dfvr, s2vr=s2vr, vg=vg, dfvg=dfvg, s2vg=s2vg, ve=ve,
                 dfve=dfve, s2ve=s2ve, outfreq=printfreq, threads=threads, verbose=verbose, seed=seed,
-                device=device, panel=panel, precise=precise, store_alpha=store_alpha, comm=comm)
+                device=device, panel=panel, precise=precise, store_alpha=store_alpha, comm=comm,
+                m_global=m_global, m_offset=m_offset)
     if "beta" in res:
         res["beta_names"] = fixed_names
     if "Vr" in res:
         res["Vr_names"] = list(rand_terms)
-    # GEBV, :303-308: rowMeans(M %*% alpha-samples) == M %*% rowMeans(alpha-samples)
-    gebv = np.zeros(nall)
-    alpha = res["alpha"]
-    nzc = np.flatnonzero(alpha)
-    if nzc.size:
-        gebv = M[:, nzc].astype(np.float64) @ alpha[nzc]
+    # GEBV, R/bayes.r:303-308: MCMCsamples$g = M %*% MCMCsamples$alpha over ALL genotyped individuals, g$gebv = its row means.
+    # On the device (hb_ctx_matmul: int8 genotypes x fp64 effects, eight records per pass over the non-zero columns).
+    if gebv_samples is None:
+        gebv_samples = bool(store_alpha)
+    from .engine import Context
+    with Context(nall, M.shape[1], device=device, panel=panel) as cg:
+        cg.upload(M)
+        if gebv_samples and "alpha" in res["MCMCsamples"]:
+            gs = cg.matmul(res["MCMCsamples"]["alpha"])
+            if comm is not None and comm.world > 1:
+                gs = comm.sum_array(gs)
+            res["MCMCsamples"]["g"] = gs
+            gebv = gs.mean(axis=1)
+        else:  # rowMeans(M %*% samples) == M %*% rowMeans(samples) up to rounding
+            gebv = cg.matmul(res["alpha"])[:, 0]
+            if comm is not None and comm.world > 1:
+                gebv = comm.sum_array(gebv)
     res["u_last"] = res["g"]
     res["g"] = {"id": list(M_id), "gebv": gebv}
     res["e"] = {"id": [M_id[i] for i in rows], "e": res["e"]}

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
 
 // launch wrappers implemented in hb_kernels.hip
 int hbk_init_attrs();
@@ -24,6 +25,8 @@ int hbk_bed_decode(hb_ctx *c, const uint8_t *dbed, int64_t bpc, int nind, const 
 int hbk_generate(hb_ctx *c, uint64_t seed, int mono_every);
 int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out);
 int hbk_time_matvec(hb_ctx *c, int D, int reps, int as_pipeline, double *avg_us, int *launches);
+int hbk_probe_concurrency(hb_ctx *c, int *concurrent);
+int hbk_xmat(hb_ctx *c, const int *didx, const double *dval, int nnz, double *dout);
 
 static thread_local std::string g_err;
 
@@ -45,6 +48,7 @@ static int dev_alloc(T **p, size_t count, bool zero = true)
 // normalise (pipeline, Lv, D) and derive the Gram band / version ring sizes
 static void hb_pipeline_geometry(hb_ctx *c)
 {
+    if (!c->concurrent) c->pipeline = 0; // the persistent pipeline needs co-resident kernels (hbk_probe_concurrency)
     c->Lv = std::max(0, std::min(6, c->Lv));
     c->D = c->pipeline ? std::max(1, std::min(8, c->D)) : 1;
     // Lv counts mat-vec GROUPS of look-ahead; the Gram band then spans (Lv + 1) * D - 1 earlier panels
@@ -71,7 +75,7 @@ int hb_device_count(void)
     return n;
 }
 
-size_t hb_exchange_count(int32_t n) { return (size_t)2 * (size_t)n + 16; }
+size_t hb_exchange_count(int32_t n) { return (size_t)n + 16; }
 
 static int auto_panel(int m)
 {
@@ -200,6 +204,29 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
 #undef TRY
     // the allocation memsets ran on the null stream, which the context's non-blocking streams do not wait for
     HB_HIP(hipDeviceSynchronize());
+    {   // can the persistent pipeline run here at all?
+        const char *why = nullptr;
+        if (getenv("AMD_SERIALIZE_KERNEL") && atoi(getenv("AMD_SERIALIZE_KERNEL")) != 0) why = "AMD_SERIALIZE_KERNEL is set";
+        else if (getenv("HIP_LAUNCH_BLOCKING") && atoi(getenv("HIP_LAUNCH_BLOCKING")) != 0) why = "HIP_LAUNCH_BLOCKING is set";
+        else if (getenv("HB_FORCE_SERIAL") && atoi(getenv("HB_FORCE_SERIAL")) != 0) why = "HB_FORCE_SERIAL is set";
+        else {
+            int conc = 1;
+            const int prc = hbk_probe_concurrency(c, &conc);
+            if (prc) {
+                hb_ctx_destroy(c);
+                return prc;
+            }
+            if (!conc) why = "kernels on two streams do not run concurrently here (serialising profiler or shared GPU)";
+        }
+        if (why) {
+            c->concurrent = false;
+            c->pipeline_note = why;
+            if (!c->env_pinned || c->pipeline) c->Lv = std::min(c->Lv, 2);
+            hb_pipeline_geometry(c);
+            fprintf(stderr, "hibayes_gpu: %s: the sweep uses the event-ordered per-panel kernels instead of the persistent "
+                            "pipeline (same chain, slower)\n", why);
+        }
+    }
     *out = c;
     return HB_OK;
 }
@@ -380,7 +407,7 @@ int hb_ctx_set_pipeline(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t 
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_set_pipeline");
     if (rc) return rc;
-    if (c->env_pinned) return HB_OK; // HB_PIPELINE / HB_LOOKAHEAD / HB_DOTGROUP in the environment win (tuning runs)
+    if (c->env_pinned && c->concurrent) return HB_OK; // HB_PIPELINE / HB_LOOKAHEAD / HB_DOTGROUP in the environment win (tuning runs)
     const int op = c->pipeline, ol = c->Lv, od = c->D;
     c->pipeline = pipeline ? 1 : 0;
     c->Lv = lookahead;
@@ -443,6 +470,8 @@ int hb_ctx_download_gram_band(hb_ctx *c, int32_t panel_index, int32_t l, int32_t
                      hipMemcpyDeviceToHost));
     return HB_OK;
 }
+
+const char *hb_ctx_pipeline_note(const hb_ctx *c) { return (c && !c->concurrent) ? c->pipeline_note.c_str() : nullptr; }
 
 int hb_ctx_get_pipeline(const hb_ctx *c, int32_t *pipeline, int32_t *lookahead, int32_t *dotgroup, int32_t *band)
 {
@@ -544,6 +573,54 @@ int hb_ctx_matvec(hb_ctx *c, const double *alpha, double *out)
     (void)hipFree(dout);
     if (rc) return rc;
     if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("hb_ctx_matvec: ") + hipGetErrorString(e));
+    return HB_OK;
+}
+
+// out (n x R) = X (n x m) * A (m x R): the GEBV sample matrix MCMCsamples$g = M %*% MCMCsamples$alpha of reference
+// R/bayes.r:303-305, eight records per pass over the columns that carry a non-zero effect in any of them
+int hb_ctx_matmul(hb_ctx *c, const double *A, int64_t ldA, int32_t R, double *out, int64_t ldo)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_matmul");
+    if (rc) return rc;
+    if (!A || !out || R < 0 || ldA < c->m || ldo < c->n) return hb_fail(HB_ERR_INVALID, "hb_ctx_matmul: bad argument");
+    if (R == 0) return HB_OK;
+    const int RB = 8;
+    int *didx = nullptr;
+    double *dval = nullptr, *dout = nullptr;
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&didx), sizeof(int) * (size_t)c->m));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dval), sizeof(double) * (size_t)c->m * RB);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dout), sizeof(double) * (size_t)c->ld * RB);
+    std::vector<int> idx;
+    std::vector<double> val, ho((size_t)c->ld * RB);
+    for (int r0 = 0; r0 < R && e == hipSuccess && rc == HB_OK; r0 += RB) {
+        const int nr = std::min(RB, R - r0);
+        idx.clear();
+        val.clear();
+        for (int j = 0; j < c->m; j++) {
+            bool any = false;
+            for (int r = 0; r < nr; r++) any |= A[(size_t)(r0 + r) * ldA + j] != 0.0;
+            if (!any) continue;
+            idx.push_back(j);
+            for (int r = 0; r < RB; r++) val.push_back(r < nr ? A[(size_t)(r0 + r) * ldA + j] : 0.0);
+        }
+        const int nnz = (int)idx.size();
+        if (nnz) {
+            e = hipMemcpyAsync(didx, idx.data(), sizeof(int) * nnz, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(dval, val.data(), sizeof(double) * (size_t)nnz * RB, hipMemcpyHostToDevice, c->stream);
+        }
+        if (e != hipSuccess) break;
+        rc = hbk_xmat(c, didx, dval, nnz, dout);
+        if (rc) break;
+        e = hipMemcpyAsync(ho.data(), dout, sizeof(double) * (size_t)c->ld * RB, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) break;
+        for (int r = 0; r < nr; r++) std::memcpy(out + (size_t)(r0 + r) * ldo, ho.data() + (size_t)r * c->ld, sizeof(double) * c->n);
+    }
+    (void)hipFree(didx);
+    if (dval) (void)hipFree(dval);
+    if (dout) (void)hipFree(dout);
+    if (rc) return rc;
+    if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("hb_ctx_matmul: ") + hipGetErrorString(e));
     return HB_OK;
 }
 
@@ -661,11 +738,13 @@ int hb_ctx_level_axpy(hb_ctx *c, int32_t term, const double *delta)
     return hbk_level_axpy(c, term, c->lev_buf);
 }
 
-int hb_ctx_sweep(hb_ctx *c, const hb_sweep_in *in, hb_sweep_out *out)
+// one sweep in two halves, so that a caller can enqueue more work on the stream (the multi-GPU exchange) before the single
+// host synchronisation of the iteration
+int hb_ctx_sweep_begin(hb_ctx *c, const hb_sweep_in *in)
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_sweep");
     if (rc) return rc;
-    if (!in || !out) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep: null argument");
+    if (!in) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep: null argument");
     if (in->model_index < 1 || in->model_index > 6) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep: bad model_index");
     if (in->n_fold < 2 || in->n_fold > HB_MAX_FOLD) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep: bad n_fold");
     if (in->model_index == 6)
@@ -686,7 +765,13 @@ int hb_ctx_sweep(hb_ctx *c, const hb_sweep_in *in, hb_sweep_out *out)
         rc = hbk_windows(c);
         if (rc) return rc;
     }
-    rc = fetch_acc(c);
+    return HB_OK;
+}
+
+int hb_ctx_sweep_end(hb_ctx *c, hb_sweep_out *out)
+{
+    if (!out) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep: null argument");
+    int rc = fetch_acc(c);
     if (rc) return rc;
     const double *a = c->h_acc;
     out->sum_g2 = a[HB_ACC_SUMG2];
@@ -699,6 +784,14 @@ int hb_ctx_sweep(hb_ctx *c, const hb_sweep_in *in, hb_sweep_out *out)
     out->n_cache_miss = a[HB_ACC_MISS];
     out->n_redo = a[HB_ACC_REDO];
     return HB_OK;
+}
+
+int hb_ctx_sweep(hb_ctx *c, const hb_sweep_in *in, hb_sweep_out *out)
+{
+    if (!in || !out) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep: null argument");
+    int rc = hb_ctx_sweep_begin(c, in);
+    if (rc) return rc;
+    return hb_ctx_sweep_end(c, out);
 }
 
 int hb_ctx_get_counters(hb_ctx *c, double *nzrate, double *alpha_sum, double *alpha_sq)

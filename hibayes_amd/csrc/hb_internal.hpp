@@ -41,6 +41,8 @@ struct hb_ctx {
     int D = 1;     // panels per mat-vec launch
     int NB = 1;    // residual versions kept = Lv + D
     int pipeline = 0;              // 0: serial kernels per panel; 1: persistent chain workgroup + flags
+    bool concurrent = true;        // kernels on two streams were seen running at the same time (probe at create)
+    std::string pipeline_note;     // why the persistent pipeline is off, when it is
     unsigned int *flags = nullptr; // [0] chain_done (panels whose moves are published), [1] abort
     unsigned int *h_flags = nullptr;
     int *hot_slot = nullptr, *hot_list = nullptr, *hot_n = nullptr; // per-sweep hot-lists (k_hotlist)
@@ -117,4 +119,7 @@ struct hb_ctx {
 };
 
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed);
+extern "C" int hb_ctx_sweep_begin(hb_ctx *c, const hb_sweep_in *in);
+extern "C" int hb_ctx_sweep_end(hb_ctx *c, hb_sweep_out *out);
+int hb_comm_allreduce_f64(hb_comm *c, double *buf, size_t count, hipStream_t st);
 int hb_build_gram_impl(hb_ctx *c);

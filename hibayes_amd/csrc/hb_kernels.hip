@@ -1792,8 +1792,7 @@ __global__ void k_delta_pack(const double *__restrict__ r, const double *__restr
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    buf[i] = r[i] - r0[i];
-    buf[n + i] = u[i] - u0[i];
+    buf[i] = r[i] - r0[i]; // (u moved by exactly the negative: u = X g, yadj = y - ... - X g)
 }
 
 __global__ void k_delta_unpack(double *__restrict__ r, double *__restrict__ u, float *__restrict__ r32,
@@ -1805,7 +1804,7 @@ __global__ void k_delta_unpack(double *__restrict__ r, double *__restrict__ u, f
     const double a = r0[i] + buf[i];
     r[i] = a;
     r32[i] = (float)a;
-    u[i] = u0[i] + buf[n + i];
+    u[i] = u0[i] - buf[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1881,6 +1880,51 @@ __global__ __launch_bounds__(256) void k_xalpha(const int8_t *__restrict__ X, in
     if (a1 != 0.0) atomicAdd(out + row0 + 1, a1);
     if (a2 != 0.0) atomicAdd(out + row0 + 2, a2);
     if (a3 != 0.0) atomicAdd(out + row0 + 3, a3);
+}
+
+// out[rec][row] = sum_e x[row][idx[e]] * val[e][rec] for 8 sample records at once: MCMCsamples$g = M %*% MCMCsamples$alpha,
+// reference R/bayes.r:303-305. The host hands over only the columns where any of the 8 records is non-zero (the
+// point-mass models keep ~0.1-5 % of the markers in the model), so the work is n x nnz x 8 instead of n x m x 8.
+// thread = 4 rows x 8 records (32 fp64 accumulators, no atomics); the column index and its 8 effects are wave-uniform.
+#define HB_XM_RB 8
+__global__ __launch_bounds__(256) void k_xmat(const int8_t *__restrict__ X, int64_t ld, const int *__restrict__ idx,
+                                              const double *__restrict__ val, int nnz, double *__restrict__ out, int64_t ldo)
+{
+    const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (row0 >= ld) return;
+    double acc[4][HB_XM_RB];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int r = 0; r < HB_XM_RB; r++) acc[a][r] = 0.0;
+    for (int e0 = 0; e0 < nnz; e0 += 4) {
+        int w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = *reinterpret_cast<const int *>(X + (int64_t)idx[min(e0 + k, nnz - 1)] * ld + row0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (e0 + k < nnz) { // uniform
+                const double *v = val + (size_t)(e0 + k) * HB_XM_RB;
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const double x = (double)(int8_t)(w[k] >> (8 * a));
+#pragma unroll
+                    for (int r = 0; r < HB_XM_RB; r++) acc[a][r] = fma(x, v[r], acc[a][r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < HB_XM_RB; r++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) out[(int64_t)r * ldo + row0 + a] = acc[a][r];
+}
+
+int hbk_xmat(hb_ctx *c, const int *didx, const double *dval, int nnz, double *dout)
+{
+    hipLaunchKernelGGL(k_xmat, dim3((unsigned)((c->ld / 4 + 255) / 256)), dim3(256), 0, c->stream, c->X, c->ld, didx, dval, nnz, dout, c->ld);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
 }
 
 // synthetic genotypes, SURVEY §8(d): p_j ~ U(0.05, 0.5), x ~ Binomial(2, p_j); thread = 4 rows
@@ -2283,6 +2327,41 @@ int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
         c->graph_fold = in->n_fold;
     }
     HB_HIP(hipGraphLaunch(c->gexec, c->stream));
+    return HB_OK;
+}
+
+// ---- co-residency probe of the persistent pipeline ----
+// The pipeline's two graph branches hand-shake through memory (the chain polls dsum[], the update rows poll chain_done), so
+// it only makes progress where kernels on two streams really run at the same time. Environments that serialise kernels
+// (AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING, a counter-collecting profiler, a time-sliced GPU) would stall every sweep
+// until its 3 s timeout. The probe: two one-lane kernels on the two streams, each raises its word and waits (<= 10 ms) for the
+// other's. Both see each other only if they were co-resident.
+__global__ void k_probe(unsigned *w, int me, int other)
+{
+    st_flag(w + me, 1u);
+    const unsigned long long t0 = wall_clock64();
+    while (ld_flag(w + other) == 0u) {
+        if (wall_clock64() - t0 > 1000000ull) { // 10 ms at 100 MHz
+            st_flag(w + me, 2u);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+int hbk_probe_concurrency(hb_ctx *c, int *concurrent)
+{
+    unsigned *w = c->flags + 32;
+    HB_HIP(hipMemsetAsync(w, 0, 2 * sizeof(unsigned), c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_probe, dim3(1), dim3(1), 0, c->s_chain, w, 0, 1);
+    hipLaunchKernelGGL(k_probe, dim3(1), dim3(1), 0, c->stream, w, 1, 0);
+    HB_HIP(hipGetLastError());
+    HB_HIP(hipStreamSynchronize(c->s_chain));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    unsigned h[2] = {0, 0};
+    HB_HIP(hipMemcpy(h, w, sizeof(h), hipMemcpyDeviceToHost));
+    *concurrent = (h[0] == 1u && h[1] == 1u) ? 1 : 0;
     return HB_OK;
 }
 

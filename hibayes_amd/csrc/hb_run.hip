@@ -23,6 +23,8 @@ int hbk_delta_pack(hb_ctx *c, const double *r0, const double *u0, double *buf);
 int hbk_delta_unpack(hb_ctx *c, const double *r0, const double *u0, const double *buf);
 int hbk_reduce_ru(hb_ctx *c);
 int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out);
+extern "C" int hb_comm_world(const hb_comm *c);
+extern "C" int hb_comm_rank(const hb_comm *c);
 
 namespace {
 
@@ -63,7 +65,7 @@ struct hb_run {
     std::vector<double> y, Cmat, Pi, fold_, g_init;
     std::vector<uint32_t> wind;
     int n = 0, m = 0, model_index = 0, n_pi = 0, n_fold = 0, nc = 0, nr = 0, world = 1;
-    bool fixpi = false, always_in = false;
+    bool fixpi = false, always_in = false, sharded = false;
     int64_t m_global = 0;
     int niter = 0, nburn = 0, thin = 1, n_records = 0;
     // ---- device ----
@@ -107,14 +109,26 @@ struct hb_run {
         else { fputs(buf, stdout); fputc('\n', stdout); fflush(stdout); }
     }
 
-    int allreduce_host(double *vals, int cnt)
-    { // a few host scalars through the device exchange buffer
-        if (world == 1) return HB_OK;
-        HB_HIP(hipMemsetAsync(xbuf, 0, sizeof(double) * xcount, c->stream));
-        HB_HIP(hipMemcpyAsync(xbuf, vals, sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
+    // sum over ranks of xbuf[0 .. xcount), on the sweep stream: RCCL inside the library when a communicator was given
+    // (nothing but an enqueue), else the host language's callback (needs the stream quiesced on both sides)
+    int exchange()
+    {
+        if (a.comm) return hb_comm_allreduce_f64(a.comm, xbuf, xcount, c->stream);
         HB_HIP(hipStreamSynchronize(c->stream));
         if (a.allreduce(xbuf, xcount, a.allreduce_user)) return hb_fail(HB_ERR_COMM, "all-reduce callback failed");
-        HB_HIP(hipMemcpy(vals, xbuf, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+        return HB_OK;
+    }
+
+    int allreduce_host(double *vals, int cnt)
+    { // a few host scalars through the device exchange buffer
+        if (!sharded) return HB_OK;
+        if ((size_t)cnt > xcount) return hb_fail(HB_ERR_INVALID, "allreduce_host: too many values");
+        HB_HIP(hipMemsetAsync(xbuf, 0, sizeof(double) * xcount, c->stream));
+        HB_HIP(hipMemcpyAsync(xbuf, vals, sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
+        int rc = exchange();
+        if (rc) return rc;
+        HB_HIP(hipMemcpyAsync(vals, xbuf, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream));
         return HB_OK;
     }
 
@@ -167,9 +181,15 @@ int hb_run::setup(const hb_bayes_args *args)
         return hb_fail(HB_ERR_UNSUPPORTED, "the single-step epsilon block is not part of the GPU path");
 
     world = a.world > 1 ? a.world : 1;
-    m_global = world > 1 ? a.m_global : m;
-    if (world > 1 && (!a.allreduce || m_global < m))
-        return hb_fail(HB_ERR_INVALID, "hb_bayes_run: sharded run needs allreduce and m_global");
+    if (a.comm) {
+        world = hb_comm_world(a.comm);
+        a.rank = hb_comm_rank(a.comm);
+    }
+    sharded = world > 1 || a.comm != nullptr; // (a one-rank communicator still runs the exchange path)
+    m_global = (world > 1 || a.m_global > 0) ? a.m_global : m;
+    if (world > 1 && ((!a.allreduce && !a.comm) || m_global < m))
+        return hb_fail(HB_ERR_INVALID, "hb_bayes_run: sharded run needs a communicator (comm or allreduce) and m_global");
+    if (m_global < m) m_global = m;
 
     // ---- sizes, :119-124 ----
     vary = var_n1(y.data(), n);
@@ -265,7 +285,7 @@ int hb_run::setup(const hb_bayes_args *args)
         c = a.ctx;
         own_ctx = false;
         c->seed = a.seed;
-        if (world > 1) c->m_offset = a.m_offset; // (a single-process run keeps the context's own marker addressing)
+        if (sharded) c->m_offset = a.m_offset; // (a single-process run keeps the context's own marker addressing)
         c->precise = a.precise;
         c->graph_model = -1;
     } else {
@@ -276,7 +296,7 @@ int hb_run::setup(const hb_bayes_args *args)
         cp.panel = a.panel;
         if (!cp.panel && always_in) cp.panel = m >= 128 ? 128 : 64; // every marker moves: keep all Gram rows LDS-resident
         cp.precise = a.precise;
-        cp.m_offset = world > 1 ? a.m_offset : 0;
+        cp.m_offset = sharded ? a.m_offset : 0;
         cp.seed = a.seed;
         rc = hb_ctx_create(&cp, &c);
         if (rc) return rc;
@@ -295,7 +315,7 @@ int hb_run::setup(const hb_bayes_args *args)
     HB_HIP(hipSetDevice(c->device));
 
     xcount = hb_exchange_count(n);
-    if (world > 1) {
+    if (sharded) {
         if (a.exchange_buf) xbuf = static_cast<double *>(a.exchange_buf);
         else {
             HB_HIP(hipMalloc(reinterpret_cast<void **>(&xbuf_own), sizeof(double) * xcount));
@@ -349,6 +369,7 @@ int hb_run::setup(const hb_bayes_args *args)
     if (!wind.empty()) {
         for (int i = 0; i < m; i++) nw = std::max(nw, (int)wind[i]);
         if (world > 1) { // window ids are global: every rank needs the same nw (max over ranks)
+            if ((size_t)world > xcount) return hb_fail(HB_ERR_INVALID, "too many ranks for the exchange buffer");
             std::vector<double> slots(world, 0.0);
             slots[a.rank] = nw;
             rc = allreduce_host(slots.data(), world);
@@ -384,6 +405,9 @@ int hb_run::setup(const hb_bayes_args *args)
     line("    Marker var %f", varg);
     line("    Inv-Chisq alpar %f %f", dfvara_, s2varg_);
     if (nw) line("    Number of windows for GWAS analysis %d", nw);
+    if (world > 1 && always_in)
+        line("    WARNING: %d marker shards with a model in which every marker moves every sweep (%s): shards are stale with "
+             "respect to each other inside a sweep, variance components are biased (DESIGN.md section 8)", world, model.c_str());
     line("MCMC started: ");
     line(" Iter  NumNZSnp  pi  %sVg  Ve  h2  Timeleft", model == "BayesL" ? "Lambda  " : "");
 
@@ -498,37 +522,29 @@ int hb_run::step()
     in.lambda2 = lambda2;
     in.count_pip = (iter >= nburn) && !always_in;
     in.store = (iter >= nburn) && ((iter + 1 - nburn) % thin == 0);
-    if (world > 1) {
+    if (sharded) {
         HB_HIP(hipMemcpyAsync(r0, c->r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
         HB_HIP(hipMemcpyAsync(u0, c->u, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
     }
     hb_sweep_out so{};
-    rc = hb_ctx_sweep(c, &in, &so);
+    rc = hb_ctx_sweep_begin(c, &in);
     if (rc) return rc;
-    if (world > 1) {
-        // once per sweep: sum the shards' residual deltas and scalar sums (SURVEY §8 e)
+    if (sharded) {
+        // once per sweep: sum the shards' residual deltas (n doubles; u moves by the negative) and the 16 scalar sums — all
+        // enqueued on the sweep stream behind the sweep itself; the iteration's only host synchronisation is the fetch below
         rc = hbk_delta_pack(c, r0, u0, xbuf);
         if (rc) return rc;
-        HB_HIP(hipMemcpyAsync(xbuf + 2 * (size_t)n, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
-        HB_HIP(hipStreamSynchronize(c->stream));
-        if (a.allreduce(xbuf, xcount, a.allreduce_user)) return hb_fail(HB_ERR_COMM, "all-reduce callback failed");
+        HB_HIP(hipMemcpyAsync(xbuf + (size_t)n, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
+        rc = exchange();
+        if (rc) return rc;
         rc = hbk_delta_unpack(c, r0, u0, xbuf);
         if (rc) return rc;
-        HB_HIP(hipMemcpyAsync(c->acc, xbuf + 2 * (size_t)n, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
+        HB_HIP(hipMemcpyAsync(c->acc, xbuf + (size_t)n, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
         rc = hbk_reduce_ru(c);
         if (rc) return rc;
-        HB_HIP(hipMemcpyAsync(c->h_acc, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToHost, c->stream));
-        HB_HIP(hipStreamSynchronize(c->stream));
-        so.sum_g2 = c->h_acc[HB_ACC_SUMG2];
-        for (int k = 0; k < HB_MAX_FOLD; k++) so.class_count[k] = c->h_acc[HB_ACC_COUNT0 + k];
-        so.sum_vargL = c->h_acc[HB_ACC_SUMVARGL];
-        so.n_events = c->h_acc[HB_ACC_EVENTS];
-        so.n_cache_miss = c->h_acc[HB_ACC_MISS];
-        so.n_redo = c->h_acc[HB_ACC_REDO];
-        so.sum_r = c->h_acc[HB_ACC_SUMR];
-        so.sum_r2 = c->h_acc[HB_ACC_SUMR2];
-        so.var_u = c->h_acc[HB_ACC_VARU];
     }
+    rc = hb_ctx_sweep_end(c, &so);
+    if (rc) return rc;
     events_sum += so.n_events;
     miss_sum += so.n_cache_miss;
     redo_sum += so.n_redo;
@@ -673,11 +689,9 @@ int hb_run::finish(hb_bayes_out *o)
         std::vector<double> xa(n);
         rc = hb_ctx_matvec(c, asum.data(), xa.data());
         if (rc) return rc;
-        if (world > 1) {
-            HB_HIP(hipMemset(xbuf, 0, sizeof(double) * xcount));
-            HB_HIP(hipMemcpy(xbuf, xa.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-            if (a.allreduce(xbuf, xcount, a.allreduce_user)) return hb_fail(HB_ERR_COMM, "all-reduce callback failed");
-            HB_HIP(hipMemcpy(xa.data(), xbuf, sizeof(double) * n, hipMemcpyDeviceToHost));
+        if (sharded) {
+            rc = allreduce_host(xa.data(), n);
+            if (rc) return rc;
         }
         for (int k = 0; k < n; k++) e[k] -= xa[k];
     }
@@ -715,9 +729,11 @@ int hb_run::finish(hb_bayes_out *o)
         std::vector<double> w(nw);
         rc = hb_ctx_get_windows(c, w.data());
         if (rc) return rc;
-        if (world > 1) {
-            rc = allreduce_host(w.data(), nw);
-            if (rc) return rc;
+        if (sharded) { // (chunked: the exchange buffer holds n + 16 values)
+            for (int k0 = 0; k0 < nw; k0 += (int)xcount) {
+                rc = allreduce_host(w.data() + k0, std::min((int)xcount, nw - k0));
+                if (rc) return rc;
+            }
         }
         for (int k = 0; k < nw; k++) {
             double p = w[k] / nzct;

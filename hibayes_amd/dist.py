@@ -71,5 +71,76 @@ class TorchComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
+    def sum_array(self, a):
+        """Element-wise sum over ranks of a host array (GEBV partial products of the shards)."""
+        t = self.torch.tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
     def barrier(self):
         self.dist.barrier(group=self.group)
+
+
+class RcclComm:
+    """The library's own RCCL communicator (include/hibayes_gpu.h: hb_comm_*): the per-sweep all-reduce is then ONE
+    ncclAllReduce enqueued on the sweep's HIP stream by the library itself — no host synchronisation, no Python in the
+    loop. Rank 0 creates the 128-byte RCCL id; `share` ships it (default: a torch.distributed broadcast, which is only used
+    for this bootstrap and for the few host-side scalars ibrm() needs)."""
+
+    def __init__(self, rank=0, world=1, device=0, share=None, side=None):
+        from ._lib import check, lib
+        self.L = lib()
+        self.rank, self.world, self.side = int(rank), int(world), side
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            check(self.L.hb_comm_unique_id(ident))
+        if self.world > 1:
+            if share is None:
+                raise ValueError("RcclComm: world > 1 needs `share` to distribute rank 0's id")
+            raw = share(bytes(ident) if self.rank == 0 else None)
+            ident = (C.c_ubyte * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        check(self.L.hb_comm_init(C.byref(h), ident, self.rank, self.world, int(device)))
+        self.handle = h
+        if self.L.hb_comm_world(h) != self.world:
+            raise RuntimeError("RCCL reports %d ranks, expected %d" % (self.L.hb_comm_world(h), self.world))
+
+    @classmethod
+    def from_torch(cls, device_index, group=None):
+        """Bootstrap over an initialised torch.distributed process group (any backend)."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        on_gpu = dist.get_backend(group) == "nccl"
+        dev = torch.device("cuda", device_index) if on_gpu else torch.device("cpu")
+
+        def share(raw):
+            t = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if raw is not None:
+                t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            dist.broadcast(t, src=0, group=group)
+            return bytes(t.cpu().numpy().tobytes())
+
+        side = TorchComm(device=torch.device("cuda", device_index) if on_gpu else torch.device("cpu"), group=group)
+        return cls(rank, world, device_index, share=share, side=side)
+
+    def max_int(self, v):
+        return int(v) if self.world == 1 else self.side.max_int(v)
+
+    def sum_array(self, a):
+        return np.asarray(a, dtype=np.float64) if self.world == 1 else self.side.sum_array(a)
+
+    def barrier(self):
+        if self.world > 1:
+            self.side.barrier()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.hb_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

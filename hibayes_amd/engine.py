@@ -88,6 +88,17 @@ class Context:
         check(self.L.hb_ctx_download_gram(self.h, p, G.ctypes.data))
         return G
 
+    def pipeline_note(self):
+        v = self.L.hb_ctx_pipeline_note(self.h)
+        return None if v is None else v.decode()
+
+    def matmul(self, A):
+        """X @ A on the device (A: m x R); the GEBV sample matrix of R/bayes.r:303-305."""
+        A = np.asfortranarray(A, dtype=np.float64).reshape(self.m, -1, order="F")
+        out = np.zeros((self.n, A.shape[1]), order="F")
+        check(self.L.hb_ctx_matmul(self.h, A.ctypes.data, self.m, A.shape[1], out.ctypes.data, self.n))
+        return out
+
     def gram_band(self, p, l):
         P = self.panel
         G = np.zeros((P, P), dtype=np.int32)

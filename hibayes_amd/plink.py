@@ -23,8 +23,14 @@ def read_bim(path):
             p = line.split()
             if len(p) < 6:
                 continue
-            chrom.append(p[0]); snp.append(p[1]); pos.append(float(p[3])); a1.append(p[4]); a2.append(p[5])
-    return {"SNP": snp, "Chr": chrom, "Pos": np.array(pos), "A1": a1, "A2": a2}
+            chrom.append(p[0]); snp.append(p[1]); pos.append(p[3]); a1.append(p[4]); a2.append(p[5])
+    # the reference keeps every column as text (vector<string>); Pos is also offered as numbers (NaN where it is not one)
+    def num(v):
+        try:
+            return float(v)
+        except ValueError:
+            return float("nan")
+    return {"SNP": snp, "Chr": chrom, "Pos": np.array([num(v) for v in pos]), "Pos_text": pos, "A1": a1, "A2": a2}
 
 
 def read_fam(path):
@@ -80,14 +86,114 @@ def read_plink(bfile, maxLine=10000, impute=True, mode="A", out=None, threads=4)
         raw = f.read()
     geno = decode_bed(raw, n, m, impute=impute, mode=mode)
     if out is not None:
-        geno.T.tofile(out + ".bin")  # column-major bytes
-        with open(out + ".id", "w") as f:
+        write_bigmatrix(out, geno)
+        with open(out + ".id", "w") as f:                       # R/read_plink.r:75
             f.write("\n".join(r[1] for r in fam) + "\n")
-        with open(out + ".map", "w") as f:
-            f.write("SNP\tChr\tPos\tA1\tA2\n")
+        with open(out + ".map", "w") as f:                      # rMap_c, src/read_bed.cpp:78-85: the .bim text, untouched
+            f.write("SNP\tCHROM\tPOS\tA1\tA2\n")
             for i in range(m):
-                f.write("%s\t%s\t%g\t%s\t%s\n" % (bim["SNP"][i], bim["Chr"][i], bim["Pos"][i], bim["A1"][i], bim["A2"][i]))
+                f.write("%s\t%s\t%s\t%s\t%s\n" % (bim["SNP"][i], bim["Chr"][i], bim["Pos_text"][i], bim["A1"][i], bim["A2"][i]))
     return {"fam": fam, "geno": geno, "map": bim}
+
+
+# --------------------------------------------------------------------------------------------
+# bigmemory file-backed matrices: the on-disk form read_plink() leaves behind (R/read_plink.r:57-65) and that a later
+# session re-opens with attach.big.matrix("xx.desc"). The .bin is the raw column-major array (type "char" = int8, NA =
+# -128); the .desc is R's dput() of a big.matrix.descriptor. Third-party format: bigmemory (CRAN; hibayes DESCRIPTION
+# Imports it without a version pin), files R/bigmemory.R (describe / attach.resource) and src/BigMatrix.cpp.
+# --------------------------------------------------------------------------------------------
+_BM_TYPES = {"char": np.int8, "short": np.int16, "integer": np.int32, "float": np.float32, "double": np.float64,
+             "raw": np.uint8}
+
+
+def write_bigmatrix(out, geno):
+    """Write `geno` (n x m int8) as out.bin + out.desc, the pair bigmemory::big.matrix(backingfile=, descriptorfile=)
+    creates for type = "char"."""
+    g = np.asarray(geno)
+    if g.dtype != np.int8:
+        raise ValueError("the bigmemory 'char' matrix holds int8 genotype codes")
+    n, m = g.shape
+    np.asfortranarray(g).T.tofile(out + ".bin")   # column-major bytes
+    d = os.path.dirname(os.path.abspath(out))
+    with open(out + ".desc", "w") as f:
+        f.write('new("big.matrix.descriptor", description = list(sharedType = "FileBacked", \n'
+                '    filename = "%s", dirname = "%s/", totalRows = %dL, \n'
+                '    totalCols = %dL, rowOffset = c(0, %d), colOffset = c(0, \n'
+                '    %d), nrow = %d, ncol = %d, rowNames = NULL, colNames = NULL, \n'
+                '    type = "char", separated = FALSE))\n' % (os.path.basename(out) + ".bin", d, n, m, n, m, n, m))
+
+
+def parse_bigmatrix_desc(text):
+    """Fields of a big.matrix.descriptor as dput() prints it (whitespace and line breaks anywhere)."""
+    import re
+    t = " ".join(text.split())
+    if "big.matrix.descriptor" not in t:
+        raise ValueError("not a bigmemory descriptor file")
+
+    def field(name, pat):
+        mm = re.search(name + r"\s*=\s*" + pat, t)
+        return mm.group(1) if mm else None
+
+    def pair(name):
+        mm = re.search(name + r"\s*=\s*c\(\s*([-0-9.eE+]+)L?\s*,\s*([-0-9.eE+]+)L?\s*\)", t)
+        return (int(float(mm.group(1))), int(float(mm.group(2)))) if mm else None
+
+    d = {"filename": field("filename", r'"([^"]*)"'), "dirname": field("dirname", r'"([^"]*)"'),
+         "type": field("type", r'"([^"]*)"'), "sharedType": field("sharedType", r'"([^"]*)"'),
+         "separated": field("separated", r"(TRUE|FALSE)") == "TRUE"}
+    for k in ("totalRows", "totalCols", "nrow", "ncol"):
+        v = field(k, r"([-0-9.eE+]+)L?")
+        d[k] = None if v is None else int(float(v))
+    d["rowOffset"], d["colOffset"] = pair("rowOffset"), pair("colOffset")
+    if d["filename"] is None or d["totalRows"] is None or d["totalCols"] is None or d["type"] is None:
+        raise ValueError("incomplete bigmemory descriptor")
+    return d
+
+
+def attach_bigmatrix(descfile, backingpath=None):
+    """attach.big.matrix(descfile): memory-map the backing file and return the n x m matrix WITHOUT loading it
+    (numpy.memmap, Fortran order) — for type "char" this is exactly the int8 column-major layout hb_ctx_upload_genotype_i8
+    / Bayes(X_i8) take, so a 25 GB genotype file goes from disk to the device without a host copy of doubles
+    (the reference's as.matrix() at R/bayes.r:284 makes one of 8 bytes per genotype). A sub-matrix descriptor
+    (rowOffset / colOffset) is honoured. `backingpath` overrides the recorded directory (files that were moved)."""
+    with open(descfile) as f:
+        d = parse_bigmatrix_desc(f.read())
+    if d["separated"]:
+        raise ValueError("separated (one file per column) big.matrix descriptors are not supported")
+    if d["type"] not in _BM_TYPES:
+        raise ValueError("unknown big.matrix type '%s'" % d["type"])
+    cands = []
+    if backingpath is not None:
+        cands.append(os.path.join(backingpath, d["filename"]))
+    cands.append(os.path.join(os.path.dirname(os.path.abspath(descfile)), d["filename"]))
+    if d["dirname"]:
+        cands.append(os.path.join(d["dirname"], d["filename"]))
+    path = next((c for c in cands if os.path.exists(c)), None)
+    if path is None:
+        raise FileNotFoundError("backing file '%s' of %s not found" % (d["filename"], descfile))
+    dt = np.dtype(_BM_TYPES[d["type"]])
+    R, C = d["totalRows"], d["totalCols"]
+    if os.path.getsize(path) < R * C * dt.itemsize:
+        raise ValueError("backing file shorter than totalRows x totalCols")
+    mm = np.memmap(path, dtype=dt, mode="r", shape=(R, C), order="F")
+    r0, nr = d["rowOffset"] if d["rowOffset"] else (0, R)
+    c0, nc = d["colOffset"] if d["colOffset"] else (0, C)
+    return mm[r0:r0 + nr, c0:c0 + nc]
+
+
+def read_bigmatrix(prefix):
+    """The four files read_plink(out = prefix) leaves: genotypes (memory-mapped), individual ids, map."""
+    geno = attach_bigmatrix(prefix + ".desc")
+    ids = None
+    if os.path.exists(prefix + ".id"):
+        with open(prefix + ".id") as f:
+            ids = [l.strip() for l in f if l.strip()]
+    mp = None
+    if os.path.exists(prefix + ".map"):
+        t = read_table(prefix + ".map")
+        mp = {"SNP": t["SNP"], "Chr": t["CHROM"], "Pos_text": t["POS"],
+              "Pos": np.array([float(v) if v is not None else float("nan") for v in t["POS"]]), "A1": t["A1"], "A2": t["A2"]}
+    return {"geno": geno, "id": ids, "map": mp}
 
 
 def read_table(path, sep="\t"):

@@ -55,6 +55,17 @@ int hb_device_count(void);
  * Return 0 on success.
  * ------------------------------------------------------------------------------------ */
 typedef int (*hb_allreduce_fn)(void *device_buf, size_t count, void *user);
+/* The same collective INSIDE the library: an RCCL communicator (librccl is dlopen()ed on first use). With
+ * hb_bayes_args.comm set, the per-sweep exchange is one ncclAllReduce enqueued on the sweep's HIP stream — no host
+ * synchronisation and no callback, so it also works from the R shim. Rank 0 calls hb_comm_unique_id(), ships the
+ * HB_COMM_ID_BYTES to the other ranks by any means (torch.distributed / MPI / a file), every rank calls hb_comm_init(). */
+#define HB_COMM_ID_BYTES 128
+typedef struct hb_comm hb_comm;
+int hb_comm_unique_id(void *id_out /* HB_COMM_ID_BYTES */);
+int hb_comm_init(hb_comm **out, const void *id, int32_t rank, int32_t world, int32_t device);
+int hb_comm_world(const hb_comm *c);   /* ranks RCCL reports for the communicator */
+int hb_comm_rank(const hb_comm *c);
+void hb_comm_destroy(hb_comm *c);
 typedef struct hb_ctx hb_ctx; /* device context of one genotype shard, see the engine API below */
 /* called once per iteration from the calling thread; non-zero return stops the run
  * (the shim wires it to R_CheckUserInterrupt; the reference cannot be interrupted) */
@@ -127,9 +138,12 @@ typedef struct hb_bayes_args {
     /* warm start (no reference counterpart; ABI 2): m effects the chain starts from instead of g = 0
      * (src/Bayes.cpp:297). yadj = y - mu - X g_init, u = X g_init; classes restart as (g != 0). */
     const double *g_init;
+    /* in-library RCCL collective (takes precedence over `allreduce`); with world == 1 the exchange path still runs,
+     * which is how a one-GPU box exercises it */
+    hb_comm *comm;
 } hb_bayes_args;
 
-/* number of doubles exchanged per sweep for n individuals */
+/* number of doubles exchanged per sweep for n individuals: the residual delta (u moves by its negative) + 16 scalar sums */
 size_t hb_exchange_count(int32_t n);
 
 /* ------------------------------------------------------------------------------------
@@ -242,6 +256,10 @@ int hb_ctx_download_gram(hb_ctx *c, int32_t panel_index, int32_t *G);
 /* band block l of panel p (row-major int32, P x P): G[k][t] = x_{(p-l)P+k} . x_{pP+t}, l = 0..band; the look-ahead
  * pipeline folds the moves of panel p-l into panel p's right-hand sides with it */
 int hb_ctx_download_gram_band(hb_ctx *c, int32_t panel_index, int32_t l, int32_t *G);
+/* NULL when the persistent pipeline is available; otherwise the reason the context fell back to the event-ordered
+ * per-panel kernels (kernels on two streams are not co-resident here: AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING, a
+ * counter-collecting profiler ...). Probed once at hb_ctx_create(); hb_ctx_set_pipeline(1, ...) then keeps pipeline 0. */
+const char *hb_ctx_pipeline_note(const hb_ctx *c);
 /* current geometry: pipeline flag, look-ahead groups, panels per mat-vec launch, band width (blocks l = 1..band) */
 int hb_ctx_get_pipeline(const hb_ctx *c, int32_t *pipeline, int32_t *lookahead, int32_t *dotgroup, int32_t *band);
 /* move lists of the last sweep: ev_count[npanels]; ev_idx / ev_delta are [npanels][P] with ev_count[p] valid entries
@@ -258,6 +276,11 @@ int hb_ctx_dot(hb_ctx *c, int32_t col0, int32_t ncols, double *d);
 
 /* out (n) = X * alpha (m): the product behind e = y - ... - X*alpha, reference src/Bayes.cpp:971 */
 int hb_ctx_matvec(hb_ctx *c, const double *alpha, double *out);
+
+/* out (n x R, column-major, leading dimension ldo) = X * A, A (m x R, leading dimension ldA) on the host: the GEBV sample
+ * matrix MCMCsamples$g = M %*% MCMCsamples$alpha of reference R/bayes.r:303-305 (then g$gebv = its row means, :308).
+ * Eight records per pass, only over the columns with a non-zero effect in any of them. */
+int hb_ctx_matmul(hb_ctx *c, const double *A, int64_t ldA, int32_t R, double *out, int64_t ldo);
 
 /* helpers for the host blocks that share yadj (reference src/Bayes.cpp:479-516) */
 int hb_ctx_residual_sums(hb_ctx *c, double *sum_r, double *sum_r2);

@@ -173,3 +173,41 @@ def test_synthetic_generator_is_the_documented_philox_stream():
             if gj % 4 == 3:
                 x = 0
             assert X[i, j] == x
+
+
+def test_gebv_sample_matrix_on_device():
+    # MCMCsamples$g = M %*% MCMCsamples$alpha (reference R/bayes.r:303-305): int8 genotypes x fp64 effect samples
+    rng = np.random.default_rng(12)
+    n, m, R = 1537, 700, 19
+    X = rand_geno(rng, n, m, signed=True)
+    A = np.zeros((m, R))
+    for r in range(R):                                   # point-mass samples: a few markers in the model per record
+        j = rng.choice(m, 12, replace=False)
+        A[j, r] = rng.normal(0, 0.3, 12)
+    A[:, 7] = rng.normal(0, 0.01, m)                     # one dense record (BayesRR-like)
+    A[:, 8:16] = 0.0                                     # a whole block of eight empty records
+    with H.Context(n, m) as c:
+        c.upload(X)
+        G = c.matmul(A)
+        g1 = c.matmul(A[:, 3])
+    ref = X.astype(np.float64) @ A
+    np.testing.assert_allclose(G, ref, rtol=1e-13, atol=1e-13)
+    assert not G[:, 8:16].any()
+    np.testing.assert_allclose(g1[:, 0], ref[:, 3], rtol=1e-13, atol=1e-13)
+
+
+def test_bigmemory_file_to_device_without_a_host_copy(tmp_path, demo):
+    # the .bin a previous read_plink(out=) session left behind, memory-mapped and uploaded as it is (int8, column-major)
+    out = str(tmp_path / "bm")
+    H.write_bigmatrix(out, demo["plink"]["geno"])
+    g = H.attach_bigmatrix(out + ".desc")
+    assert isinstance(g, np.memmap) and g.dtype == np.int8
+    with H.Context(600, 1000) as c:
+        c.upload(g)
+        assert np.array_equal(c.download(), demo["plink"]["geno"])
+        xpx, vx, sumvx, nvar0 = c.marker_stats()
+    assert xpx[0] == float((demo["plink"]["geno"][:, 0].astype(np.int64) ** 2).sum())
+    sub = g[np.asarray(demo["rows"]), :]                 # ibrm()'s row subset (R/bayes.r:286-291)
+    r = H.Bayes(demo["y"], sub, "BayesCpi", [0.95, 0.05], niter=20, nburn=10, thin=2, seed=3, verbose=False)
+    r2 = H.Bayes(demo["y"], demo["M"], "BayesCpi", [0.95, 0.05], niter=20, nburn=10, thin=2, seed=3, verbose=False)
+    assert np.array_equal(r["alpha"], r2["alpha"])

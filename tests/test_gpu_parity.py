@@ -64,6 +64,11 @@ def test_ibrm_full_formula_with_covariates_and_random_effects(demo):
     np.testing.assert_allclose(fit["e"]["e"], g["e"], rtol=1e-7, atol=1e-8)
     assert len(fit["g"]["gebv"]) == 600 and len(fit["e"]["id"]) == 300
     np.testing.assert_allclose(fit["g"]["gebv"], pl["geno"].astype(float) @ fit["alpha"], rtol=1e-10, atol=1e-12)
+    # MCMCsamples$g = M %*% MCMCsamples$alpha over all 600 genotyped individuals, gebv = its row means (R/bayes.r:303-308)
+    gs = fit["MCMCsamples"]["g"]
+    assert gs.shape == (600, 40)
+    np.testing.assert_allclose(gs, pl["geno"].astype(float) @ fit["MCMCsamples"]["alpha"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(fit["g"]["gebv"], gs.mean(axis=1), rtol=0, atol=0)
 
 
 def test_readme_fit_on_the_gpu_inside_the_printed_posterior(demo):
@@ -259,3 +264,59 @@ def test_ragged_tiny_shapes_draw_for_draw_against_the_oracle(n, m):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
         assert (a[m // 2] == 0).all()
         np.testing.assert_allclose([r["Vg"], r["Ve"], r["mu"]], [ref["Vg"], ref["Ve"], ref["mu"]], rtol=1e-9)
+
+
+def test_serialising_environment_falls_back_to_the_per_panel_kernels():
+    """The persistent pipeline needs kernels on two streams to be co-resident; where they are not (AMD_SERIALIZE_KERNEL,
+    HIP_LAUNCH_BLOCKING, a counter-collecting profiler) the context must notice at creation and run the event-ordered
+    per-panel kernels instead of stalling into its 3 s timeout — with the same results."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import hibayes_amd as H\n"
+        "g = np.load(%r)\n"
+        "with H.Context(g['X'].shape[0], g['X'].shape[1], precise=2) as c:\n"
+        "    c.upload(g['X']); c.set_pipeline(1, 2, 6)\n"
+        "    print('NOTE', c.pipeline_note()); print('PIPE', c.pipeline()[0])\n"
+        "    r = H.Bayes(g['y'], None, 'BayesCpi', [0.95, 0.05], niter=16, nburn=6, thin=2, seed=424242, verbose=False, ctx=c)\n"
+        "    print('ERR', float(np.abs(r['MCMCsamples']['alpha'] - g['BayesCpi_alpha']).max()))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(G, "small_all_models_philox.npz"))
+    for var in ("HB_FORCE_SERIAL", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"):
+        env = dict(os.environ)
+        env[var] = "3" if var == "AMD_SERIALIZE_KERNEL" else "1"
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+        assert var in lines["NOTE"] and lines["PIPE"] == "0", out.stdout
+        assert float(lines["ERR"]) < 1e-9
+        assert "per-panel kernels" in out.stderr
+    # and without any of them the pipeline is on
+    with H.Context(64, 64) as c:
+        assert c.pipeline_note() is None and c.pipeline()[0] == 1
+
+
+def test_in_library_rccl_exchange_world_1_is_the_plain_chain(demo):
+    """The RCCL path on the one GPU this box has: a one-rank communicator still packs the residual delta, runs
+    ncclAllReduce on the sweep stream and unpacks — the chain must be the unsharded one up to the rounding of
+    yadj = yadj0 + (yadj - yadj0) (same decisions, effects to 1e-9)."""
+    from hibayes_amd.dist import RcclComm
+    comm = RcclComm(0, 1, 0)
+    assert comm.L.hb_comm_world(comm.handle) == 1
+    kw = dict(niter=60, nburn=20, thin=5, seed=99, verbose=False)
+    a = H.Bayes(demo["y"], demo["M"], "BayesCpi", [0.95, 0.05], comm=comm, **kw)
+    b = H.Bayes(demo["y"], demo["M"], "BayesCpi", [0.95, 0.05], **kw)
+    assert np.array_equal(a["MCMCsamples"]["alpha"] != 0, b["MCMCsamples"]["alpha"] != 0)
+    np.testing.assert_allclose(a["MCMCsamples"]["alpha"], b["MCMCsamples"]["alpha"], rtol=1e-9, atol=1e-13)
+    assert np.array_equal(a["pip"], b["pip"])
+    for k in ("mu", "Ve", "Vg", "h2"):
+        assert a[k] == pytest.approx(b[k], rel=1e-9)
+    np.testing.assert_allclose(a["e"], b["e"], rtol=0, atol=1e-9)
+    # with windows and a second model through the same communicator
+    wind = H.cutwind_by_num(np.array([int(c) for c in demo["plink"]["map"]["Chr"]]), demo["plink"]["map"]["Pos"], 50)
+    a = H.Bayes(demo["y"], demo["M"], "BayesR", [0.95, 0.02, 0.02, 0.01], fold=[0, 1e-4, 1e-3, 1e-2], windindx=wind, comm=comm, **kw)
+    b = H.Bayes(demo["y"], demo["M"], "BayesR", [0.95, 0.02, 0.02, 0.01], fold=[0, 1e-4, 1e-3, 1e-2], windindx=wind, **kw)
+    np.testing.assert_allclose(a["alpha"], b["alpha"], rtol=1e-9, atol=1e-13)
+    assert np.array_equal(a["gwas"], b["gwas"])
+    comm.close()

@@ -99,3 +99,63 @@ def test_product_fails_loudly_without_gpu():
     assert ei.value.status == 2 and "no CPU fallback" in str(ei.value)
     with pytest.raises(H.HibayesError):
         H.Bayes(np.arange(10.0), np.ones((10, 4), dtype=np.int8), "BayesCpi", [0.95, 0.05], niter=2, nburn=0, thin=1)
+
+
+def test_bigmemory_backing_files_round_trip(tmp_path, demo):
+    """read_plink(out=) leaves xx.bin / xx.desc / xx.id / xx.map (reference R/read_plink.r:39-75); a later session
+    re-attaches them (attach.big.matrix) and hands the int8 matrix to ibrm() without a double copy."""
+    import hibayes_amd as H
+    out = str(tmp_path / "demo_out")
+    pl = H.read_plink(demo["prefix"], out=out)
+    assert os.path.getsize(out + ".bin") == 600 * 1000
+    bm = H.read_bigmatrix(out)
+    assert bm["geno"].dtype == np.int8 and bm["geno"].shape == (600, 1000) and bm["geno"].flags["F_CONTIGUOUS"]
+    assert np.array_equal(np.asarray(bm["geno"]), pl["geno"])
+    assert bm["geno"][:4, :5].tolist() == [[2, 1, 1, 1, 0], [1, 0, 1, 1, 0], [0, 2, 0, 0, 0], [1, 1, 1, 1, 0]]   # README.md:81-86
+    assert bm["id"] == [r[1] for r in pl["fam"]]
+    assert bm["map"]["SNP"] == pl["map"]["SNP"] and np.array_equal(bm["map"]["Pos"], pl["map"]["Pos"])
+    # the .map keeps the .bim's position text (rMap_c writes strings): 9-digit positions survive
+    assert open(out + ".map").readline() == "SNP\tCHROM\tPOS\tA1\tA2\n"
+
+
+def test_bigmemory_descriptor_as_r_prints_it(tmp_path):
+    import hibayes_amd as H
+    from hibayes_amd.plink import parse_bigmatrix_desc
+    # dput() of a big.matrix.descriptor as bigmemory writes it (line breaks where deparse() puts them)
+    desc = ('new("big.matrix.descriptor", description = list(sharedType = "FileBacked", \n'
+            '    filename = "g.bin", dirname = "/somewhere/else/", totalRows = 7L, \n'
+            '    totalCols = 5L, rowOffset = c(0, 7), colOffset = c(0, \n'
+            '    5), nrow = 7, ncol = 5, rowNames = NULL, colNames = NULL, \n'
+            '    type = "char", separated = FALSE))\n')
+    d = parse_bigmatrix_desc(desc)
+    assert (d["totalRows"], d["totalCols"], d["type"], d["filename"], d["separated"]) == (7, 5, "char", "g.bin", False)
+    g = (np.arange(35, dtype=np.int16).reshape(7, 5) % 3).astype(np.int8)
+    g[2, 3] = -128                                   # NA_CHAR
+    g.T.tofile(str(tmp_path / "g.bin"))              # column-major bytes, as the mmap holds them
+    (tmp_path / "g.desc").write_text(desc)
+    m = H.attach_bigmatrix(str(tmp_path / "g.desc"))  # the recorded dirname does not exist: found next to the .desc
+    assert np.array_equal(np.asarray(m), g) and m[2, 3] == -128
+    # a sub-matrix descriptor (rows 2..5, columns 1..3)
+    (tmp_path / "s.desc").write_text(desc.replace("rowOffset = c(0, 7)", "rowOffset = c(2, 4)").replace("c(0, \n    5)", "c(1, \n    3)"))
+    assert np.array_equal(np.asarray(H.attach_bigmatrix(str(tmp_path / "s.desc"))), g[2:6, 1:4])
+    with pytest.raises(ValueError):
+        parse_bigmatrix_desc("list(a = 1)")
+
+
+def test_map_argument_of_ibrm_is_validated_like_the_reference(demo):
+    from hibayes_amd.bayes import _map_columns
+    mp = demo["plink"]["map"]
+    chrom, pos = _map_columns(mp)                     # the loader's own dict (keys Chr / Pos)
+    assert chrom.size == 1000 and pos.dtype == np.float64
+    tab = np.array([["s1", "1", "100"], ["s2", "X", "123456789"], ["s3", "2", "7"], ["s4", "Y", "9"], ["s5", "X", "11"]], dtype=object)
+    chrom, pos = _map_columns(tab)                    # R/bayes.r:237-243: X, Y numbered after the largest numeric chromosome
+    assert chrom.tolist() == [1, 3, 2, 4, 3] and pos.tolist() == [100, 123456789, 7, 9, 11]
+    for bad, msg in ((np.array([["s", "0", "5"]], dtype=object), "0 is not allowed in chromosome."),
+                     (np.array([["s", "1", "0"]], dtype=object), "0 is not allowed in physical position."),
+                     (np.array([["s", None, "5"]], dtype=object), "NAs are not allowed in chromosome."),
+                     (np.array([["s", "1", "abc"]], dtype=object), "Characters are not allowed in physical position."),
+                     (np.array([["s", "1"]], dtype=object), "At least 3 columns in map.")):
+        with pytest.raises(ValueError, match=msg):
+            _map_columns(bad)
+    with pytest.raises(ValueError, match="map information must be provided."):
+        _map_columns(None)
