@@ -1282,18 +1282,23 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             constexpr int u = decltype(U)::value;
             if (Q >= 2) rg_d[(u + 1) % Q] = ld_sc1(v.dsum + (size_t)min(p + 1, np - 1) * P + t);
         });
-        // (1) Gram rows of the next panel's hot markers: four 1-KiB pieces per wave travel during the rounds
-        int4 pre0 = make_int4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
-        int plin0 = -1, plin1 = -1, plin2 = -1, plin3 = -1;
+        // (1) Gram rows of the next panel's hot markers, straight into the other half of the LDS row cache by LDS-DMA
+        // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no destination registers, so nothing here is ever waited for
+        // by the compiler's bookkeeping; the first reader of that half — the first round of the next panel that has
+        // candidates — drains vmcnt before its barrier). A quiet panel never waits for them.
         if (have_next) {
-            if (wave < n_items) { plin0 = min((wave << 8) + lane * 4, n_total - 4);
-                pre0 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin0 >> lgP] << lgP) + (plin0 & (P - 1))); }
-            if (wave + S < n_items) { plin1 = min(((wave + S) << 8) + lane * 4, n_total - 4);
-                pre1 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin1 >> lgP] << lgP) + (plin1 & (P - 1))); }
-            if (wave + 2 * S < n_items) { plin2 = min(((wave + 2 * S) << 8) + lane * 4, n_total - 4);
-                pre2 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin2 >> lgP] << lgP) + (plin2 & (P - 1))); }
-            if (wave + 3 * S < n_items) { plin3 = min(((wave + 3 * S) << 8) + lane * 4, n_total - 4);
-                pre3 = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[plin3 >> lgP] << lgP) + (plin3 & (P - 1))); }
+            const unsigned rown_lds = (unsigned)(uintptr_t)rown;
+            for (int it = wave; it < n_items; it += S) {
+                const int lin = (it << 8) + lane * 4;
+                if (lin < n_total) {
+                    const int32_t *src = gpn + ((size_t)hl[lin >> lgP] << lgP) + (lin & (P - 1));
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(src), "s"(__builtin_amdgcn_readfirstlane(rown_lds + ((unsigned)it << 10)))
+                                 : "memory");
+                }
+            }
         }
         // (2) the next panel's candidate coefficients, (3) the hot-list two panels ahead, (4) ring slot u <- panel p + Q;
         // this panel's candidate coefficients arrived a panel ago
@@ -1379,6 +1384,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                     cs_t[rank] = t;
                     cs_slot[rank] = myslot;
                 }
+                // this half of the row cache was filled by LDS-DMA a panel ago: every wave drains its own pieces before the barrier
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(12);
                 const int t_hi = tot > 64 ? *s_thi : P;
@@ -1436,9 +1443,36 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                             iv = ge ? cinvv[c] : iv;
                             sz = ge ? csdz[c] : sz;
                         }
-                        gn = (cls > 0) ? fma(rhsv, iv, sz) : 0.0;
+                        gn = (q >= cthr[0]) ? fma(rhsv, iv, sz) : 0.0; // (thresholds ascend: class > 0 <=> q >= thr[0])
                         if (model == 5 && fabs(gn) < 1e-6) gn = 1e-6;
                     };
+                    if (crowded) {
+                        // Dense round: the Gram entries were gathered into cg[][] (zero on and below the diagonal, so a move of
+                        // lane k leaves lanes <= k alone without a compare). The loop is software-pipelined around its only
+                        // loop-carried value, crhs: the rows of cg travel two steps ahead of their use (an LDS read takes ~100
+                        // cycles), a certain mover needs no ballot, and a zero change needs no branch (it adds an exact zero).
+                        int r1 = cg[lane], r2 = cg[(ncr > 1 ? 64 : 0) + lane];
+                        double gnx = (double)r1;
+                        r1 = r2;
+                        for (int k = 0; k < ncr; k++) {
+                            const double gcur = gnx;
+                            r2 = cg[min(k + 2, ncr - 1) * 64 + lane];
+                            bool stays = false;
+                            if (!((hotm >> k) & 1ull)) { // (uniform) a marker at zero moves only if it crosses its entry threshold
+                                const unsigned long long mv = __ballot(crhs * crhs >= cthr[0]) & vmask;
+                                stays = !((mv >> k) & 1ull);
+                            }
+                            if (!stays) {
+                                int cls;
+                                double gn;
+                                decide(crhs, cls, gn);
+                                const double dk = readlane_f64(gn - cgold, k);
+                                crhs = fma(-gcur, dk, crhs);
+                            }
+                            gnx = (double)r1; // (landed an iteration ago)
+                            r1 = r2;
+                        }
+                    } else
                     for (int k = 0; k < ncr; k++) {
                         const double q = crhs * crhs;
                         const unsigned long long mv = (__ballot(q >= cthr[0]) & vmask) | hotm;
@@ -1589,26 +1623,6 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             }
         } else {
             cacc[0] += active ? 1 : 0; // a quiet panel: nothing moved, nothing to write
-        }
-        if (have_next && n_items > 0) { // the next panel's hot rows: they have had the whole panel to arrive
-            if (plin0 >= 0) *reinterpret_cast<int4 *>(rown + plin0) = pre0;
-            if (plin1 >= 0) *reinterpret_cast<int4 *>(rown + plin1) = pre1;
-            if (plin2 >= 0) *reinterpret_cast<int4 *>(rown + plin2) = pre2;
-            if (plin3 >= 0) *reinterpret_cast<int4 *>(rown + plin3) = pre3;
-            for (int it = 4 * S + wave; it < n_items; it += 4 * S) { // many hot markers: the rest, four pieces in flight
-                int4 r4[4];
-                int l4[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int iu = it + u * S;
-                    l4[u] = (iu < n_items) ? min((iu << 8) + lane * 4, n_total - 4) : -1;
-                    const int lc = max(l4[u], 0);
-                    r4[u] = *reinterpret_cast<const int4 *>(gpn + ((size_t)hl[lc >> lgP] << lgP) + (lc & (P - 1)));
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (l4[u] >= 0) *reinterpret_cast<int4 *>(rown + l4[u]) = r4[u];
-            }
         }
         if (wave == S - 1 && group_end) {
             // last panel of its mat-vec group: the update of this group is waiting for exactly these moves, and the
