@@ -109,12 +109,11 @@ def cpu_baseline(ctx, y, args, Pi, fold):
                 rng=O.RNG_PHILOX, seed=args.seed)
     out[1] = r["iters_done"] / r["loop_seconds"] * (mc / float(args.m))
     one_thread_s = r["loop_seconds"]
-    # threaded dot/axpy (what a threaded BLAS would give the reference, README.md:18). BLAS-1 on
-    # n-long vectors rarely scales; bounded by a wall-clock guard in a child process.
-    thr = min(cores, 16)
-    if thr > 1:
-        import multiprocessing as mp
+    # threaded dot/axpy (what a threaded BLAS would give the reference, README.md:18; BASELINE.md §3: threads = 1 and = all
+    # cores). BLAS-1 on n-long vectors rarely scales; each setting is bounded by a wall-clock guard in a child process.
+    import multiprocessing as mp
 
+    def timed(thr):
         def _child(q):
             os.environ["OMP_WAIT_POLICY"] = "passive"
             rr = O.bayes(y, Xd, args.model, Pi, fold=fold, niter=it, nburn=it - 1, thin=1, threads=thr,
@@ -124,17 +123,31 @@ def cpu_baseline(ctx, y, args, Pi, fold):
         q = mp.get_context("fork").Queue()
         p = mp.get_context("fork").Process(target=_child, args=(q,))
         p.start()
-        p.join(timeout=max(30.0, 4.0 * one_thread_s))
+        p.join(timeout=max(20.0, 3.0 * one_thread_s))
         if p.is_alive():
             p.terminate()
             p.join()
-        elif not q.empty():
-            out[thr] = q.get() * (mc / float(args.m))
+            return None
+        return q.get() * (mc / float(args.m)) if not q.empty() else None
+
+    for thr in sorted(set([min(cores, 16), cores]) - {1}):
+        v = timed(thr)
+        if v is not None:
+            out[thr] = v
     best_thr = max(out, key=lambda k: out[k])
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": out[best_thr], "unit": "sweeps/s", "cores": best_thr, "kind": "port",
-            "sample": "oracle/hb_oracle.c (double col-major X, serial marker loop) on the first %d of %d markers, "
-                      "n=%d, %d sweeps, scaled by m_sample/m" % (mc, args.m, args.n, 1 + args.cpu_sweeps),
-            "value_1thread": out[1], "host_cores": cores}
+            "sample": "oracle/hb_oracle.c (double col-major X, serial marker loop, OpenMP inside dot/axpy) on the first %d of %d "
+                      "markers, n=%d, %d sweeps, scaled by m_sample/m" % (mc, args.m, args.n, 1 + args.cpu_sweeps),
+            "value_1thread": out[1], "by_threads": {str(k): v for k, v in sorted(out.items())}, "host_cores": cores,
+            "cpu_model": cpu_model}
 
 
 PIPELINE = {  # (pipeline, look-ahead groups, panels per mat-vec launch): see DESIGN.md §2
@@ -187,9 +200,25 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
             comm.barrier()
             torch.cuda.synchronize(local_rank)
 
+    curve = []
     if burn > 0:
-        check(L.hb_run_step(run, burn, ct.byref(fin)))
-        sync()
+        # the burn-in doubles as the regime curve: sweeps/s against markers changed per sweep, from the cold start (5 % of
+        # the markers enter in the first sweeps) down to the stationary regime the timed region runs in
+        done, prev = 0, RunInfo()
+        check(L.hb_run_state(run, ct.byref(prev)))
+        for upto in sorted(set(min(burn, x) for x in (5, 20, 60, 150, burn))):
+            if upto <= done:
+                continue
+            sync()
+            tc = time.perf_counter()
+            check(L.hb_run_step(run, upto - done, ct.byref(fin)))
+            sync()
+            dt = time.perf_counter() - tc
+            cur = RunInfo()
+            check(L.hb_run_state(run, ct.byref(cur)))
+            mv = (cur.mean_events * cur.iter - prev.mean_events * prev.iter) / max(1, upto - done)
+            curve.append({"sweeps": "%d-%d" % (done, upto), "moves_per_sweep": round(mv, 1), "sweeps_per_s": round((upto - done) / dt, 2)})
+            done, prev = upto, cur
         note("%s: burn-in done (%d sweeps)" % (model, burn))
     check(L.hb_run_step(run, W, ct.byref(fin)))
     sync()
@@ -211,6 +240,7 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
     del keep
     ev = (info.mean_events * info.iter - info0.mean_events * info0.iter) / max(1, K)   # over the timed sweeps only
     ms = (info.mean_misses * info.iter - info0.mean_misses * info0.iter) / max(1, K)
+    measure.curve = curve
     return elapsed, ev, info.nnz, ms
 
 
@@ -273,6 +303,8 @@ def main():
     K, W = args.steps, args.warmup
     elapsed, mean_events, nnz, misses = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
                                         m_global, comm, torch, note, burn=args.burnin)
+    curve_main = list(getattr(measure, "curve", []))
+    curve_main.append({"sweeps": "timed region", "moves_per_sweep": round(mean_events, 1), "sweeps_per_s": round(world * K / elapsed, 2)})
     # the dominant kernel on its own: the sweep's mat-vec launches, back to back, HIP events on their stream
     avg_ms, launches, cols = ctx.time_matvec(reps=3)
     alg_bytes = float(n) * cols  # one read of the launch's int8 genotypes (SURVEY.md §8 d: n*m per sweep)
@@ -311,6 +343,7 @@ def main():
                    "setup_seconds": {"generate": gen_s, "gram": gram_s}},
         "achieved_GBps": (K / elapsed) * n * m_global / 1e9, "achieved_frac_of_hbm_peak": (K / elapsed) * n * m_global / 1e9 / (HBM_PEAK_GBPS * world),
         "roofline": roof,
+        "regime_curve": curve_main,   # sweeps/s is set by the serial chain, i.e. by how many markers change per sweep
     }
     if args.secondary and args.secondary != args.model and world == 1:
         # the other model family of BASELINE.json's configs on the same genotypes, shorter run
@@ -325,6 +358,7 @@ def main():
                             "ms_per_step": el2 / K2 * 1e3, "achieved_frac_of_hbm_peak": K2 / el2 * n * m / 1e9 / HBM_PEAK_GBPS,
                             "mcmc_burn_in_sweeps_before_warmup": args.burnin_secondary,
                           "mean_changed_markers_per_sweep": ev2, "row_cache_misses_per_sweep": miss2, "NumNZSnp_last": nnz2,
+                            "regime_curve": list(getattr(measure, "curve", [])),
                             "pipeline": {"persistent_chain": geo2[0], "lookahead_groups": geo2[1], "panels_per_matvec": geo2[2]}}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:

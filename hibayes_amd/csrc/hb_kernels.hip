@@ -1278,10 +1278,6 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         // (0) the next panel's dot once more: when the ring slot was filled, Q panels ago, it may not have been written yet.
         // The later load simply lands on top of the earlier one. It is the first request of the panel because it is the
         // first to be used: the memory counter is in-order, so everything issued before a load is waited for with it.
-        ring_switch(p, [&](auto U) {
-            constexpr int u = decltype(U)::value;
-            if (Q >= 2) rg_d[(u + 1) % Q] = ld_sc1(v.dsum + (size_t)min(p + 1, np - 1) * P + t);
-        });
         // (1) Gram rows of the next panel's hot markers, straight into the other half of the LDS row cache by LDS-DMA
         // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no destination registers, so nothing here is ever waited for
         // by the compiler's bookkeeping; the first reader of that half — the first round of the next panel that has
