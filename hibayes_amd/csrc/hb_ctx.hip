@@ -190,7 +190,8 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->scratch, 8192));
     TRY(dev_alloc(&c->flags, (size_t)4096));
     TRY(dev_alloc(&c->hot_slot, mp));
-    TRY(dev_alloc(&c->hot_list, (size_t)c->npanels * 160));
+    TRY(dev_alloc(&c->hot_list, (size_t)(c->npanels + 1) * 256));
+    TRY(dev_alloc(&c->thr0f, mp + 1024));
     TRY(dev_alloc(&c->hot_n, (size_t)c->npanels));
     {
         hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&c->h_acc), sizeof(double) * HB_ACC_N);
@@ -247,7 +248,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
     void *ptrs[] = {c->X, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->dots, c->ev_count, c->ev_idx,
-                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
+                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_acc) (void)hipHostFree(c->h_acc);

@@ -45,7 +45,8 @@ struct hb_ctx {
     std::string pipeline_note;     // why the persistent pipeline is off, when it is
     unsigned int *flags = nullptr; // [0] chain_done (panels whose moves are published), [1] abort
     unsigned int *h_flags = nullptr;
-    int *hot_slot = nullptr, *hot_list = nullptr, *hot_n = nullptr; // per-sweep hot-lists (k_hotlist)
+    int *hot_slot = nullptr, *hot_list = nullptr, *hot_n = nullptr; // per-sweep row-cache lists (k_hotlist): hot_list is packed, 256 ints per panel
+    float *thr0f = nullptr;                                          // per-sweep opening filter of the chain (k_hotlist)
     int64_t ld = 0; // bytes per genotype column on device (multiple of 256)
     int precise = 0;
     int64_t m_offset = 0;

@@ -988,7 +988,8 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
 struct persist_view {
     int npanels, D, Lv, Lb;
     unsigned *flags;
-    const int *slot_of, *hotlist, *nhot; // per-sweep hot-lists from k_hotlist
+    const int *slot_of, *hotpack;        // per-sweep row-cache lists from k_hotlist
+    const float *thr0f;                  // ... and the opening filter
     double candf;                        // a marker at zero is a chain candidate when q >= candf * thr0 (candf <= 1)
 };
 
@@ -1001,19 +1002,35 @@ struct persist_view {
 // "thr0 <= kappa * xx * vare" predicts almost every entry (history does not: re-entry is at chance level).
 // A predicted marker only gets its Gram row prefetched; whether it moves is still decided by the chain.
 // Produced once per sweep, off the chain's critical path. One workgroup per panel.
+#define HB_HS 256 /* ints per panel in the packed hot-list: [0] = rows to cache, [4 ...] = their markers (one 1-KiB DMA piece) */
 __global__ __launch_bounds__(512) void k_hotlist(const hb_sweep_in *__restrict__ pin, const double *__restrict__ vx,
                                                  const double *__restrict__ g, const double *__restrict__ thr0,
                                                  const double *__restrict__ xpx, double kappa, int P, int nslot,
-                                                 int *__restrict__ slot_of, int *__restrict__ hotlist, int *__restrict__ nhot,
+                                                 int *__restrict__ slot_of, int *__restrict__ hotpack, float *__restrict__ thr0f,
                                                  uint8_t *__restrict__ tracker)
 {
     __shared__ int wcnt[16];
     const int p = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63, S = P >> 6;
     const int j = p * P + t;
-    const bool hot = vx[j] != 0.0 && (g[j] != 0.0 || thr0[j] <= kappa * xpx[j] * pin->vare);
+    const bool active = vx[j] != 0.0;
+    const bool hot = active && (g[j] != 0.0 || thr0[j] <= kappa * xpx[j] * pin->vare);
     // the chain only rewrites the class of markers that are or were in the model: a marker at zero is class 0 by
     // definition, whatever state the caller may have installed
     if (g[j] == 0.0) tracker[j] = 0;
+    // The chain's opening filter, 4 bytes per marker (it travels to the chain's LDS by DMA): NaN = monomorphic marker
+    // (skipped, src/Bayes.cpp:589), -inf = in the model (certain to move), else the entry threshold on q = rhs^2 rounded
+    // DOWN to float — a superset test; whoever passes it is decided with the exact fp64 threshold.
+    {
+        float f;
+        if (!active) f = __int_as_float(0x7fc00000);
+        else if (g[j] != 0.0) f = -__int_as_float(0x7f800000);
+        else {
+            const double th = thr0[j];
+            f = (float)th;
+            if ((double)f > th) f = nextafterf(f, -__int_as_float(0x7f800000));
+        }
+        thr0f[j] = f;
+    }
     const unsigned long long hmask = __ballot(hot);
     if (lane == 0) wcnt[wave] = __popcll(hmask);
     __syncthreads();
@@ -1025,9 +1042,9 @@ __global__ __launch_bounds__(512) void k_hotlist(const hb_sweep_in *__restrict__
     }
     const int raw = sbase + __popcll(hmask & ((1ull << lane) - 1ull));
     const int slot = (hot && raw < nslot) ? raw : -1;
-    slot_of[j] = vx[j] != 0.0 ? slot : -2; // -2: monomorphic marker, skipped by the chain
-    if (slot >= 0) hotlist[(size_t)p * nslot + slot] = t;
-    if (t == 0) nhot[p] = min(tot, nslot);
+    slot_of[j] = active ? slot : -2; // -2: monomorphic marker, skipped by the chain
+    if (slot >= 0) hotpack[(size_t)p * HB_HS + 4 + slot] = t;
+    if (t == 0) hotpack[(size_t)p * HB_HS] = min(tot, nslot);
 }
 
 // Forward corrections of one batch shape: FW moves x up to LB band blocks, all loads in flight together.
@@ -1086,7 +1103,7 @@ __device__ __forceinline__ void hb_read8(const int *w, int (&o)[8])
 // already finished) and the Gram rows of its hot markers (into the other half of a double-buffered LDS row
 // cache, two 1-KiB pieces per wave per turn boundary).
 template <int K1>
-__global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__restrict__ pin, chain_view v, persist_view pv,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_persist(const hb_sweep_in *__restrict__ pin, chain_view v, persist_view pv,
                                                        int nslot)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1096,11 +1113,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     char *base = smem + (size_t)2 * nslot * P * 4;
     double *ev_del = reinterpret_cast<double *>(base);
     int *ev_ix = reinterpret_cast<int *>(base + (size_t)P * 8);
-    int *hl0 = reinterpret_cast<int *>(base + (size_t)P * 12);                // hot-lists being prefetched, by panel parity
     double *red = reinterpret_cast<double *>(base + (size_t)P * 20);
     int *cnts = reinterpret_cast<int *>(base + (size_t)P * 20 + 128);
     int *s_thi = cnts + 18;   // first candidate left for the next round
-    int *s_nh0 = cnts + 19;   // [2] hot rows of the panel being prefetched, by panel parity
     int *wcnt0 = cnts + 32;   // candidates per wave: [32..47] even panels, [64..79] odd panels
     int *wviol = cnts + 48;   // wave saw a mis-speculated marker
     // staging of one round's candidates (<= 64): [field][candidate]
@@ -1120,6 +1135,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     const int R = pv.Lb + 1;
     double *corrL = reinterpret_cast<double *>(cg + 64 * 64);
     for (int l = 0; l < R; l++) corrL[(size_t)l * P + t] = 0.0;
+    // opening ring (see below): HB_RD slots of [P reduced dots: 8 B][P filter words: 4 B][pad to 1 KiB][1 KiB packed hot-list]
+    const int OSZ = ((12 * P + 1023) >> 10) << 10, OSLOT = OSZ + 1024, NPC = (OSZ >> 10) + 1; // NPC: DMA pieces per group
+    char *oring = reinterpret_cast<char *>(corrL + (size_t)R * P);
     int pslot = -1; // p mod R
     double wacc = 0.0;
     int cacc[K1 + 1];
@@ -1129,96 +1147,117 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
     double mbr = v.mb ? v.mb[0] : 0.0; // running bound on max |yadj| (kept by the publishing wave)
     int gcount = 0;                     // mat-vec groups published so far
 
-    // ---- prefetch registers ----
-    // What the opening of a panel needs (its reduced dot, entry threshold, old effect, x'x, row-cache slot) is kept in
-    // a ring of Q register sets filled Q panels ahead: with the mat-vec streaming at full rate a load takes several
-    // microseconds to come back, far longer than a quiet panel lasts. The loop below is unrolled Q times so that every
-    // ring access has a static index, every ring load is unconditional (a conditional load would make the compiler
-    // merge register copies, and a copy waits for the load), and nothing the loop consumes early is issued late:
-    // the memory counter is in-order, so using a young load forces every older one of the wave to land first.
-    // What only a panel with candidates needs (the remaining thresholds and the conditional-mean coefficients) is
-    // fetched one panel ahead into two alternating sets.
+    // ---- the opening ring ----
+    // What the opening of a panel needs — its reduced dots and one filter word per marker (k_hotlist: NaN monomorphic, -inf in
+    // the model, else the entry threshold rounded down) — plus the next panel's row-cache list travel to LDS by LDS-DMA
+    // (global_load_lds_dwordx4, 1 KiB per instruction), HB_RD - 1 panels ahead: with the mat-vec streaming at full rate a load
+    // takes microseconds, far longer than a quiet panel lasts, and a register prefetch ring does not survive hipcc (a loaded
+    // register that lives across the loop edge is copied, and the copy waits: every panel paid two loaded round trips).
+    // A DMA piece has no destination register, so the only waits are the ones written here: wave 0 issues all pieces of a
+    // group and, at the top of each panel, lets at most the youngest group stay in flight (counted vmcnt; everything the
+    // next panel's take needs has then landed, and the panel's one barrier publishes it to the other waves).
+    // A panel without candidates touches no global memory at all. A panel with candidates fetches the exact per-marker
+    // data (thresholds, conditional-mean coefficients, old effect, x'x, row-cache slot) on the spot: one round trip.
     // The reduced dots need no flag: the sweep starts with dsum[] filled with a NaN bit pattern no sum can produce,
     // every 8-byte result lands atomically, so a value is either that pattern (not there yet: re-read) or final.
-    constexpr int Q = (K1 <= 3) ? 4 : 2;
+    constexpr int HB_RD = 4;
     constexpr long long HB_SENT = -1ll; // memset 0xFF
-    double rg_d[Q], rg_thr0[Q], rg_gold[Q], rg_xx[Q];
-    int rg_slot[Q];   // row-cache slot, -1: none, -2: monomorphic marker (skipped)
-    double n_thr[2][K1], n_invv[2][K1], n_sdz[2][K1];
+    const unsigned oring_lds = (unsigned)(uintptr_t)oring;
+    // group G(x) = dots and filter of panel x + row-cache list of panel x + 1, into ring slot x mod HB_RD
+    // the NPC pieces of a group are dealt round-robin to the first RW waves (half of the workgroup; the other half fills the row
+    // cache), so that a ring wave's memory queue holds ring pieces only — which is what makes its counted wait exact
+    const int RW = S > 1 ? (S >> 1) : 1;
+    // (a piece's source is "wave-uniform base + 16 bytes per lane" whenever the dots' and the filter's segments of a panel are
+    // whole pieces, P >= 128: the global_load_lds form with a scalar base and a loop-invariant lane offset then needs no vector
+    // arithmetic and no vector temporaries per issue — hipcc guards a reused temporary with a vmcnt wait, which would stall the
+    // issue behind whatever the panel still has in flight)
+    const unsigned lane16 = (unsigned)lane * 16;
+    auto dma_piece_s = [&](const char *sbase_, unsigned lds_dst_, bool fresh) {
+        // (values that ARE wave-uniform, but that hipcc may have computed on the vector unit when scalar registers ran short)
+        const unsigned long long sb = (unsigned long long)(uintptr_t)sbase_;
+        const char *sbase = reinterpret_cast<const char *>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sb >> 32)) << 32) |
+                                                                       (unsigned)__builtin_amdgcn_readfirstlane((int)sb)));
+        const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_);
+        unsigned keep;
+        if (fresh)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane16), "s"(sbase), "s"(lds_dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane16), "s"(sbase), "s"(lds_dst) : "memory");
+    };
+    auto issue_group = [&](int x, int slot) {
+        const unsigned dst = oring_lds + (unsigned)slot * OSLOT;
+        const char *dsrc = reinterpret_cast<const char *>(v.dsum + (size_t)x * P);
+        const char *fsrc = reinterpret_cast<const char *>(pv.thr0f + (size_t)x * P);
+        const char *hsrc = reinterpret_cast<const char *>(pv.hotpack + (size_t)min(x + 1, np - 1) * HB_HS);
+        const int w = __builtin_amdgcn_readfirstlane(wave);
+        for (int i = w; i < NPC; i += RW) {
+            if (i == NPC - 1) {
+                dma_piece_s(hsrc, dst + (unsigned)OSZ, false);
+            } else if (P >= 128) {
+                const int off = i << 10; // whole piece inside one segment
+                dma_piece_s(off < 8 * P ? dsrc + off : fsrc + (off - 8 * P), dst + (unsigned)off, true);
+            } else {
+                const int off = (i << 10) + lane * 16;
+                if (off < 12 * P) {
+                    const char *src = off < 8 * P ? dsrc + off : fsrc + (off - 8 * P);
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst + ((unsigned)i << 10)))
+                                 : "memory");
+                }
+            }
+        }
+    };
+    const int my_pieces = wave < RW ? (NPC - wave + RW - 1) / RW : 0; // ring pieces this wave issues per group
     int n_nhot = 0;
-    // hot-list entry / count two panels ahead (landed by the time they are stored). The count is loaded by thread 0
-    // alone and travels through LDS: a wave-uniform load would be waited for on the spot (s_waitcnt vmcnt(0) +
-    // readfirstlane), draining every prefetch issued before it.
-    int hl_reg = 0, nh_reg = 0;
 
-    // ---- prologue: fill the ring ----
+    // ---- prologue ----
     for (int i = t; i < 128; i += P) cnts[i] = 0; // (a 64-marker panel has 64 threads; absent waves' words must read 0)
-#pragma unroll
-    for (int u = 0; u < Q; u++) {
-        const int jq = min(u, np - 1) * P + t;
-        rg_thr0[u] = v.thr[jq];
-        rg_gold[u] = v.g[jq];
-        rg_xx[u] = v.xpx[jq];
-        rg_slot[u] = pv.slot_of[jq];
-        rg_d[u] = ld_sc1(&v.dsum[jq]);
-    }
-#pragma unroll
-    for (int c = 0; c < K1; c++) {
-        n_thr[0][c] = v.thr[(size_t)c * v.m_pad + t];
-        n_invv[0][c] = v.invv[(size_t)c * v.m_pad + t];
-        n_sdz[0][c] = v.sdz[(size_t)c * v.m_pad + t];
-        n_thr[1][c] = 0.0; n_invv[1][c] = 0.0; n_sdz[1][c] = 0.0;
-    }
+    if (wave < RW)
+        for (int x = 0; x < HB_RD - 1 && x < np; x++) issue_group(x, x);
     bool ok = true;
     {   // row cache 0 for panel 0
-        n_nhot = pv.nhot[0];
+        n_nhot = pv.hotpack[0];
         const int total = n_nhot << lgP, items = (total + 255) >> 8;
         const int32_t *gp0 = v.gram;
         for (int it = wave; it < items; it += S) {
             const int lin = min((it << 8) + lane * 4, total - 4);
-            const int k = pv.hotlist[lin >> lgP];
+            const int k = pv.hotpack[4 + (lin >> lgP)];
             *reinterpret_cast<int4 *>(rowc0 + lin) = *reinterpret_cast<const int4 *>(gp0 + ((size_t)k << lgP) + (lin & (P - 1)));
         }
     }
-    if (np > 1) {
-        if (t < nslot) hl_reg = pv.hotlist[(size_t)nslot + t];
-        if (t == 0) nh_reg = pv.nhot[1];
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // The ring registers need static indices, everything else does not: only the three small ring accesses of a panel are
-    // instantiated Q times (a uniform switch on p mod Q picks the copy); the rest of the loop body exists once, which keeps
-    // the kernel inside the instruction cache.
-    auto ring_switch = [&](int pp, auto &&f) {
-        switch (pp & (Q - 1)) {
-        case 0: f(std::integral_constant<int, 0>{}); break;
-        case 1: f(std::integral_constant<int, 1 % Q>{}); break;
-        case 2: f(std::integral_constant<int, 2 % Q>{}); break;
-        default: f(std::integral_constant<int, 3 % Q>{}); break;
-        }
-    };
+    int oslot = -1; // p mod HB_RD
     int pmodD = -1; // p mod D, without a division per panel
     for (int p = 0; ok && p < np; p++) {
         pmodD = (pmodD + 1 == pv.D) ? 0 : pmodD + 1;
         pslot = (pslot + 1 == R) ? 0 : pslot + 1;
+        oslot = (oslot + 1 == HB_RD) ? 0 : oslot + 1;
         const int j = p * P + t;
         const int cur = p & 1;
         int32_t *rowc = rowc0 + (size_t)cur * nslot * P;
         int32_t *rown = rowc0 + (size_t)(cur ^ 1) * nslot * P;
         const int32_t *gp = v.gram + (size_t)p * (pv.Lb + 1) * P * P;
-        int *hl = hl0 + (size_t)cur * P, *s_nh = s_nh0 + cur, *wcnt = wcnt0 + (cur << 5);
+        int *wcnt = wcnt0 + (cur << 5);
+        const char *oslotp = oring + (size_t)oslot * OSLOT;
         HB_STAMP(0);
-        // ---- take over the prefetched panel ----
-        double dj = 0.0, gold = 0.0, xx = 0.0, thr0v = 0.0;
-        int myslot = -2;
-        ring_switch(p, [&](auto U) {
-            constexpr int u = decltype(U)::value;
-            dj = rg_d[u];
-            gold = rg_gold[u];
-            xx = rg_xx[u];
-            myslot = rg_slot[u];
-            thr0v = rg_thr0[u];
-        });
+        // ring waves: the group of panel p + 1 has landed once at most the youngest group (panel p + 2's) is still in flight;
+        // the barrier below hands it to everybody before the next panel's take
+        if (wave < RW) {
+            if (S == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a 64-marker panel: the same wave also fills the row cache)
+            else if (my_pieces == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (my_pieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        }
+        // ---- take over the panel: LDS only ----
+        double dj = reinterpret_cast<const double *>(oslotp)[t];
+        const float fthr = reinterpret_cast<const float *>(oslotp + 8 * P)[t];
         bool aborted = false;
         {
             bool bad = __double_as_longlong(dj) == HB_SENT;
@@ -1240,30 +1279,28 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                 }
             }
         }
-        double thr[K1], invv[K1], sdz[K1];
-        thr[0] = thr0v;
-        double rhs = dj;
-        if (gold != 0.0) rhs = fma(xx, gold, rhs);
+        double corrv;
         {
             double *cp = corrL + (size_t)pslot * P + t;
-            rhs -= *cp;
+            corrv = *cp;
             *cp = 0.0; // the slot is panel p + R's from now on
         }
-        const bool active = myslot > -2;
-        const bool hot = active && gold != 0.0;
+        const bool active = fthr == fthr;                          // not NaN: a polymorphic marker
+        const bool hot = fthr == -__int_as_float(0x7f800000);      // in the model: certain to move
         const bool have_next = p + 1 < np;
         const bool group_end = have_next && pmodD == pv.D - 1;
         const int32_t *gpn = gp + (size_t)(pv.Lb + 1) * P * P;
-        {   // who can move at all: certain movers and markers near their entry threshold (first round of the chain)
-            const unsigned long long cm0 = __ballot(active && (hot || rhs * rhs >= pv.candf * thr[0]));
+        // who can move at all: certain movers and markers whose q reaches the (rounded-down) entry threshold. For a marker at
+        // zero rhs = d - corrections; the exact test follows in the chain.
+        bool cand0;
+        {
+            const double r0 = dj - corrv;
+            cand0 = active && (hot || r0 * r0 >= pv.candf * (double)fthr);
+            const unsigned long long cm0 = __ballot(cand0);
             if (lane == 0) wcnt[wave] = __popcll(cm0) | (aborted ? 0x10000 : 0);
         }
-        if (have_next) {
-            if (t < nslot) hl[t] = hl_reg; // fetched one panel ago
-            if (t == 0) *s_nh = nh_reg;
-        }
         HB_STAMP(1);
-        __syncthreads(); // the panel's one fixed barrier: wcnt[], hl[], *s_nh staged; everybody is done with panel p-1
+        __syncthreads(); // the panel's one fixed barrier: wcnt[] staged, ring group of panel p + 1 published; everybody is done with panel p-1
         int tot0 = 0;
         {
             int w8[8];
@@ -1272,61 +1309,26 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             for (int w = 0; w < 8; w++) tot0 += w8[w];
         }
         if (tot0 >> 16) { ok = false; break; } // a wave gave up waiting for its dots: the sweep is aborted
-        if (have_next) n_nhot = *s_nh;
-        const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
-        // ---- prefetch: issued oldest-needed first, nothing waited for ----
-        // (0) the next panel's dot once more: when the ring slot was filled, Q panels ago, it may not have been written yet.
-        // The later load simply lands on top of the earlier one. It is the first request of the panel because it is the
-        // first to be used: the memory counter is in-order, so everything issued before a load is waited for with it.
-        // (1) Gram rows of the next panel's hot markers, straight into the other half of the LDS row cache by LDS-DMA
-        // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no destination registers, so nothing here is ever waited for
-        // by the compiler's bookkeeping; the first reader of that half — the first round of the next panel that has
-        // candidates — drains vmcnt before its barrier). A quiet panel never waits for them.
-        if (have_next) {
-            const unsigned rown_lds = (unsigned)(uintptr_t)rown;
-            for (int it = wave; it < n_items; it += S) {
-                const int lin = (it << 8) + lane * 4;
-                if (lin < n_total) {
-                    const int32_t *src = gpn + ((size_t)hl[lin >> lgP] << lgP) + (lin & (P - 1));
-                    unsigned keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep)
-                                 : "v"(src), "s"(__builtin_amdgcn_readfirstlane(rown_lds + ((unsigned)it << 10)))
-                                 : "memory");
-                }
+        // (2) a panel with candidates: the exact per-marker data, one round trip
+        double thr[K1], invv[K1], sdz[K1];
+        double gold = 0.0, rhs = 0.0;
+        int myslot = -1;
+#pragma unroll
+        for (int c = 0; c < K1; c++) { thr[c] = HB_INF; invv[c] = 0.0; sdz[c] = 0.0; }
+        if (tot0 > 0) {
+            gold = v.g[j];
+            const double xx = v.xpx[j];
+            myslot = pv.slot_of[j];
+#pragma unroll
+            for (int c = 0; c < K1; c++) {
+                thr[c] = v.thr[(size_t)c * v.m_pad + j];
+                invv[c] = v.invv[(size_t)c * v.m_pad + j];
+                sdz[c] = v.sdz[(size_t)c * v.m_pad + j];
             }
+            rhs = dj;
+            if (gold != 0.0) rhs = fma(xx, gold, rhs);
+            rhs -= corrv;
         }
-        // (2) the next panel's candidate coefficients, (3) the hot-list two panels ahead, (4) ring slot u <- panel p + Q;
-        // this panel's candidate coefficients arrived a panel ago
-        ring_switch(p, [&](auto U) {
-            constexpr int u = decltype(U)::value;
-            constexpr int sa = u & 1, sb = sa ^ 1;
-            // (addresses as wave-uniform panel base + lane index: the scalar unit does the 64-bit part)
-            const size_t o1 = (size_t)min(p + 1, np - 1) * P;
-#pragma unroll
-            for (int c = 0; c < K1; c++) {
-                const size_t oc = (size_t)c * v.m_pad + o1;
-                if (c > 0) n_thr[sb][c] = (v.thr + oc)[t];
-                n_invv[sb][c] = (v.invv + oc)[t];
-                n_sdz[sb][c] = (v.sdz + oc)[t];
-            }
-            if (p + 2 < np) {
-                if (t < nslot) hl_reg = (pv.hotlist + (size_t)(p + 2) * nslot)[t];
-                if (t == 0) nh_reg = pv.nhot[p + 2];
-            }
-            const size_t oq = (size_t)min(p + Q, np - 1) * P;
-            rg_thr0[u] = (v.thr + oq)[t];
-            rg_gold[u] = (v.g + oq)[t];
-            rg_xx[u] = (v.xpx + oq)[t];
-            rg_slot[u] = (pv.slot_of + oq)[t];
-            rg_d[u] = ld_sc1(v.dsum + oq + t);
-#pragma unroll
-            for (int c = 0; c < K1; c++) {
-                if (c > 0) thr[c] = n_thr[sa][c];
-                invv[c] = n_invv[sa][c];
-                sdz[c] = n_sdz[sa][c];
-            }
-        });
         HB_STAMP(7);
 
         // ---- the serial chain, speculatively compacted ----
@@ -1345,7 +1347,8 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             bool first = true; // the first round's candidate counts were staged before the panel's opening barrier
             for (;;) {
                 const bool undec = t >= t_lo;
-                const bool isc = undec && active && (hot || forced || rhs * rhs >= pv.candf * thr[0]);
+                // (the first round's counts were taken with the opening filter: the same predicate must rank them)
+                const bool isc = first ? cand0 : (undec && active && (hot || forced || rhs * rhs >= pv.candf * thr[0]));
                 const unsigned long long cm = __ballot(isc);
                 if (!first) {
                     if (lane == 0) wcnt[wave] = __popcll(cm);
@@ -1445,9 +1448,9 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
                     if (crowded) {
                         // Dense round: the Gram entries were gathered into cg[][] (zero on and below the diagonal, so a move of
                         // lane k leaves lanes <= k alone without a compare). The loop is software-pipelined around its only
-                        // loop-carried value, crhs: the rows of cg travel two steps ahead of their use (an LDS read takes ~100
-                        // cycles), a certain mover needs no ballot, and a zero change needs no branch (it adds an exact zero).
-                        int r1 = cg[lane], r2 = cg[(ncr > 1 ? 64 : 0) + lane];
+                        // loop-carried value, crhs: row k + 1 of cg is fetched (and converted) while step k decides, a certain
+                        // mover needs no ballot, and a zero change needs no branch (it adds an exact zero).
+                        int r1 = cg[lane], r2 = cg[(ncr > 1 ? 64 : 0) + lane]; // rows k + 1 and k + 2 in flight (two deep: a read takes ~100 cycles)
                         double gnx = (double)r1;
                         r1 = r2;
                         for (int k = 0; k < ncr; k++) {
@@ -1620,6 +1623,7 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
         } else {
             cacc[0] += active ? 1 : 0; // a quiet panel: nothing moved, nothing to write
         }
+        HB_STAMP(8);
         if (wave == S - 1 && group_end) {
             // last panel of its mat-vec group: the update of this group is waiting for exactly these moves, and the
             // next panel's take may itself have to wait for a later launch — publish now rather than at that take
@@ -1627,6 +1631,43 @@ __global__ __launch_bounds__(512) void k_chain_persist(const hb_sweep_in *__rest
             gcount++;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(p + 1));
+        }
+        HB_STAMP(9);
+        // ---- requests for the panels ahead, as the LAST thing of the panel: hipcc's own waits count only the loads it knows,
+        // so any of them placed after a DMA piece would drain that piece as well (the queue is in-order); issued here, the
+        // pieces have the whole next panel — which, when quiet, contains no vector-memory wait at all — to land ----
+        // (0) ring group of panel p + HB_RD - 1, into the slot panel p - 1 has just left
+        if (wave < RW && p + HB_RD - 1 < np) issue_group(p + HB_RD - 1, (oslot + HB_RD - 1) % HB_RD);
+        // (1) Gram rows of the next panel's hot markers, straight into the other half of the LDS row cache by LDS-DMA; the
+        // first reader of that half — the first round of the next panel that has candidates — drains vmcnt before its
+        // barrier. A quiet panel never waits for them. (Wave 0 is left out when there are other waves: its memory queue
+        // then holds ring groups only, which is what makes its counted wait at the top of the panel exact.)
+        const int *hpk = reinterpret_cast<const int *>(oslotp + OSZ); // packed list of panel p + 1 (came with group p)
+        if (have_next) n_nhot = hpk[0];
+        const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
+        if (have_next && (S == 1 || wave >= RW)) {
+            const unsigned rown_lds = (unsigned)(uintptr_t)rown;
+            const int w0 = S == 1 ? 0 : wave - RW, ws = S == 1 ? 1 : S - RW;
+            if (P >= 256) { // a piece is (part of) ONE row: scalar base, invariant lane offset
+                const int w0u = __builtin_amdgcn_readfirstlane(w0);
+                const int lg = lgP - 8; // pieces per row = P / 256
+                for (int it = w0u; it < n_items; it += ws) {
+                    const int kk = __builtin_amdgcn_readfirstlane(hpk[4 + (it >> lg)]);
+                    const int32_t *srow = gpn + ((size_t)kk << lgP) + ((it & ((1 << lg) - 1)) << 8);
+                    dma_piece_s(reinterpret_cast<const char *>(srow), rown_lds + ((unsigned)it << 10), false);
+                }
+            } else
+            for (int it = w0; it < n_items; it += ws) {
+                const int lin = (it << 8) + lane * 4;
+                if (lin < n_total) {
+                    const int32_t *src = gpn + ((size_t)hpk[4 + (lin >> lgP)] << lgP) + (lin & (P - 1));
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(src), "s"(__builtin_amdgcn_readfirstlane(rown_lds + ((unsigned)it << 10)))
+                                 : "memory");
+                }
+            }
         }
         HB_STAMP(6);
         // no closing barrier: the next panel's opening barrier separates every reuse of the LDS lists, the candidate
@@ -1974,7 +2015,8 @@ static inline int kpad_for(int model, int n_fold)
 
 // LDS budget of k_chain: as many Gram rows as fit beside the event lists
 static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128 + 128 + 64)) / ((size_t)P * 4)); }
-#define HB_PERSIST_FIXED(P, LB) ((size_t)(P) * 20 + 128 + 512 + 64 * (8 * (3 + 3 * 7) + 12) + 64 * 64 * 4 + (size_t)((LB) + 1) * (P) * 8)
+#define HB_PERSIST_RING(P) ((size_t)4 * ((((size_t)12 * (P) + 1023) >> 10 << 10) + 1024)) /* HB_RD slots of the opening ring */
+#define HB_PERSIST_FIXED(P, LB) ((size_t)(P) * 20 + 128 + 512 + 64 * (8 * (3 + 3 * 7) + 12) + 64 * 64 * 4 + (size_t)((LB) + 1) * (P) * 8 + HB_PERSIST_RING(P))
 static int persist_nslot(int P, int Lb) { return std::min(P, std::min(160, (int)((160 * 1024 - HB_PERSIST_FIXED(P, Lb)) / ((size_t)P * 8)))); }
 // the whole 160 KiB: nothing that needs LDS (mat-vec, update) can then be co-scheduled on the chain's CU
 static size_t persist_smem(int) { return (size_t)160 * 1024; }
@@ -2266,7 +2308,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     }
     const int ns = persist_nslot(c->P, c->L);
     hipLaunchKernelGGL(k_hotlist, dim3(np), dim3(c->P), 0, sA, c->d_in, c->vx, c->g, c->thr, c->xpx, c->kappa, c->P, ns, c->hot_slot,
-                       c->hot_list, c->hot_n, c->tracker);
+                       c->hot_list, c->thr0f, c->tracker);
     HB_HIP(hipEventRecord(c->ev_fork, sA));
     HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
     const double xabs = std::max(std::abs((double)c->xmin), std::abs((double)c->xmax));
@@ -2275,7 +2317,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
                   c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
     const int last_panels = np - (ngroups - 1) * D;
     persist_view pv{np, D, Lv, c->L, c->flags,
-                    c->hot_slot, c->hot_list, c->hot_n, c->candf};
+                    c->hot_slot, c->hot_list, c->thr0f, c->candf};
     {
         hipError_t e = kp == 1 ? launch_chain_persist<1>(c, cv, pv, sB) : kp == 3 ? launch_chain_persist<3>(c, cv, pv, sB)
                                                                                  : launch_chain_persist<7>(c, cv, pv, sB);
