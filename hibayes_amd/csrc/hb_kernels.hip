@@ -1113,13 +1113,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     char *base = smem + (size_t)2 * nslot * P * 4;
     double *ev_del = reinterpret_cast<double *>(base);
     int *ev_ix = reinterpret_cast<int *>(base + (size_t)P * 8);
-    double *red = reinterpret_cast<double *>(base + (size_t)P * 20);
-    int *cnts = reinterpret_cast<int *>(base + (size_t)P * 20 + 128);
+    double *red = reinterpret_cast<double *>(base + (size_t)P * 12);
+    int *cnts = reinterpret_cast<int *>(base + (size_t)P * 12 + 128);
     int *s_thi = cnts + 18;   // first candidate left for the next round
     int *wcnt0 = cnts + 32;   // candidates per wave: [32..47] even panels, [64..79] odd panels
     int *wviol = cnts + 48;   // wave saw a mis-speculated marker
     // staging of one round's candidates (<= 64): [field][candidate]
-    double *cs_d = reinterpret_cast<double *>(base + (size_t)P * 20 + 128 + 512); // rhs, gold, thr[K1], invv[K1], sdz[K1]
+    double *cs_d = reinterpret_cast<double *>(base + (size_t)P * 12 + 128 + 512); // rhs, gold, thr[K1], invv[K1], sdz[K1]
     double *res_g = cs_d + (2 + 3 * K1) * 64;
     int *cs_t = reinterpret_cast<int *>(res_g + 64);
     int *cs_slot = cs_t + 64;
@@ -2016,8 +2016,10 @@ static inline int kpad_for(int model, int n_fold)
 // LDS budget of k_chain: as many Gram rows as fit beside the event lists
 static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128 + 128 + 64)) / ((size_t)P * 4)); }
 #define HB_PERSIST_RING(P) ((size_t)4 * ((((size_t)12 * (P) + 1023) >> 10 << 10) + 1024)) /* HB_RD slots of the opening ring */
-#define HB_PERSIST_FIXED(P, LB) ((size_t)(P) * 20 + 128 + 512 + 64 * (8 * (3 + 3 * 7) + 12) + 64 * 64 * 4 + (size_t)((LB) + 1) * (P) * 8 + HB_PERSIST_RING(P))
-static int persist_nslot(int P, int Lb) { return std::min(P, std::min(160, (int)((160 * 1024 - HB_PERSIST_FIXED(P, Lb)) / ((size_t)P * 8)))); }
+// move lists (12 B per marker) + reduction / counter words + one round's candidate staging (sized by the model's K1 non-null classes)
+// + the 64 x 64 block of mutual Gram entries + the correction ring + the opening ring; the rest is the double-buffered row cache
+#define HB_PERSIST_FIXED(P, LB, K1) ((size_t)(P) * 12 + 128 + 512 + 64 * (8 * (3 + 3 * (K1)) + 12) + 64 * 64 * 4 + (size_t)((LB) + 1) * (P) * 8 + HB_PERSIST_RING(P))
+static int persist_nslot(int P, int Lb, int K1) { return std::min(P, std::min(160, (int)((160 * 1024 - HB_PERSIST_FIXED(P, Lb, K1)) / ((size_t)P * 8)))); }
 // the whole 160 KiB: nothing that needs LDS (mat-vec, update) can then be co-scheduled on the chain's CU
 static size_t persist_smem(int) { return (size_t)160 * 1024; }
 static size_t chain_smem(int P) { return (size_t)chain_nslot(P) * P * 4 + (size_t)P * 16 + 128 + 128 + 64; }
@@ -2282,7 +2284,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
 template <int K1>
 static hipError_t launch_chain_persist(hb_ctx *c, const chain_view &cv, const persist_view &pv, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_chain_persist<K1>, dim3(1), dim3(c->P), persist_smem(c->P), st, c->d_in, cv, pv, persist_nslot(c->P, c->L));
+    hipLaunchKernelGGL(k_chain_persist<K1>, dim3(1), dim3(c->P), persist_smem(c->P), st, c->d_in, cv, pv, persist_nslot(c->P, c->L, K1));
     return hipGetLastError();
 }
 
@@ -2306,7 +2308,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
         pre_view pvw{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
         hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pvw);
     }
-    const int ns = persist_nslot(c->P, c->L);
+    const int ns = persist_nslot(c->P, c->L, kp);
     hipLaunchKernelGGL(k_hotlist, dim3(np), dim3(c->P), 0, sA, c->d_in, c->vx, c->g, c->thr, c->xpx, c->kappa, c->P, ns, c->hot_slot,
                        c->hot_list, c->thr0f, c->tracker);
     HB_HIP(hipEventRecord(c->ev_fork, sA));
