@@ -1109,8 +1109,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int P = v.P, S = P >> 6;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    int32_t *rowc0 = reinterpret_cast<int32_t *>(smem);                       // two row caches of nslot rows
-    char *base = smem + (size_t)2 * nslot * P * 4;
+    // ONE row cache of nslot rows: the next panel's rows are requested (LDS-DMA) as the last thing of a panel, after the last
+    // barrier of its rounds — nobody reads the cache between that barrier and the next panel's first round, which drains the
+    // pieces — so the fill can go straight on top of the rows just used and the LDS a second buffer would take holds rows instead
+    int32_t *rowc0 = reinterpret_cast<int32_t *>(smem);
+    char *base = smem + (size_t)nslot * P * 4;
     double *ev_del = reinterpret_cast<double *>(base);
     int *ev_ix = reinterpret_cast<int *>(base + (size_t)P * 8);
     double *red = reinterpret_cast<double *>(base + (size_t)P * 12);
@@ -1240,8 +1243,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         oslot = (oslot + 1 == HB_RD) ? 0 : oslot + 1;
         const int j = p * P + t;
         const int cur = p & 1;
-        int32_t *rowc = rowc0 + (size_t)cur * nslot * P;
-        int32_t *rown = rowc0 + (size_t)(cur ^ 1) * nslot * P;
+        int32_t *rowc = rowc0;
+        int32_t *rown = rowc0;
         const int32_t *gp = v.gram + (size_t)p * (pv.Lb + 1) * P * P;
         int *wcnt = wcnt0 + (cur << 5);
         const char *oslotp = oring + (size_t)oslot * OSLOT;
@@ -2019,7 +2022,7 @@ static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128
 // move lists (12 B per marker) + reduction / counter words + one round's candidate staging (sized by the model's K1 non-null classes)
 // + the 64 x 64 block of mutual Gram entries + the correction ring + the opening ring; the rest is the double-buffered row cache
 #define HB_PERSIST_FIXED(P, LB, K1) ((size_t)(P) * 12 + 128 + 512 + 64 * (8 * (3 + 3 * (K1)) + 12) + 64 * 64 * 4 + (size_t)((LB) + 1) * (P) * 8 + HB_PERSIST_RING(P))
-static int persist_nslot(int P, int Lb, int K1) { return std::min(P, std::min(160, (int)((160 * 1024 - HB_PERSIST_FIXED(P, Lb, K1)) / ((size_t)P * 8)))); }
+static int persist_nslot(int P, int Lb, int K1) { return std::min(P, std::min(250, (int)((160 * 1024 - HB_PERSIST_FIXED(P, Lb, K1)) / ((size_t)P * 4)))); }
 // the whole 160 KiB: nothing that needs LDS (mat-vec, update) can then be co-scheduled on the chain's CU
 static size_t persist_smem(int) { return (size_t)160 * 1024; }
 static size_t chain_smem(int P) { return (size_t)chain_nslot(P) * P * 4 + (size_t)P * 16 + 128 + 128 + 64; }
