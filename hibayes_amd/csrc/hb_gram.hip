@@ -7,6 +7,7 @@
 // v_mfma_i32_32x32x32_i8 straight from one 16-byte global load, no LDS transpose.
 // One wave = one 64x64 block of the panel's P x P matrix (2x2 MFMA tiles of 32x32).
 #include "hb_internal.hpp"
+#include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -57,8 +58,83 @@ __global__ __launch_bounds__(64) void k_gram(const int8_t *__restrict__ X, int64
             }
 }
 
+// The same blocks for P >= 256, one 256 x 256 tile per workgroup of 16 waves (4 x 4 wave tiles of 64 x 64): per 64-row step the
+// 256 + 256 operand columns are staged through LDS once (16-byte global loads into registers one step ahead, ds_write_b128 with
+// an 80-byte column stride so that the MFMA operand reads are bank-conflict free) instead of being re-read from global memory by
+// every wave tile — 4x less traffic than k_gram (9.5 TB -> 1.8 TB of fetches for the 18 GB band at n=50k, m=500k).
+#define HG_T 256
+#define HG_KS 64
+#define HG_CS 80 /* bytes per staged column: 64 + 16 */
+__global__ __launch_bounds__(1024) void k_gram_tiled(const int8_t *__restrict__ X, int64_t ld, int P, int L, int32_t *__restrict__ gram)
+{
+    __shared__ __attribute__((aligned(16))) char sa[HG_T * HG_CS], sb[HG_T * HG_CS];
+    const int nt = P / HG_T;
+    const int pl = blockIdx.x / (nt * nt);
+    const int p = pl / (L + 1), l = pl % (L + 1);
+    if (p - l < 0) return;
+    const int rem = blockIdx.x % (nt * nt);
+    const int ti = rem / nt, tj = rem % nt;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 2, wc = wave & 3;
+    // staging: thread -> (column tid / 4, 16-byte part tid % 4) of both operand tiles
+    const int scol = tid >> 2, spart = tid & 3;
+    const int8_t *ga = X + ((int64_t)(p - l) * P + ti * HG_T + scol) * ld + spart * 16;
+    const int8_t *gb = X + ((int64_t)p * P + tj * HG_T + scol) * ld + spart * 16;
+    char *wa = sa + scol * HG_CS + spart * 16, *wb = sb + scol * HG_CS + spart * 16;
+    // MFMA operands: lane & 31 = column inside the 32-wide sub-tile, lane >> 5 = which 16 of the 32 k values
+    const char *ra = sa + (wr * 64 + (lane & 31)) * HG_CS + (lane >> 5) * 16;
+    const char *rb = sb + (wc * 64 + (lane & 31)) * HG_CS + (lane >> 5) * 16;
+    v16i acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
+    v4i na = *reinterpret_cast<const v4i *>(ga), nb = *reinterpret_cast<const v4i *>(gb);
+    for (int64_t kk = 0; kk < ld; kk += HG_KS) {
+        __syncthreads(); // everybody is done reading the previous step
+        *reinterpret_cast<v4i *>(wa) = na;
+        *reinterpret_cast<v4i *>(wb) = nb;
+        __syncthreads();
+        if (kk + HG_KS < ld) { // next step's operands travel while this one is multiplied
+            na = *reinterpret_cast<const v4i *>(ga + kk + HG_KS);
+            nb = *reinterpret_cast<const v4i *>(gb + kk + HG_KS);
+        }
+#pragma unroll
+        for (int ks = 0; ks < HG_KS; ks += 32) {
+            const v4i a0 = *reinterpret_cast<const v4i *>(ra + ks);
+            const v4i a1 = *reinterpret_cast<const v4i *>(ra + 32 * HG_CS + ks);
+            const v4i b0 = *reinterpret_cast<const v4i *>(rb + ks);
+            const v4i b1 = *reinterpret_cast<const v4i *>(rb + 32 * HG_CS + ks);
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    int32_t *gp = gram + (size_t)pl * P * P;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = ti * HG_T + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = tj * HG_T + wc * 64 + b * 32 + (lane & 31);
+                gp[(size_t)row * P + col] = acc[a][b][r];
+            }
+}
+
 int hb_build_gram_impl(hb_ctx *c)
 {
+    if (c->P >= HG_T && !getenv("HB_GRAM_UNTILED")) {
+        const int nt = c->P / HG_T;
+        hipLaunchKernelGGL(k_gram_tiled, dim3((unsigned)(c->npanels * (c->L + 1) * nt * nt)), dim3(1024), 0, c->stream, c->X, c->ld,
+                           c->P, c->L, c->gram);
+        HB_HIP(hipGetLastError());
+        return HB_OK;
+    }
     const int nb = c->P / 64;
     hipLaunchKernelGGL(k_gram, dim3((unsigned)(c->npanels * (c->L + 1) * nb * nb)), dim3(64), 0, c->stream, c->X, c->ld, c->P,
                        c->L, c->gram);
