@@ -127,7 +127,7 @@ SYMBOLS = [
     "hb_ctx_marker_stats", "hb_ctx_build_gram", "hb_ctx_download_gram", "hb_ctx_set_residual",
     "hb_ctx_get_residual", "hb_ctx_set_effects", "hb_ctx_get_effects", "hb_ctx_dot", "hb_ctx_residual_sums",
     "hb_ctx_residual_shift", "hb_ctx_set_covariates", "hb_ctx_cov_dot", "hb_ctx_cov_axpy", "hb_ctx_set_levels",
-    "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_sweep", "hb_ctx_get_counters", "hb_ctx_set_windows",
+    "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_blocks_setup", "hb_ctx_blocks_step", "hb_ctx_blocks_state", "hb_ctx_sweep", "hb_ctx_get_counters", "hb_ctx_set_windows",
     "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec",
     "hb_ctx_download_gram_band", "hb_ctx_get_pipeline", "hb_ctx_get_events", "hb_ctx_pipeline_note", "hb_ctx_matmul",
     "hb_comm_unique_id", "hb_comm_init", "hb_comm_world", "hb_comm_rank", "hb_comm_destroy",
@@ -144,7 +144,18 @@ def lib():
         raise ImportError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). hibayes_amd has no CPU fallback." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    # ONE HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64 / librccl (sonames without a version, so
+    # they do not dedupe against /opt/rocm's) and load them RTLD_GLOBAL: whichever is loaded first wins the symbol lookup of
+    # everything loaded later. If torch arrived between two first calls into a lazily bound library, its hip* calls would be
+    # split over two runtimes (a stream of one handed to the other: "unhandled cuda error" from RCCL). So where torch is
+    # importable it is loaded first — this library, the RCCL it dlopen()s and torch's tensors (TorchComm's exchange buffer)
+    # then all sit on the same runtime — and every symbol is bound at load time, not at first call.
+    if not os.environ.get("HIBAYES_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(LIB_PATH, mode=os.RTLD_NOW)
     L.hb_version.restype = C.c_char_p
     L.hb_last_error.restype = C.c_char_p
     L.hb_exchange_count.restype = C.c_size_t
@@ -190,6 +201,9 @@ def lib():
     L.hb_ctx_set_levels.argtypes = [vp, vp, i32, vp]
     L.hb_ctx_level_sums.argtypes = [vp, i32, vp]
     L.hb_ctx_level_axpy.argtypes = [vp, i32, vp]
+    L.hb_ctx_blocks_setup.argtypes = [vp, vp, vp, vp]
+    L.hb_ctx_blocks_step.argtypes = [vp, dbl, vp, vp, vp, dbl, dbl]
+    L.hb_ctx_blocks_state.argtypes = [vp, vp, vp, vp, vp]
     L.hb_ctx_sweep.argtypes = [vp, C.POINTER(SweepIn), C.POINTER(SweepOut)]
     L.hb_ctx_get_counters.argtypes = [vp, vp, vp, vp]
     L.hb_ctx_set_windows.argtypes = [vp, vp, i32]

@@ -26,6 +26,9 @@ int hbk_generate(hb_ctx *c, uint64_t seed, int mono_every);
 int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out);
 int hbk_time_matvec(hb_ctx *c, int D, int reps, int as_pipeline, double *avg_us, int *launches);
 int hbk_probe_concurrency(hb_ctx *c, int *concurrent);
+int hbk_cov_step(hb_ctx *c, int i, double v, double vare, double z, double *beta_i);
+int hbk_lev_step(hb_ctx *c, int term, int q0, int qr, const double *zz, double *estR, const double *z, double vare, double *vrtmp,
+                 double *vr, double s2r_dfr, double chis);
 int hbk_xmat(hb_ctx *c, const int *didx, const double *dval, int nnz, double *dout);
 
 static thread_local std::string g_err;
@@ -232,6 +235,8 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     return HB_OK;
 }
 
+static void blocks_free(hb_ctx *c);
+
 void hb_ctx_destroy(hb_ctx *c)
 {
     if (!c) return;
@@ -251,6 +256,7 @@ void hb_ctx_destroy(hb_ctx *c)
                     c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    blocks_free(c);
     if (c->h_acc) (void)hipHostFree(c->h_acc);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
@@ -629,6 +635,7 @@ static int fetch_acc(hb_ctx *c)
 {
     HB_HIP(hipMemcpyAsync(c->h_acc, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipMemcpyAsync(c->h_flags, c->flags, 16, hipMemcpyDeviceToHost, c->stream));
+    if (c->blk_n) HB_HIP(hipMemcpyAsync(c->h_blk, c->blk, sizeof(double) * c->blk_n, hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
     if (c->h_flags[1]) return hb_fail(HB_ERR_HIP, "device pipeline timed out waiting on a flag (sweep aborted)");
     return HB_OK;
@@ -741,6 +748,77 @@ int hb_ctx_level_axpy(hb_ctx *c, int32_t term, const double *delta)
 
 // one sweep in two halves, so that a caller can enqueue more work on the stream (the multi-GPU exchange) before the single
 // host synchronisation of the iteration
+static void blocks_free(hb_ctx *c)
+{
+    if (c->blk) (void)hipFree(c->blk);
+    if (c->blk_zz) (void)hipFree(c->blk_zz);
+    if (c->blk_z) (void)hipFree(c->blk_z);
+    if (c->h_blk) (void)hipHostFree(c->h_blk);
+    if (c->h_z) (void)hipHostFree(c->h_z);
+    c->blk = c->blk_zz = c->blk_z = c->h_blk = c->h_z = nullptr;
+    c->blk_n = 0;
+}
+
+int hb_ctx_blocks_setup(hb_ctx *c, const double *cpc, const double *zz, const double *vrtmp0)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_blocks_setup");
+    if (rc) return rc;
+    blocks_free(c);
+    c->blk_cpc.assign(cpc, cpc + c->nc);
+    const int nb = c->nc + c->lev_total + 2 * c->nr;
+    if (nb == 0) return HB_OK;
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->blk), sizeof(double) * nb));
+    HB_HIP(hipMemset(c->blk, 0, sizeof(double) * nb));
+    HB_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_blk), sizeof(double) * nb));
+    std::memset(c->h_blk, 0, sizeof(double) * nb);
+    if (c->lev_total) {
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->blk_zz), sizeof(double) * c->lev_total));
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->blk_z), sizeof(double) * c->lev_total));
+        HB_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_z), sizeof(double) * c->lev_total));
+        HB_HIP(hipMemcpy(c->blk_zz, zz, sizeof(double) * c->lev_total, hipMemcpyHostToDevice));
+        HB_HIP(hipMemcpy(c->blk + c->nc + c->lev_total, vrtmp0, sizeof(double) * c->nr, hipMemcpyHostToDevice));
+    }
+    c->blk_n = nb;
+    return HB_OK;
+}
+
+int hb_ctx_blocks_step(hb_ctx *c, double vare, const double *z_beta, const double *z_levels, const double *chisq, double dfr, double s2r)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_blocks_step");
+    if (rc) return rc;
+    if (c->nc + c->nr == 0) return HB_OK;
+    if (!c->blk) return hb_fail(HB_ERR_INVALID, "hb_ctx_blocks_step: call hb_ctx_blocks_setup first");
+    for (int i = 0; i < c->nc; i++) {
+        rc = hbk_cov_step(c, i, c->blk_cpc[i], vare, z_beta[i], c->blk + i);
+        if (rc) return rc;
+    }
+    if (c->nr) {
+        std::memcpy(c->h_z, z_levels, sizeof(double) * c->lev_total); // pinned staging: the caller's array may be a temporary
+        HB_HIP(hipMemcpyAsync(c->blk_z, c->h_z, sizeof(double) * c->lev_total, hipMemcpyHostToDevice, c->stream));
+        double *estR = c->blk + c->nc, *vrtmp = estR + c->lev_total, *vr = vrtmp + c->nr;
+        for (int t = 0; t < c->nr; t++) {
+            rc = hbk_lev_step(c, t, c->lev_first[t], c->nlev[t], c->blk_zz, estR, c->blk_z, vare, vrtmp + t, vr + t, s2r * dfr, chisq[t]);
+            if (rc) return rc;
+        }
+    }
+    return HB_OK;
+}
+
+int hb_ctx_blocks_state(hb_ctx *c, double *beta, double *estR, double *vrtmp, double *vr)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_blocks_state");
+    if (rc) return rc;
+    if (!c->blk_n) return HB_OK;
+    HB_HIP(hipMemcpyAsync(c->h_blk, c->blk, sizeof(double) * c->blk_n, hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    const double *h = c->h_blk;
+    if (beta) std::memcpy(beta, h, sizeof(double) * c->nc);
+    if (estR) std::memcpy(estR, h + c->nc, sizeof(double) * c->lev_total);
+    if (vrtmp) std::memcpy(vrtmp, h + c->nc + c->lev_total, sizeof(double) * c->nr);
+    if (vr) std::memcpy(vr, h + c->nc + c->lev_total + c->nr, sizeof(double) * c->nr);
+    return HB_OK;
+}
+
 int hb_ctx_sweep_begin(hb_ctx *c, const hb_sweep_in *in)
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_sweep");

@@ -100,6 +100,11 @@ struct hb_ctx {
     std::vector<int> nlev, lev_first;
     double *lev_buf = nullptr;
     int lev_total = 0;
+    // device-resident state of the covariate / random-effect blocks (hb_ctx_blocks_*): [beta nc][estR lev_total][vrtmp nr][vr nr]
+    double *blk = nullptr, *h_blk = nullptr; // device, pinned mirror
+    double *blk_zz = nullptr, *blk_z = nullptr, *h_z = nullptr; // level counts, this iteration's level deviates (device, pinned staging)
+    int blk_n = 0;
+    std::vector<double> blk_cpc; // C_i . C_i
     double *scratch = nullptr; // small device scratch (>= 4096 doubles)
     long long *dbg = nullptr;  // optional chain-kernel cycle stamps, 32 per panel
 

@@ -87,6 +87,7 @@ struct hb_run {
     bool done = false;
     double setup_seconds = 0, gram_seconds = 0, loop_seconds = 0;
     // MCMC sample stores kept inside the run (copied out by finish)
+    std::vector<double> zb_, zl_, ch_; // this iteration's pre-drawn deviates for the covariate / random-effect blocks
     std::vector<double> s_mu, s_Vg, s_Ve, s_h2, s_pi, s_beta, s_Vr, s_r, s_alpha;
 
     ~hb_run()
@@ -386,6 +387,8 @@ int hb_run::setup(const hb_bayes_args *args)
     if (rc) return rc;
     rc = hb_ctx_set_levels(c, nr ? zid.data() : nullptr, nr, nr ? nlev.data() : nullptr);
     if (rc) return rc;
+    rc = hb_ctx_blocks_setup(c, cpc.data(), zz.data(), vrtmp.data());
+    if (rc) return rc;
 
     // ---- console, :393-461 ----
     line("Prior parameters:");
@@ -467,41 +470,20 @@ int hb_run::step()
     rc = hb_ctx_residual_shift(c, mu_);
     if (rc) return rc;
 
-    // covariates, :484-494
-    for (int i = 0; i < nc; i++) {
-        const double oldgi = beta[i], v = cpc[i];
-        double rhs;
-        rc = hb_ctx_cov_dot(c, i, &rhs);
-        if (rc) return rc;
-        rhs += v * oldgi;
-        const double gi = rhs / v + std::sqrt(vare_ / v) * hs.norm();
-        rc = hb_ctx_cov_axpy(c, i, oldgi - gi);
-        if (rc) return rc;
-        beta[i] = gi;
-    }
-
-    // environmental random effects, :496-516
-    std::vector<double> r_RHS, estR_new, lev_delta;
-    for (int t = 0; t < nr; t++) {
-        const int q0 = lev_first[t], qr = nlev[t];
-        r_RHS.assign(qr, 0.0);
-        estR_new.assign(qr, 0.0);
-        lev_delta.assign(qr, 0.0);
-        rc = hb_ctx_level_sums(c, t, r_RHS.data());
-        if (rc) return rc;
-        for (int q = 0; q < qr; q++) r_RHS[q] += zz[q0 + q] * estR[q0 + q];
-        for (int q = 0; q < qr; q++) {
-            const double l = zz[q0 + q] + vare_ / vrtmp[t];
-            estR_new[q] = r_RHS[q] / l + std::sqrt(vare_ / l) * hs.norm();
-            lev_delta[q] = estR[q0 + q] - estR_new[q];
+    // covariates (:484-494) and environmental random effects (:496-516): enqueued as device kernels. Their deviates do not
+    // depend on the data, so they are drawn here first, in the reference's order — one normal per covariate, then per term
+    // its level normals followed by its chisq — and the state comes back with the sweep's fetch: one host sync per iteration
+    if (nc + nr) {
+        zb_.resize(nc);
+        zl_.resize(n_levels);
+        ch_.resize(nr);
+        for (int i = 0; i < nc; i++) zb_[i] = hs.norm();
+        for (int t = 0; t < nr; t++) {
+            for (int q = 0; q < nlev[t]; q++) zl_[lev_first[t] + q] = hs.norm();
+            ch_[t] = hs.chisq(nlev[t] + dfr);
         }
-        rc = hb_ctx_level_axpy(c, t, lev_delta.data());
+        rc = hb_ctx_blocks_step(c, vare_, zb_.data(), zl_.data(), ch_.data(), dfr, s2r);
         if (rc) return rc;
-        double ss = 0;
-        for (int q = 0; q < qr; q++) ss += estR_new[q] * estR_new[q];
-        vrtmp[t] = (ss + s2r * dfr) / hs.chisq(qr + dfr);
-        vr[t] = var_n1(estR_new.data(), qr);
-        for (int q = 0; q < qr; q++) estR[q0 + q] = estR_new[q];
     }
 
     // ---------------- marker sweep on the device, :586-816 ----------------
@@ -550,6 +532,13 @@ int hb_run::step()
     redo_sum += so.n_redo;
     sum_r = so.sum_r;
     sum_r2 = so.sum_r2;
+    if (nc + nr) { // the block state arrived with the sweep's fetch
+        const double *h = c->h_blk;
+        std::copy(h, h + nc, beta.begin());
+        std::copy(h + nc, h + nc + n_levels, estR.begin());
+        std::copy(h + nc + n_levels, h + nc + n_levels + nr, vrtmp.begin());
+        std::copy(h + nc + n_levels + nr, h + nc + n_levels + 2 * nr, vr.begin());
+    }
 
     // hyper-parameters after the sweep
     auto draw_pi = [&]() { // rdirichlet_sample, src/stats.cpp:69-76

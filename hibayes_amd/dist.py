@@ -89,13 +89,8 @@ class RcclComm:
 
     def __init__(self, rank=0, world=1, device=0, share=None, side=None):
         from ._lib import check, lib
-        # One RCCL per process: PyTorch ships its own librccl and loads it on import; the library dlopen()s "librccl.so.1" by
-        # soname, which resolves to an already loaded copy. If torch were imported AFTER our dlopen, two different RCCL builds
-        # would live in one process (and crash in their exit handlers) — so where torch exists, load it first.
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
+        # _lib.lib() loads torch (where it exists) before the library, so that this library, the system librccl it dlopen()s
+        # and torch all use one HIP runtime, and torch's own RCCL build is torn down after ours at exit.
         self.L = lib()
         self.rank, self.world, self.side = int(rank), int(world), side
         ident = (C.c_ubyte * 128)()

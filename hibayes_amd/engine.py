@@ -183,6 +183,23 @@ class Context:
         d = np.ascontiguousarray(delta, dtype=np.float64)
         check(self.L.hb_ctx_level_axpy(self.h, t, d.ctypes.data))
 
+    def blocks_setup(self, cpc, zz, vrtmp0):
+        """Device-resident covariate / random-effect state (reference src/Bayes.cpp:484-516); after set_covariates / set_levels."""
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (cpc, zz, vrtmp0)]
+        self._blk = (len(a[0]), len(a[1]), len(a[2]))
+        check(self.L.hb_ctx_blocks_setup(self.h, *[x.ctypes.data for x in a]))
+
+    def blocks_step(self, vare, z_beta, z_levels, chisq, dfr, s2r):
+        """Enqueue the iteration's covariate and random-effect kernels with the host's pre-drawn deviates (no host sync)."""
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (z_beta, z_levels, chisq)]
+        check(self.L.hb_ctx_blocks_step(self.h, float(vare), *[x.ctypes.data for x in a], float(dfr), float(s2r)))
+
+    def blocks_state(self):
+        nc, nl, nr = self._blk
+        out = [np.zeros(nc), np.zeros(nl), np.zeros(nr), np.zeros(nr)]
+        check(self.L.hb_ctx_blocks_state(self.h, *[x.ctypes.data for x in out]))
+        return out
+
     def set_windows(self, windindx):
         w = np.ascontiguousarray(windindx, dtype=np.uint32)
         self._nw = int(w.max())

@@ -292,6 +292,14 @@ int hb_ctx_set_levels(hb_ctx *c, const int32_t *zid, int32_t nr, const int32_t *
 int hb_ctx_level_sums(hb_ctx *c, int32_t term, double *sums);         /* Z_t' yadj         */
 int hb_ctx_level_axpy(hb_ctx *c, int32_t term, const double *delta);  /* yadj += Z_t delta */
 
+/* The covariate and random-effect blocks of one iteration (src/Bayes.cpp:484-516) as device kernels with no host
+ * synchronisation: the caller draws the deviates first, in the reference's order (they do not depend on the data) —
+ * z_beta[nc], then per term its level normals (z_levels, all terms concatenated) and chisq[term] = chisq_sample(q_t + dfr) —
+ * and reads the state back whenever it needs it (hb_ctx_blocks_state synchronises). set_covariates / set_levels first. */
+int hb_ctx_blocks_setup(hb_ctx *c, const double *cpc /* nc */, const double *zz /* levels */, const double *vrtmp0 /* nr */);
+int hb_ctx_blocks_step(hb_ctx *c, double vare, const double *z_beta, const double *z_levels, const double *chisq, double dfr, double s2r);
+int hb_ctx_blocks_state(hb_ctx *c, double *beta, double *estR, double *vrtmp, double *vr);
+
 /* One marker sweep (reference src/Bayes.cpp:586-816) plus the two reductions behind
  * :819 and :823.  Hyper-parameters come from the host, per-SNP draws happen on device. */
 typedef struct hb_sweep_in {

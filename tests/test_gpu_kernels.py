@@ -121,6 +121,59 @@ def test_matvec_and_residual_helpers():
         np.testing.assert_allclose(got, cur + delta[zid[:, 0]], rtol=1e-13, atol=1e-13)
 
 
+def test_covariate_and_random_effect_blocks_on_the_device():
+    """hb_ctx_blocks_step (reference src/Bayes.cpp:484-516 with the deviates passed in) against the same arithmetic in
+    numpy: two iterations, two covariates, two random terms; tolerance 1e-11 relative (sums in a different order)."""
+    rng = np.random.default_rng(11)
+    n, m = 3000, 128
+    X = rand_geno(rng, n, m)
+    r = rng.normal(size=n)
+    Cm = rng.normal(size=(n, 2))
+    zid = np.stack([rng.integers(0, 9, size=n), rng.integers(0, 150, size=n)], axis=1)
+    nlev = [9, 150]
+    first = [0, 9]
+    zz = np.concatenate([np.bincount(zid[:, t], minlength=nlev[t]) for t in range(2)]).astype(float)
+    cpc = (Cm * Cm).sum(0)
+    vrtmp = np.array([0.3, 0.7])
+    dfr, s2r, vare = -1.0, 0.0, 1.3
+    beta = np.zeros(2)
+    estR = np.zeros(159)
+    vr = np.zeros(2)
+    with H.Context(n, m) as c:
+        c.upload(X)
+        c.set_residual(r, np.zeros(n))
+        c.set_covariates(Cm)
+        c.set_levels(zid, nlev)
+        c.blocks_setup(cpc, zz, vrtmp)
+        cur = r.copy()
+        for it in range(2):
+            zb, zl = rng.normal(size=2), rng.normal(size=159)
+            ch = rng.chisquare([nlev[0] + dfr, nlev[1] + dfr])
+            c.blocks_step(vare, zb, zl, ch, dfr, s2r)
+            for i in range(2):
+                rhs = Cm[:, i] @ cur + cpc[i] * beta[i]
+                gi = rhs / cpc[i] + np.sqrt(vare / cpc[i]) * zb[i]
+                cur += (beta[i] - gi) * Cm[:, i]
+                beta[i] = gi
+            for t in range(2):
+                sl = slice(first[t], first[t] + nlev[t])
+                rhs = np.bincount(zid[:, t], weights=cur, minlength=nlev[t]) + zz[sl] * estR[sl]
+                l = zz[sl] + vare / vrtmp[t]
+                en = rhs / l + np.sqrt(vare / l) * zl[sl]
+                cur += (estR[sl] - en)[zid[:, t]]
+                estR[sl] = en
+                vrtmp[t] = (en @ en + s2r * dfr) / ch[t]
+                vr[t] = en.var(ddof=1)
+            vare = 0.9
+        b, e, vt, v = c.blocks_state()
+        got, _ = c.get_residual()
+    np.testing.assert_allclose(b, beta, rtol=1e-11)
+    np.testing.assert_allclose(e, estR, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(vt, vrtmp, rtol=1e-11)
+    np.testing.assert_allclose(v, vr, rtol=1e-11)
+    np.testing.assert_allclose(got, cur, rtol=1e-10, atol=1e-11)
+
+
 def test_bed_decode_on_device_matches_golden(demo):
     raw = open(demo["prefix"] + ".bed", "rb").read()
     with H.Context(300, 1000) as c:
