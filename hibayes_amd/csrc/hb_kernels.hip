@@ -994,6 +994,9 @@ struct persist_view {
 };
 
 #define HB_LBMAX 20
+#ifndef HB_NPF
+#define HB_NPF 1 /* candidates per panel whose band rows are requested ahead (1 or 2) */
+#endif
 #define HB_CROWD 8 /* candidates in a round from which their Gram entries are gathered up front */
 
 // Row-cache list of every panel, in marker order, capped at nslot rows: the markers that are certain to move
@@ -1102,7 +1105,9 @@ __device__ __forceinline__ void hb_read8(const int *w, int (&o)[8])
 // while panel p's serial turns run — its per-marker coefficients, its mat-vec partials (if that mat-vec has
 // already finished) and the Gram rows of its hot markers (into the other half of a double-buffered LDS row
 // cache, two 1-KiB pieces per wave per turn boundary).
-template <int K1>
+// NPL: band blocks whose rows are requested ahead for a panel's first two candidates (== Lb, or 0: none) — a template
+// parameter because the counted waits that keep those loads in flight need the count at compile time.
+template <int K1, int NPL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_persist(const hb_sweep_in *__restrict__ pin, chain_view v, persist_view pv,
                                                        int nslot)
 {
@@ -1300,39 +1305,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const double r0 = dj - corrv;
             cand0 = active && (hot || r0 * r0 >= pv.candf * (double)fthr);
             const unsigned long long cm0 = __ballot(cand0);
-            if (lane == 0) wcnt[wave] = __popcll(cm0) | (aborted ? 0x10000 : 0);
+            // count | lane of the wave's first candidate << 8 | lane of its second << 14 | gave-up-waiting << 24
+            const unsigned long long cm1 = cm0 & (cm0 - 1ull);
+            if (lane == 0)
+                wcnt[wave] = __popcll(cm0) | (cm0 ? (__ffsll((long long)cm0) - 1) << 8 : 0) | (cm1 ? (__ffsll((long long)cm1) - 1) << 14 : 0) |
+                             (aborted ? 1 << 24 : 0);
         }
         HB_STAMP(1);
         __syncthreads(); // the panel's one fixed barrier: wcnt[] staged, ring group of panel p + 1 published; everybody is done with panel p-1
-        int tot0 = 0;
+        int tot0 = 0, c1 = -1, c2 = -1; // candidates in the panel; its first two (thread = marker index in the panel)
         {
-            int w8[8];
+            int w8[8], gaveup = 0;
             hb_read8(wcnt, w8);
 #pragma unroll
-            for (int w = 0; w < 8; w++) tot0 += w8[w];
+            for (int w = 0; w < 8; w++) {
+                const int cnt = w8[w] & 0xff, a = w * 64 + ((w8[w] >> 8) & 63), b = w * 64 + ((w8[w] >> 14) & 63);
+                tot0 += cnt;
+                gaveup |= w8[w] >> 24;
+                if (cnt) {
+                    if (c1 < 0) { c1 = a; c2 = cnt > 1 ? b : -1; }
+                    else if (c2 < 0) c2 = a;
+                }
+            }
+            if (gaveup) { ok = false; break; } // a wave gave up waiting for its dots: the sweep is aborted
         }
-        if (tot0 >> 16) { ok = false; break; } // a wave gave up waiting for its dots: the sweep is aborted
         // (2) a panel with candidates: the exact per-marker data, one round trip
         double thr[K1], invv[K1], sdz[K1];
         double gold = 0.0, rhs = 0.0;
         int myslot = -1;
 #pragma unroll
         for (int c = 0; c < K1; c++) { thr[c] = HB_INF; invv[c] = 0.0; sdz[c] = 0.0; }
-        if (tot0 > 0) {
-            gold = v.g[j];
-            const double xx = v.xpx[j];
-            myslot = pv.slot_of[j];
-#pragma unroll
-            for (int c = 0; c < K1; c++) {
-                thr[c] = v.thr[(size_t)c * v.m_pad + j];
-                invv[c] = v.invv[(size_t)c * v.m_pad + j];
-                sdz[c] = v.sdz[(size_t)c * v.m_pad + j];
-            }
-            rhs = dj;
-            if (gold != 0.0) rhs = fma(xx, gold, rhs);
-            rhs -= corrv;
-        }
-        HB_STAMP(7);
 
         // ---- the serial chain, speculatively compacted ----
         // Only markers that are in the model (certain to move) or whose q is near their entry threshold can move.
@@ -1344,15 +1346,67 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int cls_f = 0;
         double g_f = 0.0;
         int nev = 0;
+        int pre[2][NPL > 0 ? NPL : 1];
         if (tot0 > 0) {
+            // the exact per-marker data, for the candidates only (one CU pulls ~18 bytes per clock from memory — measured,
+            // tools/rowfetch_bench.hip — and every thread's copy of six arrays was a quarter of a move-panel's traffic). A marker
+            // that is not a candidate is at zero; until it becomes one it is judged with its filter word (the entry threshold
+            // rounded down: a superset test) and fetches its data then.
+            double xx = 0.0;
+            bool have_exact = cand0;
+            if (cand0) {
+                gold = v.g[j];
+                xx = v.xpx[j];
+                myslot = pv.slot_of[j];
+#pragma unroll
+                for (int c = 0; c < K1; c++) {
+                    thr[c] = v.thr[(size_t)c * v.m_pad + j];
+                    invv[c] = v.invv[(size_t)c * v.m_pad + j];
+                    sdz[c] = v.sdz[(size_t)c * v.m_pad + j];
+                }
+            }
+            const double thr_lo = (double)fthr; // <= thr[0]; NaN for a monomorphic marker (every comparison false)
+            // (3) ... and, requested right behind it, the band-Gram rows that the panel's first two candidates would fold forward if
+            // they move (in the sparse regime a candidate almost always does, and a panel rarely has more than two): by the time the
+            // rounds are through they have landed, and the fold at the end of the panel costs no round trip. Always 2 * NPL loads, so
+            // that the counted waits below are exact; rows of panels that do not exist are read from the panel's own block.
+            if (NPL > 0) {
+                __builtin_amdgcn_sched_barrier(0); // (the order of issue is the point: hipcc must not move these ahead of the data above)
+                const int lmax = np - 1 - p;
+                const size_t PP = (size_t)P * P, step = (size_t)(pv.Lb + 2) * PP;
+                const int k1 = __builtin_amdgcn_readfirstlane(c1), k2 = __builtin_amdgcn_readfirstlane(c2 < 0 ? c1 : c2);
+                const int32_t *blk = v.gram + ((size_t)(p + 1) * (pv.Lb + 1) + 1) * PP;
+#pragma unroll
+                for (int l = 1; l <= NPL; l++) {
+                    const int32_t *b = l <= lmax ? blk : gp;
+                    pre[0][l - 1] = (b + (size_t)k1 * P)[t];
+                    if (HB_NPF > 1) pre[1][l - 1] = (b + (size_t)k2 * P)[t];
+                    blk += step;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rhs = dj;
+            if (gold != 0.0) rhs = fma(xx, gold, rhs);
+            rhs -= corrv;
+            HB_STAMP(7);
             int t_lo = 0, nev0 = 0;
             bool forced = false;
             bool first = true; // the first round's candidate counts were staged before the panel's opening barrier
             for (;;) {
                 const bool undec = t >= t_lo;
                 // (the first round's counts were taken with the opening filter: the same predicate must rank them)
-                const bool isc = first ? cand0 : (undec && active && (hot || forced || rhs * rhs >= pv.candf * thr[0]));
+                const bool isc = first ? cand0 : (undec && active && (hot || forced || rhs * rhs >= pv.candf * thr_lo));
                 const unsigned long long cm = __ballot(isc);
+                if (isc && !have_exact) { // (rare: more than 64 candidates, or a marker pushed over its threshold by a move)
+                    myslot = pv.slot_of[j];
+#pragma unroll
+                    for (int c = 0; c < K1; c++) {
+                        thr[c] = v.thr[(size_t)c * v.m_pad + j];
+                        invv[c] = v.invv[(size_t)c * v.m_pad + j];
+                        sdz[c] = v.sdz[(size_t)c * v.m_pad + j];
+                    }
+                    have_exact = true;
+                }
                 if (!first) {
                     if (lane == 0) wcnt[wave] = __popcll(cm);
                     __syncthreads();
@@ -1364,7 +1418,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     hb_read8(wcnt, w8);
 #pragma unroll
                     for (int w = 0; w < 8; w++) {
-                        const int c = w8[w] & 0xffff;
+                        const int c = w8[w] & 0xff;
                         basec += (w < wave) ? c : 0;
                         tot += c;
                     }
@@ -1386,8 +1440,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     cs_t[rank] = t;
                     cs_slot[rank] = myslot;
                 }
-                // this half of the row cache was filled by LDS-DMA a panel ago: every wave drains its own pieces before the barrier
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the row cache was filled by LDS-DMA a panel ago: every wave drains its own pieces before the barrier — everything
+                // older than the 2 * npl candidate rows requested above, which may stay in flight (the queue completes in order)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HB_NPF * NPL) : "memory");
                 __syncthreads();
                 if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(12);
                 const int t_hi = tot > 64 ? *s_thi : P;
@@ -1554,7 +1609,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
                 if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(14);
-                const bool viol = undec && !inr && t < t_hi && active && rhs_new * rhs_new >= thr[0];
+                const bool viol = undec && !inr && t < t_hi && active && rhs_new * rhs_new >= (have_exact ? thr[0] : thr_lo);
                 const unsigned long long vm = __ballot(viol);
                 if (lane == 0) wviol[wave] = vm != 0ull;
                 __syncthreads();
@@ -1616,8 +1671,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             evacc = nev + evacc;
             HB_STAMP(5);
             // ---- fold the moves forward into the corrections of the next Lb panels ----
-            if (nev > 0) { // batch shape by band width: as many loads in flight as the registers allow
-                const int lcount = min(min(pv.Lb, (pv.Lv + 1) * pv.D - 1 - pmodD), np - 1 - p); // panels that need the correction
+            const int lcount = min(min(pv.Lb, (pv.Lv + 1) * pv.D - 1 - pmodD), np - 1 - p); // panels that need the correction
+            bool from_pre = NPL > 0 && nev > 0 && nev <= HB_NPF;
+            int w0 = 0, w1 = 0;
+            if (from_pre) { // did exactly (a subset of) the first two candidates move? Their rows are already here
+                const int e0 = ev_ix[0] & 0xffff, e1 = ev_ix[nev - 1] & 0xffff;
+                w0 = e0 == c1 ? 0 : (HB_NPF > 1 && e0 == c2 ? 1 : -1);
+                w1 = e1 == c1 ? 0 : (HB_NPF > 1 && e1 == c2 ? 1 : -1);
+                from_pre = w0 >= 0 && w1 >= 0;
+            }
+            if (from_pre) {
+                const double d0 = ev_del[0], d1 = nev > 1 ? ev_del[1] : 0.0;
+                int slot = pslot;
+#pragma unroll
+                for (int l = 1; l <= (NPL > 0 ? NPL : 1); l++) {
+                    slot = (slot + 1 == R) ? 0 : slot + 1;
+                    if (l <= lcount) { // (lcount <= Lb = NPL here; the same fused multiply-adds, in event order, as fold_forward's)
+                        double *cp = corrL + (size_t)slot * P + t;
+                        double acc = *cp;
+                        acc = fma((double)(HB_NPF > 1 && w0 ? pre[1][l - 1] : pre[0][l - 1]), d0, acc);
+                        if (HB_NPF > 1 && nev > 1) acc = fma((double)(w1 ? pre[1][l - 1] : pre[0][l - 1]), d1, acc);
+                        *cp = acc;
+                    }
+                }
+            } else if (nev > 0) { // batch shape by band width: as many loads in flight as the registers allow
                 if (pv.Lb <= 2) fold_forward<2, 16>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
                 else if (pv.Lb <= 5) fold_forward<5, 8>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
                 else if (pv.Lb <= 12) fold_forward<12, 2>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
@@ -2115,9 +2192,10 @@ static size_t chain_smem(int P) { return (size_t)chain_nslot(P) * P * 4 + (size_
 
 int hbk_init_attrs()
 {
-    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_persist<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_persist<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_persist<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define HB_PERSIST_ATTR(K1, NPL) HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_persist<K1, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    HB_PERSIST_ATTR(1, 0); HB_PERSIST_ATTR(1, 1); HB_PERSIST_ATTR(1, 17);
+    HB_PERSIST_ATTR(3, 0); HB_PERSIST_ATTR(3, 2);
+    HB_PERSIST_ATTR(7, 0); HB_PERSIST_ATTR(7, 2);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2370,11 +2448,24 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
     return HB_OK;
 }
 
+template <int K1, int NPL>
+static hipError_t launch_chain_persist2(hb_ctx *c, const chain_view &cv, const persist_view &pv, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_chain_persist<K1, NPL>), dim3(1), dim3(c->P), persist_smem(c->P), st, c->d_in, cv, pv, persist_nslot(c->P, c->L, K1));
+    return hipGetLastError();
+}
+
 template <int K1>
 static hipError_t launch_chain_persist(hb_ctx *c, const chain_view &cv, const persist_view &pv, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_chain_persist<K1>, dim3(1), dim3(c->P), persist_smem(c->P), st, c->d_in, cv, pv, persist_nslot(c->P, c->L, K1));
-    return hipGetLastError();
+    // candidate rows ahead (NPL == Lb) for the band widths of the default geometries; any other band goes without
+    if (K1 == 1) {
+        if (pv.Lb == 17) return launch_chain_persist2<1, 17>(c, cv, pv, st); // (Lv, D) = (2, 6)
+        if (pv.Lb == 1) return launch_chain_persist2<1, 1>(c, cv, pv, st);
+        return launch_chain_persist2<1, 0>(c, cv, pv, st);
+    }
+    if (pv.Lb == 2) return launch_chain_persist2<K1 == 1 ? 3 : K1, 2>(c, cv, pv, st);
+    return launch_chain_persist2<K1, 0>(c, cv, pv, st);
 }
 
 // Persistent pipeline: stream A = mat-vec launches (each also carrying an update row and a partial-sum row),
