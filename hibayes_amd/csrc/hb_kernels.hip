@@ -2500,11 +2500,18 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     const int last_panels = np - (ngroups - 1) * D;
     persist_view pv{np, D, Lv, c->L, c->flags,
                     c->hot_slot, c->hot_list, c->thr0f, c->candf};
-    {
-        hipError_t e = kp == 1 ? launch_chain_persist<1>(c, cv, pv, sB) : kp == 3 ? launch_chain_persist<3>(c, cv, pv, sB)
-                                                                                 : launch_chain_persist<7>(c, cv, pv, sB);
+    // HB_CHAIN_ALONE=1 — a TIMING DIAGNOSTIC, results are meaningless: the mat-vec launches run first against a pre-set
+    // chain_done (their update rows find empty event lists), the chain afterwards with the device to itself; the stamped span
+    // (tools/chain_timeline.py with CT_ALONE=1) is then what the chain costs without the mat-vec's memory traffic beside it.
+    const bool alone = getenv("HB_CHAIN_ALONE") != nullptr;
+    auto launch_the_chain = [&](hipStream_t st) -> int {
+        hipError_t e = kp == 1 ? launch_chain_persist<1>(c, cv, pv, st) : kp == 3 ? launch_chain_persist<3>(c, cv, pv, st)
+                                                                                 : launch_chain_persist<7>(c, cv, pv, st);
         if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_persist launch: ") + hipGetErrorString(e));
-    }
+        return HB_OK;
+    };
+    if (alone) HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->flags + HB_FLAG_CHAIN_DONE), 0x7ffffff0, 1, sA));
+    else if (int rc = launch_the_chain(sB)) return rc;
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
     // Residual versions advance per mat-vec group: version h = every panel of groups <= h applied. Mat-vec launch g
     // reads version g - Lv - 1 and, in one extra grid row, carries update(h = g - Lv): version h-1 -> h, which the
@@ -2519,6 +2526,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
                    g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0, g);
     }
     launch_reduce(c, (ngroups - 1) * D * c->P, last_panels * c->P, sA, ngroups - 1);
+    if (alone)
+        if (int rc = launch_the_chain(sA)) return rc;
     for (int h = std::max(0, ngroups - Lv); h < ngroups; h++) // the updates that had no later mat-vec to ride on
         hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sA, c->ld,
                            make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags, h));

@@ -33,8 +33,11 @@ a.seed, a.precise, a.ctx = 20240901, 2, ctx.h
 run = ct.c_void_p(); check(L.hb_run_create(ct.byref(a), ct.byref(run)))
 fin = ct.c_int32()
 check(L.hb_run_step(run, burn, ct.byref(fin)))
+alone = bool(os.environ.get("CT_ALONE"))  # HB_CHAIN_ALONE timing diagnostic for the stamped sweep only
+if alone:
+    os.environ["HB_CHAIN_ALONE"] = "1"
 ctx.set_profiling(2)
-check(L.hb_run_step(run, 3, ct.byref(fin)))
+check(L.hb_run_step(run, 1 if alone else 3, ct.byref(fin)))
 P = ctx.panel; npan = (m + P - 1) // P
 st = np.zeros(32 * npan, dtype=np.int64)
 L.hb_ctx_debug_stamps.argtypes = [ct.c_void_p, ct.c_void_p]

@@ -86,5 +86,19 @@ int main()
         run<64>(buf, nrows, dout, sink, s1, tag);
     }
     CK(hipDeviceSynchronize());
+    // and what a plain streaming read of 4 GiB reaches on this device (the ceiling any mat-vec is measured against)
+    for (int blocks : {256 * 4, 256 * 8, 256 * 16}) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, s2, sbuf, sbytes / 16, 1, sink);
+        CK(hipEventRecord(e0, s2));
+        hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, s2, sbuf, sbytes / 16, 4, sink);
+        CK(hipEventRecord(e1, s2));
+        CK(hipStreamSynchronize(s2));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  streaming read, %5d blocks x 256: %.2f TB/s\n", blocks, 4.0 * sbytes / (ms * 1e-3) / 1e12);
+    }
     return 0;
 }
