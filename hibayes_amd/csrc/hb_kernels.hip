@@ -26,6 +26,7 @@
 // fence either (cdna_hip_programming.md §6 Guideline 16, forms R1 / "sc1 both sides").
 #define HB_FLAG_CHAIN_DONE 0
 #define HB_FLAG_ABORT 1
+#define HB_FLAG_XCC 2               /* 1 + the XCD the chain workgroup runs on (k_warm) */
 #define HB_NFLAGS 64                /* words in the flag block */
 #define HB_TIMEOUT_TICKS 300000000ull /* wall_clock64() runs at 100 MHz: 3 s */
 
@@ -1223,6 +1224,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int n_nhot = 0;
 
     // ---- prologue ----
+    if (t == 0) { // where this workgroup runs: k_warm's workgroups on the same XCD (= the same L2) fetch ahead of it
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        st_flag(pv.flags + HB_FLAG_XCC, (xcc & 15u) + 1u);
+    }
     for (int i = t; i < 128; i += P) cnts[i] = 0; // (a 64-marker panel has 64 threads; absent waves' words must read 0)
     if (wave < RW)
         for (int x = 0; x < HB_RD - 1 && x < np; x++) issue_group(x, x);
@@ -1781,6 +1787,71 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         st_flag(pv.flags + HB_FLAG_ABORT, 1u);
         st_flag(pv.flags + HB_FLAG_CHAIN_DONE, 0x7fffffffu);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_warm: the chain workgroup's memory traffic, pulled into ITS L2 ahead of time by other compute units.
+// One compute unit gets ~18 bytes per clock out of HBM however many loads it keeps in flight (its miss queue is the limit;
+// tools/rowfetch_bench.hip: 113 cycles per 2-KiB row), but 64 bytes per clock out of its XCD's L2 (31 cycles per row). What
+// the chain will read is known a sweep ahead for every marker on a panel's hot list (k_hotlist: the markers in the model —
+// certain to move — and the likely entries): the Gram row that goes into the row cache and the band rows its move folds
+// forward. The workgroups of this kernel that landed on the chain's XCD (workgroups are dealt round-robin over the 8 XCDs;
+// the chain publishes its own) read exactly those rows, `ahead` panels in front of the chain's published progress, and
+// throw the data away. It is a hint: nothing waits for it, nothing depends on it, a late or missing row is only slower.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_warm(persist_view pv, const int32_t *__restrict__ gram, int P, int ahead, int per_xcd,
+                                              int *__restrict__ sink)
+{
+    __shared__ int s_rank;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        unsigned my;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my));
+        my &= 15u;
+        unsigned want = 0;
+        const unsigned long long t0 = wall_clock64();
+        while ((want = ld_flag(pv.flags + HB_FLAG_XCC)) == 0u) {
+            if (ld_flag(pv.flags + HB_FLAG_ABORT) || ld_flag(pv.flags + HB_FLAG_CHAIN_DONE) >= (unsigned)pv.npanels ||
+                wall_clock64() - t0 > 100000000ull) break; // (1 s: the chain never started)
+            __builtin_amdgcn_s_sleep(16);
+        }
+        s_rank = (want == my + 1u) ? (int)(blockIdx.x >> 3) % per_xcd : -1;
+    }
+    __syncthreads();
+    const int rank = s_rank;
+    if (rank < 0) return;
+    const int np = pv.npanels, Lb = pv.Lb;
+    const size_t PP = (size_t)P * P, step = (size_t)(Lb + 2) * PP;
+    const int quarter = P >> 2;            // int4 lanes per row
+    const int rows_per_pass = 256 / quarter; // rows one instruction of this workgroup covers
+    int acc = 0;
+    for (int q = 0; q < np; q++) {
+        // pace: at most `ahead` panels in front of the chain's published progress
+        unsigned done;
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+            done = ld_flag(pv.flags + HB_FLAG_CHAIN_DONE);
+            if ((int)done + ahead >= q || ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if ((int)done >= np || ld_flag(pv.flags + HB_FLAG_ABORT) || (int)done + ahead < q) break;
+        if (q < (int)done) continue; // the chain is already past this panel
+        const int *hl = pv.hotpack + (size_t)q * HB_HS;
+        const int cnt = hl[0];
+        const int lmax = min(Lb, np - 1 - q);
+        const int nitem = cnt * (1 + lmax);
+        const int32_t *gp = gram + (size_t)q * (Lb + 1) * PP;
+        const int32_t *fwd = gram + ((size_t)(q + 1) * (Lb + 1) + 1) * PP;
+        const int sub = t / quarter, col = (t - sub * quarter) * 4;
+        for (int it = rank * rows_per_pass + sub; it < nitem; it += per_xcd * rows_per_pass) {
+            const int mi = it / (1 + lmax), l = it - mi * (1 + lmax);
+            const int k = hl[4 + mi];
+            const int32_t *src = (l == 0 ? gp : fwd + (size_t)(l - 1) * step) + (size_t)k * P + col;
+            const int4 x = *reinterpret_cast<const int4 *>(src);
+            acc += x.x ^ x.y ^ x.z ^ x.w;
+        }
+    }
+    if (acc == 0x5a5a5a5a) sink[0] = acc; // (keeps the loads)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2512,6 +2583,17 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     };
     if (alone) HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->flags + HB_FLAG_CHAIN_DONE), 0x7ffffff0, 1, sA));
     else if (int rc = launch_the_chain(sB)) return rc;
+    // the L2 warmers (k_warm): a third branch of the graph, 4 workgroups per XCD of which only the chain's XCD's stay
+    int warm = 4;
+    if (const char *e = getenv("HB_WARM")) warm = std::max(0, std::min(16, atoi(e)));
+    if (alone) warm = 0;
+    if (warm) {
+        HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
+        int ahead = D + 4;
+        if (const char *e = getenv("HB_WARM_AHEAD")) ahead = std::max(1, atoi(e));
+        hipLaunchKernelGGL(k_warm, dim3(8 * warm), dim3(256), 0, c->s_upd, pv, c->gram, c->P, ahead, warm, reinterpret_cast<int *>(c->flags + 48));
+        HB_HIP(hipGetLastError());
+    }
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
     // Residual versions advance per mat-vec group: version h = every panel of groups <= h applied. Mat-vec launch g
     // reads version g - Lv - 1 and, in one extra grid row, carries update(h = g - Lv): version h-1 -> h, which the
@@ -2533,6 +2615,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
                            make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags, h));
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
+    if (warm) {
+        HB_HIP(hipEventRecord(c->ev_upd[0], c->s_upd));
+        HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[0], 0));
+    }
     const int sfin = slot2(ngroups - 1);
     if (sfin != 0) {
         HB_HIP(hipMemcpyAsync(c->r, c->r + (size_t)sfin * c->ld, sizeof(double) * c->ld, hipMemcpyDeviceToDevice, sA));

@@ -48,6 +48,51 @@ __global__ void k_stream(const int4 *__restrict__ a, size_t n, int reps, int *si
     if (acc == 0x12345678) sink[0] = acc;
 }
 
+// the same batch fetched twice: the second pass finds the rows in this XCD's L2 (the 32-KiB L1 holds an eighth of them)
+template <int N>
+__global__ __launch_bounds__(512) void k_refetch(const int *__restrict__ buf, size_t nrows, int iters, long long *out, int *sink, unsigned seed)
+{
+    const int t = threadIdx.x;
+    long long tot = 0;
+    int acc = 0;
+    unsigned s = seed;
+    for (int it = 0; it < iters; it++) {
+        int v[N];
+        size_t rows[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            s = s * 1664525u + 1013904223u;
+            rows[i] = (size_t)(((unsigned long long)s * nrows) >> 32);
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = buf[rows[i] * 512 + t];
+#pragma unroll
+        for (int i = 0; i < N; i++) acc += v[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const long long t0 = clock64();
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = __builtin_nontemporal_load(buf + rows[i] * 512 + t);
+#pragma unroll
+        for (int i = 0; i < N; i++) acc += v[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        tot += clock64() - t0;
+    }
+    if (t == 0) out[0] = tot / iters;
+    if (acc == 0x12345678) sink[0] = acc;
+}
+
+template <int N>
+static void run2(const int *buf, size_t nrows, long long *dout, int *sink, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_refetch<N>, dim3(1), dim3(512), 0, st, buf, nrows, 200, dout, sink, 777u + N);
+    CK(hipStreamSynchronize(st));
+    long long h;
+    CK(hipMemcpy(&h, dout, 8, hipMemcpyDeviceToHost));
+    printf("  L2-warm  N=%2d rows in flight: %7lld cycles per batch (%6.0f per row)\n", N, h, (double)h / N);
+}
+
 template <int N>
 static void run(const int *buf, size_t nrows, long long *dout, int *sink, hipStream_t st, const char *tag)
 {
@@ -74,6 +119,10 @@ int main()
     hipStream_t s1, s2;
     CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    run2<1>(buf, nrows, dout, sink, s1);
+    run2<8>(buf, nrows, dout, sink, s1);
+    run2<32>(buf, nrows, dout, sink, s1);
+    run2<64>(buf, nrows, dout, sink, s1);
     for (int loaded = 0; loaded < 2; loaded++) {
         if (loaded) hipLaunchKernelGGL(k_stream, dim3(255 * 8), dim3(256), 0, s2, sbuf, sbytes / 16, 60, sink);
         const char *tag = loaded ? "loaded" : "alone";
