@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhibayes_gpu.so")
+LIB_PATH = os.environ.get("HIBAYES_GPU_LIB") or os.path.join(_HERE, "libhibayes_gpu.so")  # (override: A/B builds of the library)
 HB_MAX_FOLD = 8
 _lib = None
 

@@ -1799,8 +1799,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // the chain publishes its own) read exactly those rows, `ahead` panels in front of the chain's published progress, and
 // throw the data away. It is a hint: nothing waits for it, nothing depends on it, a late or missing row is only slower.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_warm(persist_view pv, const int32_t *__restrict__ gram, int P, int ahead, int per_xcd,
-                                              int *__restrict__ sink)
+__global__ __launch_bounds__(256) void k_warm(persist_view pv, chain_view v, int K1, const int32_t *__restrict__ gram, int P, int ahead,
+                                              int per_xcd, int *__restrict__ sink)
 {
     __shared__ int s_rank;
     const int t = threadIdx.x;
@@ -1836,6 +1836,21 @@ __global__ __launch_bounds__(256) void k_warm(persist_view pv, const int32_t *__
         }
         if ((int)done >= np || ld_flag(pv.flags + HB_FLAG_ABORT) || (int)done + ahead < q) break;
         if (q < (int)done) continue; // the chain is already past this panel
+        if (rank == (q % per_xcd)) {
+            // the panel's exact per-marker data (what its candidates fetch at the opening): 8 P bytes per array
+            const size_t j0 = (size_t)q * P;
+            for (int i = t * 2; i < P; i += 512) { // 16 bytes per lane
+                const double2 a = *reinterpret_cast<const double2 *>(v.g + j0 + i), b = *reinterpret_cast<const double2 *>(v.xpx + j0 + i);
+                acc += (int)(a.x + a.y + b.x + b.y);
+                for (int c = 0; c < K1; c++) {
+                    const double2 x = *reinterpret_cast<const double2 *>(v.thr + (size_t)c * v.m_pad + j0 + i);
+                    const double2 y = *reinterpret_cast<const double2 *>(v.invv + (size_t)c * v.m_pad + j0 + i);
+                    const double2 z = *reinterpret_cast<const double2 *>(v.sdz + (size_t)c * v.m_pad + j0 + i);
+                    acc += (int)(x.x + y.y + z.x);
+                }
+            }
+            for (int i = t * 4; i < P; i += 1024) acc += reinterpret_cast<const int4 *>(pv.slot_of + j0 + i)->x;
+        }
         const int *hl = pv.hotpack + (size_t)q * HB_HS;
         const int cnt = hl[0];
         const int lmax = min(Lb, np - 1 - q);
@@ -2591,7 +2606,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         int ahead = D + 4;
         if (const char *e = getenv("HB_WARM_AHEAD")) ahead = std::max(1, atoi(e));
-        hipLaunchKernelGGL(k_warm, dim3(8 * warm), dim3(256), 0, c->s_upd, pv, c->gram, c->P, ahead, warm, reinterpret_cast<int *>(c->flags + 48));
+        hipLaunchKernelGGL(k_warm, dim3(8 * warm), dim3(256), 0, c->s_upd, pv, cv, kp, c->gram, c->P, ahead, warm, reinterpret_cast<int *>(c->flags + 48));
         HB_HIP(hipGetLastError());
     }
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
