@@ -723,7 +723,18 @@ struct chain_view {
     double xabs;
 };
 
+// Cycle stamps of the chain kernels (tools/chain_timeline.py): compiled in only with -DHB_STAMPS=1 (tools/build_variant.sh) —
+// thirteen "is profiling on?" branches per panel are a tenth of a quiet panel's instructions.
+#ifndef HB_STAMPS
+#define HB_STAMPS 0
+#endif
+#if HB_STAMPS
 #define HB_STAMP(i) do { if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + (i)] = clock64(); } while (0)
+#define HB_STAMP_VAL(i, x) do { if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + (i)] = (x); } while (0)
+#else
+#define HB_STAMP(i) do { } while (0)
+#define HB_STAMP_VAL(i, x) do { } while (0)
+#endif
 
 __device__ __forceinline__ double readlane_f64(double v, int k)
 {
@@ -1220,7 +1231,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     };
-    const int my_pieces = wave < RW ? (NPC - wave + RW - 1) / RW : 0; // ring pieces this wave issues per group
+    const int my_pieces = __builtin_amdgcn_readfirstlane(wave < RW ? (NPC - wave + RW - 1) / RW : 0); // ring pieces this wave issues per group
     int n_nhot = 0;
 
     // ---- prologue ----
@@ -1275,7 +1286,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bool aborted = false;
         {
             bool bad = __double_as_longlong(dj) == HB_SENT;
-            if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + 11] = bad ? 1 : 0;
+            HB_STAMP_VAL(11, bad ? 1 : 0);
             if (__any(bad)) { // this wave's dots had not been written when the ring slot was filled: re-read until they are
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
@@ -1321,19 +1332,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads(); // the panel's one fixed barrier: wcnt[] staged, ring group of panel p + 1 published; everybody is done with panel p-1
         int tot0 = 0, c1 = -1, c2 = -1; // candidates in the panel; its first two (thread = marker index in the panel)
         {
-            int w8[8], gaveup = 0;
+            int w8[8];
             hb_read8(wcnt, w8);
+            const int any = w8[0] | w8[1] | w8[2] | w8[3] | w8[4] | w8[5] | w8[6] | w8[7]; // a quiet panel decodes nothing
+            if (any >> 24) { ok = false; break; } // a wave gave up waiting for its dots: the sweep is aborted
+            if (any & 0xff) {
 #pragma unroll
-            for (int w = 0; w < 8; w++) {
-                const int cnt = w8[w] & 0xff, a = w * 64 + ((w8[w] >> 8) & 63), b = w * 64 + ((w8[w] >> 14) & 63);
-                tot0 += cnt;
-                gaveup |= w8[w] >> 24;
-                if (cnt) {
-                    if (c1 < 0) { c1 = a; c2 = cnt > 1 ? b : -1; }
-                    else if (c2 < 0) c2 = a;
+                for (int w = 0; w < 8; w++) {
+                    const int cnt = w8[w] & 0xff, a = w * 64 + ((w8[w] >> 8) & 63), b = w * 64 + ((w8[w] >> 14) & 63);
+                    tot0 += cnt;
+                    if (cnt) {
+                        if (c1 < 0) { c1 = a; c2 = cnt > 1 ? b : -1; }
+                        else if (c2 < 0) c2 = a;
+                    }
                 }
             }
-            if (gaveup) { ok = false; break; } // a wave gave up waiting for its dots: the sweep is aborted
         }
         // (2) a panel with candidates: the exact per-marker data, one round trip
         double thr[K1], invv[K1], sdz[K1];
@@ -1498,16 +1511,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     auto decide = [&](double rhsv, int &cls, double &gn) {
                         const double q = rhsv * rhsv;
                         cls = 0;
-                        double iv = 0.0, sz = 0.0;
+                        // (thresholds ascend, and below thr[0] the result is zeroed anyway: class 1's coefficients need no select)
+                        double iv = cinvv[0], sz = csdz[0];
+                        cls = q >= cthr[0] ? 1 : 0;
 #pragma unroll
-                        for (int c = 0; c < K1; c++) {
+                        for (int c = 1; c < K1; c++) {
                             const bool ge = q >= cthr[c];
                             cls += ge ? 1 : 0;
                             iv = ge ? cinvv[c] : iv;
                             sz = ge ? csdz[c] : sz;
                         }
-                        gn = (q >= cthr[0]) ? fma(rhsv, iv, sz) : 0.0; // (thresholds ascend: class > 0 <=> q >= thr[0])
-                        if (model == 5 && fabs(gn) < 1e-6) gn = 1e-6;
+                        gn = (q >= cthr[0]) ? fma(rhsv, iv, sz) : 0.0; // (class > 0 <=> q >= thr[0])
+                        if (K1 == 1 && model == 5 && fabs(gn) < 1e-6) gn = 1e-6; // (BayesL is a one-class model)
                     };
                     if (crowded) {
                         // Dense round: the Gram entries were gathered into cg[][] (zero on and below the diagonal, so a move of
@@ -1641,7 +1656,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             nev = cnts[0];
         }
         HB_STAMP(2);
-        if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + 10] = nev;
+        HB_STAMP_VAL(10, nev);
         HB_STAMP(3);
         if (tot0 > 0) {
             // ---- publish the panel's moves (the update of this group waits for them). Only the last wave does it,

@@ -1,6 +1,10 @@
 """Where the chain workgroup's time goes: cycle stamps of k_chain_persist (hb_ctx_set_profiling bit 1) for one sweep in the
 stationary regime. python tools/chain_timeline.py [model] [burn] [n m]"""
 import os, sys, ctypes as ct
+# the stamps are compiled in only with -DHB_STAMPS=1:  tools/build_variant.sh stamps "-DHB_STAMPS=1"
+_v = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hibayes_amd", "variants", "stamps.so")
+if "HIBAYES_GPU_LIB" not in os.environ and os.path.exists(_v):
+    os.environ["HIBAYES_GPU_LIB"] = _v
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import hibayes_amd as H
