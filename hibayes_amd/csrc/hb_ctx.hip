@@ -116,7 +116,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     // pipeline geometry; hb_ctx_set_pipeline() changes it later
     c->pipeline = 1;
     c->Lv = 2;
-    c->D = 6;
+    c->D = 7;
     if (const char *e = getenv("HB_PIPELINE")) c->pipeline = atoi(e) ? 1 : 0;
     if (const char *e = getenv("HB_LOOKAHEAD")) c->Lv = atoi(e);
     if (const char *e = getenv("HB_DOTGROUP")) c->D = atoi(e);

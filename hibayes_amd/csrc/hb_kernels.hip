@@ -2294,7 +2294,7 @@ static size_t chain_smem(int P) { return (size_t)chain_nslot(P) * P * 4 + (size_
 int hbk_init_attrs()
 {
 #define HB_PERSIST_ATTR(K1, NPL) HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_persist<K1, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-    HB_PERSIST_ATTR(1, 0); HB_PERSIST_ATTR(1, 1); HB_PERSIST_ATTR(1, 17);
+    HB_PERSIST_ATTR(1, 0); HB_PERSIST_ATTR(1, 1); HB_PERSIST_ATTR(1, 17); HB_PERSIST_ATTR(1, 20);
     HB_PERSIST_ATTR(3, 0); HB_PERSIST_ATTR(3, 2);
     HB_PERSIST_ATTR(7, 0); HB_PERSIST_ATTR(7, 2);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2561,6 +2561,7 @@ static hipError_t launch_chain_persist(hb_ctx *c, const chain_view &cv, const pe
 {
     // candidate rows ahead (NPL == Lb) for the band widths of the default geometries; any other band goes without
     if (K1 == 1) {
+        if (pv.Lb == 20) return launch_chain_persist2<1, 20>(c, cv, pv, st); // (Lv, D) = (2, 7)
         if (pv.Lb == 17) return launch_chain_persist2<1, 17>(c, cv, pv, st); // (Lv, D) = (2, 6)
         if (pv.Lb == 1) return launch_chain_persist2<1, 1>(c, cv, pv, st);
         return launch_chain_persist2<1, 0>(c, cv, pv, st);

@@ -304,7 +304,7 @@ int hb_run::setup(const hb_bayes_args *args)
         own_ctx = true;
         // few markers move per sweep in the point-mass models: long look-ahead, big mat-vec launches; where many or
         // all markers move the forward corrections dominate: short look-ahead, one panel per launch
-        if (model_index == 3 || model_index == 4) rc = hb_ctx_set_pipeline(c, 1, 2, 6);
+        if (model_index == 3 || model_index == 4) rc = hb_ctx_set_pipeline(c, 1, 2, 7);
         else rc = hb_ctx_set_pipeline(c, 1, model_index == 6 ? 2 : 1, 1);
         if (rc) return rc;
         if (a.X_i8) rc = hb_ctx_upload_genotype_i8(c, a.X_i8, a.ld_i8, 0, m);

@@ -84,7 +84,7 @@ def test_config2_bayescpi_n10k_m100k_pipeline_vs_serial():
     with H.Context(n, m, seed=2) as c:
         c.generate(20240901, mono_every=1000)
         y = synth_y(c, n, m, 11)
-        a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 6), niter=50, precise=2, nburn=10, thin=2)
+        a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 7), niter=50, precise=2, nburn=10, thin=2)
         same_chain(a, b, 1e-9, "config 2: pipeline (1,2,6) vs serial kernels")
         assert a["timing"]["mean_events"] > 100
 
@@ -95,7 +95,7 @@ def test_config4_shard_shape_bayescpi_n50k_m250k_pipeline_vs_serial():
     with H.Context(n, m, seed=4, m_offset=750000) as c:
         c.generate(20240901, mono_every=1000)
         y = synth_y(c, n, m, 13)
-        a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 6), niter=6, precise=2)
+        a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 7), niter=6, precise=2)
         same_chain(a, b, 1e-9, "config 4 shard: pipeline vs serial")
 
 
@@ -124,15 +124,15 @@ def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=
 
 
 def test_config3_bayescpi_n50k_m500k_draw_for_draw_against_live_oracle():
-    _full_size_vs_oracle(50000, 500000, "BayesCpi", [0.95, 0.05], None, (1, 2, 6), 0)
+    _full_size_vs_oracle(50000, 500000, "BayesCpi", [0.95, 0.05], None, (1, 2, 7), 0)
 
 
 def test_config5_shard_shape_bayesb_n200k_m125k_draw_for_draw_against_live_oracle():
     # rank 5 of 8 of config 5 (BayesB, n = 200k, m_global = 1M)
-    _full_size_vs_oracle(200000, 125000, "BayesB", [0.95, 0.05], None, (1, 2, 6), 625000)
+    _full_size_vs_oracle(200000, 125000, "BayesB", [0.95, 0.05], None, (1, 2, 7), 625000)
 
 
-@pytest.mark.parametrize("model,Pi,fold,geo", [("BayesCpi", [0.95, 0.05], None, (1, 2, 6)),
+@pytest.mark.parametrize("model,Pi,fold,geo", [("BayesCpi", [0.95, 0.05], None, (1, 2, 7)),
                                                 ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1))])
 def test_config3_pipeline_vs_serial_kernels_precise_and_fast(model, Pi, fold, geo):
     """n=50k, m=500k, 3 sweeps from cold. fp64 mat-vec: the pipeline and the serial per-panel kernels must give the same

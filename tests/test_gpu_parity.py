@@ -278,7 +278,7 @@ def test_serialising_environment_falls_back_to_the_per_panel_kernels():
         "import hibayes_amd as H\n"
         "g = np.load(%r)\n"
         "with H.Context(g['X'].shape[0], g['X'].shape[1], precise=2) as c:\n"
-        "    c.upload(g['X']); c.set_pipeline(1, 2, 6)\n"
+        "    c.upload(g['X']); c.set_pipeline(1, 2, 7)\n"
         "    print('NOTE', c.pipeline_note()); print('PIPE', c.pipeline()[0])\n"
         "    r = H.Bayes(g['y'], None, 'BayesCpi', [0.95, 0.05], niter=16, nburn=6, thin=2, seed=424242, verbose=False, ctx=c)\n"
         "    print('ERR', float(np.abs(r['MCMCsamples']['alpha'] - g['BayesCpi_alpha']).max()))\n"

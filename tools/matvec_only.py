@@ -13,7 +13,7 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 with H.Context(n, m, precise=precise, seed=1) as c:
     c.generate(20240901, 1000)
     c.marker_stats()
-    c.set_pipeline(1, 2, 6)
+    c.set_pipeline(1, 2, 7)
     c.set_residual(np.random.default_rng(0).normal(size=n), np.zeros(n))
     ms, nl, nc = c.time_matvec(reps=reps)
     print("precise=%d: %d launches of %d columns, %.2f us per launch, %.3f TB/s" % (precise, nl, nc, ms * 1e3, n * nc / (ms * 1e-3) / 1e12))
