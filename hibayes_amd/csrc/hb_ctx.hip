@@ -932,8 +932,14 @@ int hb_ctx_time_matvec(hb_ctx *c, int32_t reps, double *avg_ms, int32_t *launche
     }
     double us = 0;
     int nl = 0;
-    const int D = c->pipeline ? c->D : 1;
-    rc = hbk_time_matvec(c, D, reps > 0 ? reps : 1, c->pipeline, &us, &nl);
+    int D = c->pipeline ? c->D : 1, as_pipeline = c->pipeline;
+    // (a counter-collecting profiler serialises kernels, the probe then turns the pipeline off and with it the launch width:
+    // the counter passes of tools/matvec_only.py ask for the pipeline's launch shape explicitly)
+    if (const char *e = getenv("HB_TIME_MATVEC_D")) {
+        D = std::max(1, std::min(8, atoi(e)));
+        as_pipeline = 1;
+    }
+    rc = hbk_time_matvec(c, D, reps > 0 ? reps : 1, as_pipeline, &us, &nl);
     if (rc) return rc;
     if (avg_ms) *avg_ms = us * 1e-3;
     if (launches_per_sweep) *launches_per_sweep = nl;
