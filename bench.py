@@ -263,11 +263,28 @@ def main():
         comm = TorchComm(device=torch.device("cuda", local_rank))
         comm.rccl, comm.rccl_note = None, "torch.distributed all_reduce through the library's callback"
         if args.collective == "rccl" and args.backend == "nccl":
-            try:   # the library's own communicator; torch.distributed only ships rank 0's RCCL id
-                comm.rccl = RcclComm.from_torch(local_rank)
+            # the library's own communicator; torch.distributed only ships rank 0's RCCL id. ncclCommInitRank is a blocking
+            # collective: it runs in a helper thread with a deadline, so that a bootstrap that never completes on this node
+            # costs 90 s and the tested torch.distributed path, not the whole run
+            import threading
+            box = {}
+
+            def _init():
+                try:
+                    box["comm"] = RcclComm.from_torch(local_rank)
+                except Exception as e:  # noqa: BLE001
+                    box["err"] = e
+
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("HB_RCCL_INIT_TIMEOUT", "90")))
+            if th.is_alive():
+                comm.rccl_note += " (in-library RCCL: ncclCommInitRank did not return in time)"
+            elif "comm" in box:
+                comm.rccl = box["comm"]
                 comm.rccl_note = "ncclAllReduce inside libhibayes_gpu on the sweep stream, %d ranks" % comm.rccl.L.hb_comm_world(comm.rccl.handle)
-            except Exception as e:
-                comm.rccl_note += " (in-library RCCL unavailable: %r)" % (e,)
+            else:
+                comm.rccl_note += " (in-library RCCL unavailable: %r)" % (box.get("err"),)
             ok = comm.max_int(0 if comm.rccl is not None else 1)   # all ranks or none
             if ok != 0 and comm.rccl is not None:
                 comm.rccl.close()
