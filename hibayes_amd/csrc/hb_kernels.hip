@@ -1006,6 +1006,9 @@ struct persist_view {
 };
 
 #define HB_LBMAX 20
+#ifndef HB_FAST1
+#define HB_FAST1 1 /* single-candidate panels skip the rounds */
+#endif
 #ifndef HB_NPF
 #define HB_NPF 1 /* candidates per panel whose band rows are requested ahead (1 or 2) */
 #endif
@@ -1411,6 +1414,75 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             int t_lo = 0, nev0 = 0;
             bool forced = false;
             bool first = true; // the first round's candidate counts were staged before the panel's opening barrier
+            // ---- a panel with ONE candidate (most panels with a move in the sparse regime): no compaction, no serial pass ----
+            // The candidate publishes its numbers, everybody takes the same decision from them (the chain's own arithmetic),
+            // applies the move to its own rhs and checks that it stayed below its threshold: two barriers instead of four or
+            // five. A marker pushed over its threshold sends the panel through the general rounds below, exactly as a
+            // rolled-back round would.
+            bool fast_done = false;
+            if (HB_FAST1 && tot0 == 1) {
+                if (t == c1) {
+                    cs_d[0] = rhs;
+                    cs_d[64] = gold;
+#pragma unroll
+                    for (int c = 0; c < K1; c++) {
+                        cs_d[(2 + c) * 64] = thr[c];
+                        cs_d[(2 + K1 + c) * 64] = invv[c];
+                        cs_d[(2 + 2 * K1 + c) * 64] = sdz[c];
+                    }
+                    cs_slot[0] = myslot;
+                }
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HB_NPF * NPL) : "memory"); // (the row cache's DMA pieces, as in the rounds)
+                __syncthreads();
+                const double crhs = cs_d[0], cgold = cs_d[64];
+                const int cslot = cs_slot[0];
+                const double q = crhs * crhs;
+                const double cthr0 = cs_d[2 * 64];
+                double iv = cs_d[(2 + K1) * 64], sz = cs_d[(2 + 2 * K1) * 64];
+                int cls = q >= cthr0 ? 1 : 0;
+#pragma unroll
+                for (int c = 1; c < K1; c++) {
+                    const bool ge = q >= cs_d[(2 + c) * 64];
+                    cls += ge ? 1 : 0;
+                    iv = ge ? cs_d[(2 + K1 + c) * 64] : iv;
+                    sz = ge ? cs_d[(2 + 2 * K1 + c) * 64] : sz;
+                }
+                double gn = (q >= cthr0) ? fma(crhs, iv, sz) : 0.0;
+                if (K1 == 1 && model == 5 && fabs(gn) < 1e-6) gn = 1e-6;
+                const bool sel = cgold != 0.0 || q >= cthr0;
+                const int rc = sel ? cls : 0;
+                const double rg = sel ? gn : 0.0;
+                const double dk = rg - cgold;
+                double rhs_new = rhs;
+                if (dk != 0.0) { // uniform
+                    int gv = rowc[max(cslot, 0) * P + t];
+                    if (cslot < 0) gv = gp[(size_t)c1 * P + t];
+                    if (t > c1) rhs_new = fma(-(double)gv, dk, rhs);
+                    if (t == c1) { ev_ix[0] = (cslot << 16) | c1; ev_del[0] = dk; }
+                }
+                const bool viol = t != c1 && active && rhs_new * rhs_new >= thr_lo;
+                const unsigned long long vm = __ballot(viol);
+                if (lane == 0) wviol[wave] = vm != 0ull;
+                __syncthreads();
+                bool anyv = false;
+                {
+                    int w8[8];
+                    hb_read8(wviol, w8);
+                    anyv = (w8[0] | w8[1] | w8[2] | w8[3] | w8[4] | w8[5] | w8[6] | w8[7]) != 0;
+                }
+                if (!anyv) {
+                    fast_done = true;
+                    rhs = rhs_new;
+                    if (t == c1) { cls_f = rc; g_f = rg; }
+                    nev = dk != 0.0 ? 1 : 0;
+                    if (wave == 0) missacc += (dk != 0.0 && cslot < 0) ? 1 : 0;
+                } else { // as a rolled-back round: the markers that crossed join the candidates
+                    forced = viol;
+                    first = false;
+                    if (t == 0) redoacc++;
+                }
+            }
+            if (!fast_done) {
             for (;;) {
                 const bool undec = t >= t_lo;
                 // (the first round's counts were taken with the opening filter: the same predicate must rank them)
@@ -1654,6 +1726,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (t_lo >= P) break;
             }
             nev = cnts[0];
+            }
         }
         HB_STAMP(2);
         HB_STAMP_VAL(10, nev);
