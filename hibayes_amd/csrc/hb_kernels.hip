@@ -523,6 +523,16 @@ __global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
 
 // Sweep start of the fixed-point path: max |yadj| -> mb[0] and the exponent of slot 0, then slot 0's digit planes.
 // One workgroup (n is a few hundred KB).
+__global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, unsigned *__restrict__ flags, int32_t *__restrict__ ev_count,
+                                                    int np, unsigned long long *__restrict__ dsum, int m_pad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (i < HB_ACC_N) acc[i] = 0.0;
+    if (i < HB_NFLAGS) flags[i] = 0u;
+    for (int k = i; k < np; k += stride) ev_count[k] = 0;
+    for (int k = i; k < m_pad; k += stride) dsum[k] = ~0ull;
+}
+
 __global__ __launch_bounds__(1024) void k_quant0(const double *__restrict__ r, int64_t ld, int8_t *__restrict__ rq,
                                                  double *__restrict__ mb, int *__restrict__ vexp)
 {
@@ -2653,12 +2663,20 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     const int np = c->npanels, D = c->D, Lv = c->Lv;
     const int ngroups = (np + D - 1) / D;
     hipStream_t sA = c->stream, sB = c->s_chain;
-    HB_HIP(hipMemsetAsync(c->acc, 0, sizeof(double) * HB_ACC_N, sA));
-    HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * HB_NFLAGS, sA));
-    HB_HIP(hipMemsetAsync(c->ev_count, 0, sizeof(int32_t) * (size_t)np, sA)); // quiet panels do not write theirs
-    HB_HIP(hipMemsetAsync(c->dsum, 0xFF, sizeof(double) * (size_t)c->m_pad, sA)); // "not written yet": a NaN no sum can produce
+    // sweep start: one kernel clears the sweep sums, the flag block, the event counts (quiet panels do not write theirs) and
+    // fills dsum[] with "not written yet" (a NaN no sum can produce); the residual's digit planes are then written (k_quant0,
+    // one workgroup) beside k_pre / k_hotlist, which need all the other compute units. The chain must be launched BEFORE the
+    // first mat-vec launch (it needs a compute unit with all of its LDS free, and back-to-back mat-vec launches never leave
+    // one), so both branches start together after the join.
+    hipLaunchKernelGGL(k_sweep_init, dim3(256), dim3(256), 0, sA, c->acc, c->flags, c->ev_count, np,
+                       reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad);
     const bool fx = c->precise == 2;
-    if (fx) launch_quant0(c, sA);
+    if (fx) {
+        HB_HIP(hipEventRecord(c->ev_dot[0], sA));
+        HB_HIP(hipStreamWaitEvent(sB, c->ev_dot[0], 0));
+        launch_quant0(c, sB);
+        HB_HIP(hipEventRecord(c->ev_upd[1 % np], sB));
+    }
     {
         pre_view pvw{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
         hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pvw);
@@ -2666,6 +2684,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     const int ns = persist_nslot(c->P, c->L, kp);
     hipLaunchKernelGGL(k_hotlist, dim3(np), dim3(c->P), 0, sA, c->d_in, c->vx, c->g, c->thr, c->xpx, c->kappa, c->P, ns, c->hot_slot,
                        c->hot_list, c->thr0f, c->tracker);
+    if (fx) HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[1 % np], 0));
     HB_HIP(hipEventRecord(c->ev_fork, sA));
     HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
     const double xabs = std::max(std::abs((double)c->xmin), std::abs((double)c->xmax));
