@@ -1737,6 +1737,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             nev = cnts[0];
             }
+            // Every load of this panel is consumed HERE on every path, as far as hipcc can see: the exact data and the band rows
+            // are used under conditions (a staged candidate, the prefetched mover), and a load hipcc still counts as possibly
+            // outstanding at the loop's back edge makes it guard the next panel's first reuse of those registers with
+            // s_waitcnt vmcnt(0) — which also drains the DMA pieces issued at the end of this panel (it cannot see them): every
+            // panel, quiet ones included, then waited out a full memory round trip right after its opening barrier.
+            asm volatile("" ::"v"(gold), "v"(xx), "v"(myslot));
+#pragma unroll
+            for (int c = 0; c < K1; c++) asm volatile("" ::"v"(thr[c]), "v"(invv[c]), "v"(sdz[c]));
+#pragma unroll
+            for (int l = 0; l < (NPL > 0 ? NPL : 1); l++) {
+                if (NPL > 0) asm volatile("" ::"v"(pre[0][l]));
+                if (NPL > 0 && HB_NPF > 1) asm volatile("" ::"v"(pre[1][l]));
+            }
         }
         HB_STAMP(2);
         HB_STAMP_VAL(10, nev);
