@@ -1016,6 +1016,9 @@ struct persist_view {
 };
 
 #define HB_LBMAX 20
+#ifndef HB_DECIDE_PAR
+#define HB_DECIDE_PAR 1
+#endif
 #ifndef HB_FAST1
 #define HB_FAST1 1 /* single-candidate panels skip the rounds */
 #endif
@@ -1594,6 +1597,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const double q = rhsv * rhsv;
                         cls = 0;
                         // (thresholds ascend, and below thr[0] the result is zeroed anyway: class 1's coefficients need no select)
+#if HB_DECIDE_PAR
+                        // every class's conditional mean at once (independent fused multiply-adds), then ONE select per class on the
+                        // result instead of two on its coefficients: the same number, a shorter dependent chain per serial step
+                        double gsel = fma(rhsv, cinvv[0], csdz[0]);
+                        cls = q >= cthr[0] ? 1 : 0;
+#pragma unroll
+                        for (int c = 1; c < K1; c++) {
+                            const bool ge = q >= cthr[c];
+                            cls += ge ? 1 : 0;
+                            gsel = ge ? fma(rhsv, cinvv[c], csdz[c]) : gsel;
+                        }
+                        gn = (q >= cthr[0]) ? gsel : 0.0; // (class > 0 <=> q >= thr[0])
+#else
                         double iv = cinvv[0], sz = csdz[0];
                         cls = q >= cthr[0] ? 1 : 0;
 #pragma unroll
@@ -1604,6 +1620,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             sz = ge ? csdz[c] : sz;
                         }
                         gn = (q >= cthr[0]) ? fma(rhsv, iv, sz) : 0.0; // (class > 0 <=> q >= thr[0])
+#endif
                         if (K1 == 1 && model == 5 && fabs(gn) < 1e-6) gn = 1e-6; // (BayesL is a one-class model)
                     };
                     if (crowded) {
