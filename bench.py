@@ -314,6 +314,9 @@ def main():
     note("phenotype built")
     geo = PIPELINE.get(args.model, (1, 1, 1))
     ctx.set_pipeline(*geo)
+    adaptive = geo == (1, 2, 7) and not os.environ.get("HB_NO_ADAPTIVE")
+    if adaptive:
+        ctx.set_adaptive(True)  # narrow band while many markers move (burn-in), this geometry once few do (the timed region)
     gram_s = ctx.build_gram()
     note("Gram blocks built (%.2fs)" % gram_s)
 
@@ -352,7 +355,9 @@ def main():
         "config": {"workload": "%s marker sweep, n=%d individuals x m=%d int8 markers per GPU (m_global=%d), "
                                "panel=%d, pipeline=%s" % (args.model, n, m, m_global, ctx.panel, (geo,)),
                    "model": args.model, "n": n, "m_per_gpu": m, "m_global": m_global, "panel": ctx.panel,
-                   "pipeline": {"persistent_chain": geo[0], "lookahead_groups": geo[1], "panels_per_matvec": geo[2]},
+                   "pipeline": {"persistent_chain": geo[0], "lookahead_groups": geo[1], "panels_per_matvec": geo[2],
+                                "geometry_by_regime": bool(adaptive),
+                                "geometry_of_the_timed_region": list(ctx.pipeline())},
                    "sharding": "markers, contiguous ranges, one residual all-reduce per sweep" if world > 1 else "none",
                    "collective": comm.rccl_note if comm is not None else "none",
                    "mcmc_burn_in_sweeps_before_warmup": args.burnin,

@@ -242,8 +242,10 @@ void hb_ctx_destroy(hb_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
-    if (c->graph) (void)hipGraphDestroy(c->graph);
+    for (auto &ge : c->gcache) {
+        if (ge.e) (void)hipGraphExecDestroy(ge.e);
+        if (ge.g) (void)hipGraphDestroy(ge.g);
+    }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->ev_dot) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev_chain) if (e) (void)hipEventDestroy(e);
@@ -420,10 +422,16 @@ int hb_ctx_set_pipeline(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t 
     c->Lv = lookahead;
     c->D = dotgroup;
     hb_pipeline_geometry(c);
-    if (op != c->pipeline || ol != c->Lv || od != c->D) {
-        c->gram_ready = false;
-        c->graph_model = -1;
-    }
+    (void)op; (void)ol; (void)od;
+    // the stored band serves every geometry whose band fits into it (the captured sweeps are cached per geometry)
+    if (c->L > c->Lg) c->gram_ready = false;
+    return HB_OK;
+}
+
+int hb_ctx_set_adaptive(hb_ctx *c, int32_t on)
+{
+    if (!c) return hb_fail(HB_ERR_INVALID, "hb_ctx_set_adaptive: null context");
+    c->adaptive = on != 0;
     return HB_OK;
 }
 
@@ -431,7 +439,8 @@ int hb_ctx_build_gram(hb_ctx *c, double *seconds)
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_build_gram");
     if (rc) return rc;
-    const size_t need = (size_t)c->m_pad * (size_t)c->P * (size_t)(c->L + 1);
+    c->Lg = c->L; // the band this build stores
+    const size_t need = (size_t)c->m_pad * (size_t)c->P * (size_t)(c->Lg + 1);
     if (need > c->gram_cap) {
         if (c->gram) { (void)hipFree(c->gram); c->gram = nullptr; }
         c->gram_cap = 0;
@@ -461,7 +470,7 @@ int hb_ctx_download_gram(hb_ctx *c, int32_t panel_index, int32_t *G)
     if (rc) return rc;
     if (!c->gram_ready) return hb_fail(HB_ERR_INVALID, "hb_ctx_download_gram: call hb_ctx_build_gram first");
     if (panel_index < 0 || panel_index >= c->npanels) return hb_fail(HB_ERR_INVALID, "hb_ctx_download_gram: bad panel");
-    HB_HIP(hipMemcpy(G, c->gram + (size_t)panel_index * (c->L + 1) * c->P * c->P, sizeof(int32_t) * c->P * c->P, hipMemcpyDeviceToHost));
+    HB_HIP(hipMemcpy(G, c->gram + (size_t)panel_index * (c->Lg + 1) * c->P * c->P, sizeof(int32_t) * c->P * c->P, hipMemcpyDeviceToHost));
     return HB_OK;
 }
 
@@ -470,10 +479,10 @@ int hb_ctx_download_gram_band(hb_ctx *c, int32_t panel_index, int32_t l, int32_t
     int rc = check_cols(c, 0, 0, "hb_ctx_download_gram_band");
     if (rc) return rc;
     if (!c->gram_ready) return hb_fail(HB_ERR_INVALID, "hb_ctx_download_gram_band: call hb_ctx_build_gram first");
-    if (panel_index < 0 || panel_index >= c->npanels || l < 0 || l > c->L)
+    if (panel_index < 0 || panel_index >= c->npanels || l < 0 || l > c->Lg)
         return hb_fail(HB_ERR_INVALID, "hb_ctx_download_gram_band: bad panel or band index");
     HB_HIP(hipStreamSynchronize(c->stream));
-    HB_HIP(hipMemcpy(G, c->gram + ((size_t)panel_index * (c->L + 1) + l) * c->P * c->P, sizeof(int32_t) * c->P * c->P,
+    HB_HIP(hipMemcpy(G, c->gram + ((size_t)panel_index * (c->Lg + 1) + l) * c->P * c->P, sizeof(int32_t) * c->P * c->P,
                      hipMemcpyDeviceToHost));
     return HB_OK;
 }

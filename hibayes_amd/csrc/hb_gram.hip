@@ -130,14 +130,14 @@ int hb_build_gram_impl(hb_ctx *c)
 {
     if (c->P >= HG_T && !getenv("HB_GRAM_UNTILED")) {
         const int nt = c->P / HG_T;
-        hipLaunchKernelGGL(k_gram_tiled, dim3((unsigned)(c->npanels * (c->L + 1) * nt * nt)), dim3(1024), 0, c->stream, c->X, c->ld,
-                           c->P, c->L, c->gram);
+        hipLaunchKernelGGL(k_gram_tiled, dim3((unsigned)(c->npanels * (c->Lg + 1) * nt * nt)), dim3(1024), 0, c->stream, c->X, c->ld,
+                           c->P, c->Lg, c->gram);
         HB_HIP(hipGetLastError());
         return HB_OK;
     }
     const int nb = c->P / 64;
-    hipLaunchKernelGGL(k_gram, dim3((unsigned)(c->npanels * (c->L + 1) * nb * nb)), dim3(64), 0, c->stream, c->X, c->ld, c->P,
-                       c->L, c->gram);
+    hipLaunchKernelGGL(k_gram, dim3((unsigned)(c->npanels * (c->Lg + 1) * nb * nb)), dim3(64), 0, c->stream, c->X, c->ld, c->P,
+                       c->Lg, c->gram);
     HB_HIP(hipGetLastError());
     return HB_OK;
 }

@@ -78,6 +78,8 @@ struct hb_ctx {
     double candf = 1.0;  // chain candidates: markers at zero with q >= candf * thr0 (tuning knob; <= 1)
     double kappa = 3.0; // row-cache prediction: markers with thr0 <= kappa * xx * vare get their Gram row prefetched
     bool gram_ready = false, stats_ready = false;
+    int Lg = 0;       // band blocks per panel (minus one) the stored gram[] was built with: every geometry with L <= Lg runs on it
+    bool adaptive = false; // hb_run picks the geometry per sweep from the number of moves (hb_ctx_set_adaptive)
     int *xinfo = nullptr; // device: [0]=min value, [1]=max value over X
     int xmin = 0, xmax = 0;
 
@@ -115,6 +117,10 @@ struct hb_ctx {
 
     // captured sweep graph, keyed by (model_index, n_fold)
     hipGraphExec_t gexec = nullptr;
+    // captured sweeps by (model, classes, geometry): switching the geometry between sweeps (hb_run's adaptive choice) replays a
+    // cached graph instead of capturing again; graph_model == -1 marks all of them stale (pointers changed)
+    struct graph_entry { int model, fold, pipeline, Lv, D; hipGraph_t g; hipGraphExec_t e; };
+    std::vector<graph_entry> gcache;
     hipGraph_t graph = nullptr;
     int graph_model = -1, graph_fold = -1;
     bool use_graph = true;

@@ -1008,7 +1008,8 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
 // of the next Lb panels through the band Gram blocks  G_l[q][k][t] = x_{pP+k} . x_{qP+t},  l = q - p.
 // ---------------------------------------------------------------------------------------------
 struct persist_view {
-    int npanels, D, Lv, Lb;
+    int npanels, D, Lv, Lb; // Lb: panels of band the chain folds into ((Lv + 1) D - 1)
+    int Lg;                 // band blocks per panel stored in gram[] minus one (>= Lb: one stored band serves every geometry up to it)
     unsigned *flags;
     const int *slot_of, *hotpack;        // per-sweep row-cache lists from k_hotlist
     const float *thr0f;                  // ... and the opening filter
@@ -1283,7 +1284,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int cur = p & 1;
         int32_t *rowc = rowc0;
         int32_t *rown = rowc0;
-        const int32_t *gp = v.gram + (size_t)p * (pv.Lb + 1) * P * P;
+        const int32_t *gp = v.gram + (size_t)p * (pv.Lg + 1) * P * P;
         int *wcnt = wcnt0 + (cur << 5);
         const char *oslotp = oring + (size_t)oslot * OSLOT;
         HB_STAMP(0);
@@ -1330,7 +1331,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool hot = fthr == -__int_as_float(0x7f800000);      // in the model: certain to move
         const bool have_next = p + 1 < np;
         const bool group_end = have_next && pmodD == pv.D - 1;
-        const int32_t *gpn = gp + (size_t)(pv.Lb + 1) * P * P;
+        const int32_t *gpn = gp + (size_t)(pv.Lg + 1) * P * P;
         // who can move at all: certain movers and markers whose q reaches the (rounded-down) entry threshold. For a marker at
         // zero rhs = d - corrections; the exact test follows in the chain.
         bool cand0;
@@ -1408,9 +1409,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (NPL > 0) {
                 __builtin_amdgcn_sched_barrier(0); // (the order of issue is the point: hipcc must not move these ahead of the data above)
                 const int lmax = np - 1 - p;
-                const size_t PP = (size_t)P * P, step = (size_t)(pv.Lb + 2) * PP;
+                const size_t PP = (size_t)P * P, step = (size_t)(pv.Lg + 2) * PP;
                 const int k1 = __builtin_amdgcn_readfirstlane(c1), k2 = __builtin_amdgcn_readfirstlane(c2 < 0 ? c1 : c2);
-                const int32_t *blk = v.gram + ((size_t)(p + 1) * (pv.Lb + 1) + 1) * PP;
+                const int32_t *blk = v.gram + ((size_t)(p + 1) * (pv.Lg + 1) + 1) * PP;
 #pragma unroll
                 for (int l = 1; l <= NPL; l++) {
                     const int32_t *b = l <= lmax ? blk : gp;
@@ -1829,10 +1830,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
             } else if (nev > 0) { // batch shape by band width: as many loads in flight as the registers allow
-                if (pv.Lb <= 2) fold_forward<2, 16>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
-                else if (pv.Lb <= 5) fold_forward<5, 8>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
-                else if (pv.Lb <= 12) fold_forward<12, 2>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
-                else fold_forward<HB_LBMAX, 2>(corrL, R, v.gram, pv.Lb, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                if (pv.Lb <= 2) fold_forward<2, 16>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                else if (pv.Lb <= 5) fold_forward<5, 8>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                else if (pv.Lb <= 12) fold_forward<12, 2>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                else fold_forward<HB_LBMAX, 2>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
             }
         } else {
             cacc[0] += active ? 1 : 0; // a quiet panel: nothing moved, nothing to write
@@ -1948,8 +1949,8 @@ __global__ __launch_bounds__(256) void k_warm(persist_view pv, chain_view v, int
     __syncthreads();
     const int rank = s_rank;
     if (rank < 0) return;
-    const int np = pv.npanels, Lb = pv.Lb;
-    const size_t PP = (size_t)P * P, step = (size_t)(Lb + 2) * PP;
+    const int np = pv.npanels, Lb = pv.Lb, Lg = pv.Lg;
+    const size_t PP = (size_t)P * P, step = (size_t)(Lg + 2) * PP;
     const int quarter = P >> 2;            // int4 lanes per row
     const int rows_per_pass = 256 / quarter; // rows one instruction of this workgroup covers
     int acc = 0;
@@ -1983,8 +1984,8 @@ __global__ __launch_bounds__(256) void k_warm(persist_view pv, chain_view v, int
         const int cnt = hl[0];
         const int lmax = min(Lb, np - 1 - q);
         const int nitem = cnt * (1 + lmax);
-        const int32_t *gp = gram + (size_t)q * (Lb + 1) * PP;
-        const int32_t *fwd = gram + ((size_t)(q + 1) * (Lb + 1) + 1) * PP;
+        const int32_t *gp = gram + (size_t)q * (Lg + 1) * PP;
+        const int32_t *fwd = gram + ((size_t)(q + 1) * (Lg + 1) + 1) * PP;
         const int sub = t / quarter, col = (t - sub * quarter) * 4;
         for (int it = rank * rows_per_pass + sub; it < nitem; it += per_xcd * rows_per_pass) {
             const int mi = it / (1 + lmax), l = it - mi * (1 + lmax);
@@ -2589,7 +2590,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
         HB_HIP(hipStreamWaitEvent(sC, c->ev_fork, 0));
     }
     const double xabs = std::max(std::abs((double)c->xmin), std::abs((double)c->xmax));
-    chain_view cv{c->m_pad, c->P, fx ? 1 : c->nsplit, L, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
+    chain_view cv{c->m_pad, c->P, fx ? 1 : c->nsplit, L, c->Lg, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
@@ -2718,11 +2719,11 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     HB_HIP(hipEventRecord(c->ev_fork, sA));
     HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
     const double xabs = std::max(std::abs((double)c->xmin), std::abs((double)c->xmax));
-    chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->L, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
+    chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->Lg, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
     const int last_panels = np - (ngroups - 1) * D;
-    persist_view pv{np, D, Lv, c->L, c->flags,
+    persist_view pv{np, D, Lv, c->L, c->Lg, c->flags,
                     c->hot_slot, c->hot_list, c->thr0f, c->candf};
     // HB_CHAIN_ALONE=1 — a TIMING DIAGNOSTIC, results are meaningless: the mat-vec launches run first against a pre-set
     // chain_done (their update rows find empty event lists), the chain afterwards with the device to itself; the stamped span
@@ -2794,19 +2795,32 @@ int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
     if (timed) return enqueue_sweep_kernels(c, in->model_index, in->n_fold, true);
     if (!c->use_graph) return c->pipeline ? enqueue_sweep_pipeline(c, in->model_index, in->n_fold)
                                           : enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
-    if (!c->gexec || c->graph_model != in->model_index || c->graph_fold != in->n_fold) {
-        if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-        if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    if (c->graph_model == -1) { // stale: something the graphs point at has moved
+        for (auto &ge : c->gcache) {
+            if (ge.e) (void)hipGraphExecDestroy(ge.e);
+            if (ge.g) (void)hipGraphDestroy(ge.g);
+        }
+        c->gcache.clear();
+        c->gexec = nullptr;
+        c->graph = nullptr;
+        c->graph_model = 0;
+    }
+    c->gexec = nullptr;
+    for (auto &ge : c->gcache)
+        if (ge.model == in->model_index && ge.fold == in->n_fold && ge.pipeline == c->pipeline && ge.Lv == c->Lv && ge.D == c->D) c->gexec = ge.e;
+    if (!c->gexec) {
         HB_HIP(hipStreamSynchronize(c->stream));
         HB_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
         int rc = c->pipeline ? enqueue_sweep_pipeline(c, in->model_index, in->n_fold)
                              : enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
-        hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
         if (rc) return rc;
         if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        HB_HIP(hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
-        c->graph_model = in->model_index;
-        c->graph_fold = in->n_fold;
+        hipGraphExec_t ge = nullptr;
+        HB_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        c->gcache.push_back({in->model_index, in->n_fold, c->pipeline, c->Lv, c->D, g, ge});
+        c->gexec = ge;
     }
     HB_HIP(hipGraphLaunch(c->gexec, c->stream));
     return HB_OK;

@@ -74,6 +74,10 @@ class Context:
         check(self.L.hb_ctx_marker_stats(self.h, xpx.ctypes.data, vx.ctypes.data, C.byref(s), C.byref(z)))
         return xpx, vx, s.value, z.value
 
+    def set_adaptive(self, on=True):
+        """Let Bayes() choose the geometry of each sweep of a point-mass model from the number of moves of the previous one."""
+        check(self.L.hb_ctx_set_adaptive(self.h, 1 if on else 0))
+
     def set_pipeline(self, pipeline=1, lookahead=2, dotgroup=4):
         check(self.L.hb_ctx_set_pipeline(self.h, pipeline, lookahead, dotgroup))
 

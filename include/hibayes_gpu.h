@@ -260,6 +260,12 @@ int hb_ctx_download_gram_band(hb_ctx *c, int32_t panel_index, int32_t l, int32_t
  * per-panel kernels (kernels on two streams are not co-resident here: AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING, a
  * counter-collecting profiler ...). Probed once at hb_ctx_create(); hb_ctx_set_pipeline(1, ...) then keeps pipeline 0. */
 const char *hb_ctx_pipeline_note(const hb_ctx *c);
+/* Geometry by regime. The band Gram blocks are stored once, for the widest band built so far; hb_ctx_set_pipeline() to any
+ * geometry whose band fits reuses them (and the sweeps captured for each geometry are cached). With adaptive != 0,
+ * hb_bayes_run / hb_run_step choose the geometry of each sweep of a point-mass model (BayesB/C) from the number of markers that
+ * moved in the previous one: a narrow band while many move (every move costs one band row per block), the wide band with its
+ * big mat-vec launches once few do. Same chain either way. hb_bayes_run does this by itself for a context it creates. */
+int hb_ctx_set_adaptive(hb_ctx *c, int32_t adaptive);
 /* current geometry: pipeline flag, look-ahead groups, panels per mat-vec launch, band width (blocks l = 1..band) */
 int hb_ctx_get_pipeline(const hb_ctx *c, int32_t *pipeline, int32_t *lookahead, int32_t *dotgroup, int32_t *band);
 /* move lists of the last sweep: ev_count[npanels]; ev_idx / ev_delta are [npanels][P] with ev_count[p] valid entries

@@ -122,3 +122,23 @@ def test_every_band_gram_block_exact(panel, geo):
                 assert np.array_equal(G, (rows.T @ cols).astype(np.int64)), "band block p=%d l=%d" % (p, l)   # int32, bit-exact
                 checked += 1
         assert checked >= npan * (band + 1) - (band + 1) * (band + 2) // 2
+
+
+def test_geometry_by_regime_is_the_same_chain(big):
+    """hb_ctx_set_adaptive: hb_run switches between the narrow band (while many markers move) and the wide one on ONE stored
+    band and cached per-geometry graphs; the chain is the oracle's draw for draw, and the switch really happened."""
+    X, y = big["X"], big["y"]
+    m = X.shape[1]
+    kw = dict(niter=14, nburn=4, thin=2, seed=777)
+    ref = O.bayes(y, X, "BayesCpi", [0.95, 0.05], rng=O.RNG_PHILOX, store_alpha=True, **kw)
+    with H.Context(X.shape[0], m, panel=512, seed=97531) as c:
+        c.upload(X)
+        c.set_pipeline(1, 2, 7)
+        c.build_gram()
+        c.set_adaptive(True)
+        r = H.Bayes(y, None, "BayesCpi", [0.95, 0.05], verbose=False, ctx=c, **kw)
+        geo_end = c.pipeline()
+    _compare(r, ref)
+    # a cold start puts ~26 markers per panel into the model (narrow band); by the end ~1 per panel moves (wide band)
+    assert r["timing"]["mean_events"] > 2.6 * 64 / 4
+    assert geo_end[:3] in ((1, 2, 7), (1, 2, 2))
