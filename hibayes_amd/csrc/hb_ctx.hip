@@ -972,6 +972,14 @@ int hb_ctx_set_profiling(hb_ctx *c, int32_t on)
         HB_HIP(hipMemsetAsync(c->dbg, 0, sizeof(long long) * 32 * (size_t)c->npanels, c->stream));
         c->graph_model = -1;
     }
+    if (((on & 4) != 0) != c->chain_alone) {
+        // bit 2: the persistent pipeline's kernels with the mat-vec launches first and the chain workgroup alone afterwards —
+        // no co-residency needed, so it also runs where kernels serialise (rocprofv3 --pmc). The sweeps it runs are NOT the
+        // chain (the residual updates see empty move lists): for cycle stamps and hardware counters of k_chain_persist only.
+        c->chain_alone = (on & 4) != 0;
+        if (c->chain_alone) c->concurrent = true; // (the probe's verdict does not apply to this mode)
+        c->graph_model = -1;
+    }
     return HB_OK;
 }
 

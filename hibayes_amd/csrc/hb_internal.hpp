@@ -126,6 +126,7 @@ struct hb_ctx {
     bool use_graph = true;
 
     bool profiling = false;
+    bool chain_alone = false; // hb_ctx_set_profiling bit 2: the pipeline's kernels, mat-vec launches first, the chain alone afterwards
     hb_sweep_timing timing{};
     std::vector<hipEvent_t> ev_pool;
 };

@@ -2725,10 +2725,11 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     const int last_panels = np - (ngroups - 1) * D;
     persist_view pv{np, D, Lv, c->L, c->Lg, c->flags,
                     c->hot_slot, c->hot_list, c->thr0f, c->candf};
-    // HB_CHAIN_ALONE=1 — a TIMING DIAGNOSTIC, results are meaningless: the mat-vec launches run first against a pre-set
+    // HB_CHAIN_ALONE=1 / hb_ctx_set_profiling(c, 4) — a TIMING AND COUNTER DIAGNOSTIC, results are meaningless (it needs no
+    // co-resident kernels, so it is also how k_chain_persist runs under a counter-collecting profiler, tools/chain_counters.py): the mat-vec launches run first against a pre-set
     // chain_done (their update rows find empty event lists), the chain afterwards with the device to itself; the stamped span
     // (tools/chain_timeline.py with CT_ALONE=1) is then what the chain costs without the mat-vec's memory traffic beside it.
-    const bool alone = getenv("HB_CHAIN_ALONE") != nullptr;
+    const bool alone = c->chain_alone || getenv("HB_CHAIN_ALONE") != nullptr;
     auto launch_the_chain = [&](hipStream_t st) -> int {
         hipError_t e = kp == 1 ? launch_chain_persist<1>(c, cv, pv, st) : kp == 3 ? launch_chain_persist<3>(c, cv, pv, st)
                                                                                  : launch_chain_persist<7>(c, cv, pv, st);
