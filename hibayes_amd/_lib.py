@@ -57,6 +57,7 @@ class BayesArgs(C.Structure):
         ("ctx", C.c_void_p),
         ("g_init", C.c_void_p),
         ("comm", C.c_void_p),
+        ("sync_blocks", C.c_int32),
     ]
 
 

@@ -849,11 +849,34 @@ int hb_ctx_sweep_begin(hb_ctx *c, const hb_sweep_in *in)
     }
     rc = hb_sweep_enqueue(c, in, c->profiling);
     if (rc) return rc;
-    if (in->count_pip && c->nw) {
+    if (in->count_pip && c->nw && (c->rng_pe == 0 || c->rng_last)) {
         rc = hbk_windows(c);
         if (rc) return rc;
     }
     return HB_OK;
+}
+
+// One block of a sweep that comes in `nblocks` ranges of whole mat-vec groups (sync_every_blocks of the sharded sweep: the
+// caller exchanges the shards' residual deltas between the blocks). Block 0 prepares the sweep, the last block closes it;
+// hb_ctx_sweep_end() fetches the results as usual. Where the persistent pipeline is not available the first block runs the
+// whole sweep with the per-panel kernels and the others do nothing (the exchange between them then moves zeros).
+int hb_ctx_sweep_range(hb_ctx *c, const hb_sweep_in *in, int block, int nblocks)
+{
+    if (!c) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep_range: null context");
+    if (nblocks <= 1) return block == 0 ? hb_ctx_sweep_begin(c, in) : HB_OK;
+    if (!c->pipeline) return block == 0 ? hb_ctx_sweep_begin(c, in) : HB_OK;
+    const int G = (c->npanels + c->D - 1) / c->D;
+    const int nb = std::min(nblocks, G);
+    if (block >= nb) return HB_OK;
+    const int g_lo = (int)((long long)G * block / nb), g_hi = (int)((long long)G * (block + 1) / nb);
+    c->rng_pb = g_lo * c->D;
+    c->rng_pe = std::min(c->npanels, g_hi * c->D);
+    c->rng_first = block == 0;
+    c->rng_last = block == nb - 1;
+    const int rc = hb_ctx_sweep_begin(c, in);
+    c->rng_pe = 0;
+    c->rng_pb = 0;
+    return rc;
 }
 
 int hb_ctx_sweep_end(hb_ctx *c, hb_sweep_out *out)

@@ -119,7 +119,9 @@ struct hb_ctx {
     hipGraphExec_t gexec = nullptr;
     // captured sweeps by (model, classes, geometry): switching the geometry between sweeps (hb_run's adaptive choice) replays a
     // cached graph instead of capturing again; graph_model == -1 marks all of them stale (pointers changed)
-    struct graph_entry { int model, fold, pipeline, Lv, D; hipGraph_t g; hipGraphExec_t e; };
+    struct graph_entry { int model, fold, pipeline, Lv, D, pb, pe; hipGraph_t g; hipGraphExec_t e; };
+    int rng_pb = 0, rng_pe = 0;                 // panels of the (partial) sweep being enqueued; pe == 0: the whole sweep
+    bool rng_first = true, rng_last = true;
     std::vector<graph_entry> gcache;
     hipGraph_t graph = nullptr;
     int graph_model = -1, graph_fold = -1;
@@ -132,6 +134,7 @@ struct hb_ctx {
 };
 
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed);
+extern "C" int hb_ctx_sweep_range(hb_ctx *c, const hb_sweep_in *in, int block, int nblocks);
 extern "C" int hb_ctx_sweep_begin(hb_ctx *c, const hb_sweep_in *in);
 extern "C" int hb_ctx_sweep_end(hb_ctx *c, hb_sweep_out *out);
 int hb_comm_allreduce_f64(hb_comm *c, double *buf, size_t count, hipStream_t st);

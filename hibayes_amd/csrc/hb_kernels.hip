@@ -527,8 +527,8 @@ __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, un
                                                     int np, unsigned long long *__restrict__ dsum, int m_pad)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    if (i < HB_ACC_N) acc[i] = 0.0;
-    if (i < HB_NFLAGS) flags[i] = 0u;
+    if (acc && i < HB_ACC_N) acc[i] = 0.0; // (null: a later range of the same sweep keeps the sums)
+    if (i < HB_NFLAGS && (acc || i != HB_FLAG_ABORT)) flags[i] = 0u; // (a later range keeps an abort raised by an earlier one)
     for (int k = i; k < np; k += stride) ev_count[k] = 0;
     for (int k = i; k < m_pad; k += stride) dsum[k] = ~0ull;
 }
@@ -1010,6 +1010,7 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
 struct persist_view {
     int npanels, D, Lv, Lb; // Lb: panels of band the chain folds into ((Lv + 1) D - 1)
     int Lg;                 // band blocks per panel stored in gram[] minus one (>= Lb: one stored band serves every geometry up to it)
+    int p0;                 // first panel of this (partial) sweep, a multiple of D; npanels is its END (hb_ctx_sweep_range)
     unsigned *flags;
     const int *slot_of, *hotpack;        // per-sweep row-cache lists from k_hotlist
     const float *thr0f;                  // ... and the opening filter
@@ -1182,7 +1183,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int c = 0; c <= K1; c++) cacc[c] = 0;
     int evacc = 0, missacc = 0, redoacc = 0;
     double mbr = v.mb ? v.mb[0] : 0.0; // running bound on max |yadj| (kept by the publishing wave)
-    int gcount = 0;                     // mat-vec groups published so far
+    int gcount = pv.p0 / pv.D;          // mat-vec groups published so far (absolute group index)
 
     // ---- the opening ring ----
     // What the opening of a panel needs — its reduced dots and one filter word per marker (k_hotlist: NaN monomorphic, -inf in
@@ -1259,15 +1260,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     for (int i = t; i < 128; i += P) cnts[i] = 0; // (a 64-marker panel has 64 threads; absent waves' words must read 0)
     if (wave < RW)
-        for (int x = 0; x < HB_RD - 1 && x < np; x++) issue_group(x, x);
+        for (int x = pv.p0; x < pv.p0 + HB_RD - 1 && x < np; x++) issue_group(x, x - pv.p0);
     bool ok = true;
-    {   // row cache 0 for panel 0
-        n_nhot = pv.hotpack[0];
+    {   // the row cache for the first panel
+        const int *hl0 = pv.hotpack + (size_t)pv.p0 * HB_HS;
+        n_nhot = hl0[0];
         const int total = n_nhot << lgP, items = (total + 255) >> 8;
-        const int32_t *gp0 = v.gram;
+        const int32_t *gp0 = v.gram + (size_t)pv.p0 * (pv.Lg + 1) * P * P;
         for (int it = wave; it < items; it += S) {
             const int lin = min((it << 8) + lane * 4, total - 4);
-            const int k = pv.hotpack[4 + (lin >> lgP)];
+            const int k = hl0[4 + (lin >> lgP)];
             *reinterpret_cast<int4 *>(rowc0 + lin) = *reinterpret_cast<const int4 *>(gp0 + ((size_t)k << lgP) + (lin & (P - 1)));
         }
     }
@@ -1276,7 +1278,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     int oslot = -1; // p mod HB_RD
     int pmodD = -1; // p mod D, without a division per panel
-    for (int p = 0; ok && p < np; p++) {
+    for (int p = pv.p0; ok && p < np; p++) {
         pmodD = (pmodD + 1 == pv.D) ? 0 : pmodD + 1;
         pslot = (pslot + 1 == R) ? 0 : pslot + 1;
         oslot = (oslot + 1 == HB_RD) ? 0 : oslot + 1;
@@ -1898,19 +1900,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- sweep totals for the hyper-parameter draws ----
     __syncthreads();
     const double wsum = block_sum(wacc, red);
+    // (+=: a sweep may come in several ranges, hb_ctx_sweep_range; the sweep's first range starts from zeroed sums)
     if (t == 0) {
-        v.acc[HB_ACC_SUMG2] = wsum;
-        v.acc[HB_ACC_EVENTS] = (double)evacc;
+        v.acc[HB_ACC_SUMG2] += wsum;
+        v.acc[HB_ACC_EVENTS] += (double)evacc;
     }
     {
         const double ms = block_sum((double)(lane == 0 ? missacc : 0), red);
-        if (t == 0) v.acc[HB_ACC_MISS] = ms;
-        if (t == 0) v.acc[HB_ACC_REDO] = (double)redoacc;
+        if (t == 0) v.acc[HB_ACC_MISS] += ms;
+        if (t == 0) v.acc[HB_ACC_REDO] += (double)redoacc;
     }
 #pragma unroll
     for (int c = 0; c <= K1; c++) {
         const double cs = block_sum((double)cacc[c], red);
-        if (t == 0 && c < HB_MAX_FOLD) v.acc[HB_ACC_COUNT0 + c] = cs;
+        if (t == 0 && c < HB_MAX_FOLD) v.acc[HB_ACC_COUNT0 + c] += cs;
     }
     if (t == 0 && !ok) { // aborted: the host must see it (fetch_acc checks the flag), then release every waiter
         st_flag(pv.flags + HB_FLAG_ABORT, 1u);
@@ -1954,7 +1957,7 @@ __global__ __launch_bounds__(256) void k_warm(persist_view pv, chain_view v, int
     const int quarter = P >> 2;            // int4 lanes per row
     const int rows_per_pass = 256 / quarter; // rows one instruction of this workgroup covers
     int acc = 0;
-    for (int q = 0; q < np; q++) {
+    for (int q = pv.p0; q < np; q++) {
         // pace: at most `ahead` panels in front of the chain's published progress
         unsigned done;
         const unsigned long long t0 = wall_clock64();
@@ -2688,42 +2691,48 @@ static hipError_t launch_chain_persist(hb_ctx *c, const chain_view &cv, const pe
 // stream B = ONE chain workgroup for the whole sweep.  Device-side hand-offs: mat-vec -> chain through dsum[]
 // (NaN-prefilled, written through by the partial-sum row of the next launch); chain -> update through
 // chain_done; update -> mat-vec is a kernel boundary on stream A.
-static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
+// The panels [pb, pe) of a sweep (pb a multiple of D): the whole sweep, or one block of a sweep whose shards exchange their
+// residual deltas every few mat-vec groups (hb_ctx_sweep_range). A range is self-contained: the residual holds every earlier
+// move when it starts, so its corrections start from zero and its version ring from slot 0. `first` also prepares the
+// per-sweep data (k_pre, k_hotlist, zeroed sums), `last` closes the sweep (BayesL's variances, the residual's sums).
+static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int pe, bool first, bool last)
 {
     const int kp = kpad_for(model, n_fold);
-    const int np = c->npanels, D = c->D, Lv = c->Lv;
-    const int ngroups = (np + D - 1) / D;
+    const int np = pe, D = c->D, Lv = c->Lv;
+    const int g0 = pb / D;                             // absolute index of the range's first mat-vec group
+    const int ngroups = (np - pb + D - 1) / D;         // groups in the range
     hipStream_t sA = c->stream, sB = c->s_chain;
     // sweep start: one kernel clears the sweep sums, the flag block, the event counts (quiet panels do not write theirs) and
     // fills dsum[] with "not written yet" (a NaN no sum can produce); the residual's digit planes are then written (k_quant0,
     // one workgroup) beside k_pre / k_hotlist, which need all the other compute units. The chain must be launched BEFORE the
     // first mat-vec launch (it needs a compute unit with all of its LDS free, and back-to-back mat-vec launches never leave
     // one), so both branches start together after the join.
-    hipLaunchKernelGGL(k_sweep_init, dim3(256), dim3(256), 0, sA, c->acc, c->flags, c->ev_count, np,
+    hipLaunchKernelGGL(k_sweep_init, dim3(256), dim3(256), 0, sA, first ? c->acc : nullptr, c->flags, c->ev_count, c->npanels,
                        reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad);
     const bool fx = c->precise == 2;
     if (fx) {
         HB_HIP(hipEventRecord(c->ev_dot[0], sA));
         HB_HIP(hipStreamWaitEvent(sB, c->ev_dot[0], 0));
         launch_quant0(c, sB);
-        HB_HIP(hipEventRecord(c->ev_upd[1 % np], sB));
+        HB_HIP(hipEventRecord(c->ev_upd[1 % c->npanels], sB));
     }
-    {
+    if (first) {
         pre_view pvw{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
         hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pvw);
     }
     const int ns = persist_nslot(c->P, c->L, kp);
-    hipLaunchKernelGGL(k_hotlist, dim3(np), dim3(c->P), 0, sA, c->d_in, c->vx, c->g, c->thr, c->xpx, c->kappa, c->P, ns, c->hot_slot,
+    // (the hot lists are rebuilt for every range: they hold the effects as they are when the range starts)
+    hipLaunchKernelGGL(k_hotlist, dim3(c->npanels), dim3(c->P), 0, sA, c->d_in, c->vx, c->g, c->thr, c->xpx, c->kappa, c->P, ns, c->hot_slot,
                        c->hot_list, c->thr0f, c->tracker);
-    if (fx) HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[1 % np], 0));
+    if (fx) HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[1 % c->npanels], 0));
     HB_HIP(hipEventRecord(c->ev_fork, sA));
     HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
     const double xabs = std::max(std::abs((double)c->xmin), std::abs((double)c->xmax));
     chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->Lg, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
-    const int last_panels = np - (ngroups - 1) * D;
-    persist_view pv{np, D, Lv, c->L, c->Lg, c->flags,
+    const int last_panels = np - (g0 + ngroups - 1) * D;
+    persist_view pv{np, D, Lv, c->L, c->Lg, pb, c->flags,
                     c->hot_slot, c->hot_list, c->thr0f, c->candf};
     // HB_CHAIN_ALONE=1 / hb_ctx_set_profiling(c, 4) — a TIMING AND COUNTER DIAGNOSTIC, results are meaningless (it needs no
     // co-resident kernels, so it is also how k_chain_persist runs under a counter-collecting profiler, tools/chain_counters.py): the mat-vec launches run first against a pre-set
@@ -2754,20 +2763,22 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
     // reads version g - Lv - 1 and, in one extra grid row, carries update(h = g - Lv): version h-1 -> h, which the
     // NEXT launch reads. Two buffers ping-pong (slot = (version + 1) & 1). No third stream, no cross-stream events.
     auto slot2 = [](int v) { return v < 0 ? 0 : ((v + 1) & 1); };
+    // (g, h: group indices within the range — they drive the version slots; ga, ha: the absolute ones — they address panels)
     for (int g = 0; g < ngroups; g++) {
-        const int p0 = g * D, p1 = std::min(np, p0 + D);
-        const int h = g - Lv;
+        const int ga = g0 + g;
+        const int p0 = ga * D, p1 = std::min(np, p0 + D);
+        const int h = g - Lv, ha = g0 + h;
         upd_view uq{};
-        if (h >= 0) uq = make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags, h);
+        if (h >= 0) uq = make_upd(c, ha * D, std::min(np, ha * D + D), slot2(h - 1), slot2(h), c->flags, ha);
         launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, true, h >= 0 ? &uq : nullptr,
-                   g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0, g);
+                   g > 0 ? (ga - 1) * D * c->P : 0, g > 0 ? D * c->P : 0, ga);
     }
-    launch_reduce(c, (ngroups - 1) * D * c->P, last_panels * c->P, sA, ngroups - 1);
+    launch_reduce(c, (g0 + ngroups - 1) * D * c->P, last_panels * c->P, sA, g0 + ngroups - 1);
     if (alone)
         if (int rc = launch_the_chain(sA)) return rc;
     for (int h = std::max(0, ngroups - Lv); h < ngroups; h++) // the updates that had no later mat-vec to ride on
         hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sA, c->ld,
-                           make_upd(c, h * D, std::min(np, h * D + D), slot2(h - 1), slot2(h), c->flags, h));
+                           make_upd(c, (g0 + h) * D, std::min(np, (g0 + h) * D + D), slot2(h - 1), slot2(h), c->flags, g0 + h));
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
     if (warm) {
@@ -2779,12 +2790,12 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold)
         HB_HIP(hipMemcpyAsync(c->r, c->r + (size_t)sfin * c->ld, sizeof(double) * c->ld, hipMemcpyDeviceToDevice, sA));
         HB_HIP(hipMemcpyAsync(c->r32, c->r32 + (size_t)sfin * c->ld, sizeof(float) * c->ld, hipMemcpyDeviceToDevice, sA));
     }
-    if (model == 5) {
+    if (model == 5 && last) {
         hipLaunchKernelGGL(k_bayesl_post, dim3((c->m + 255) / 256), dim3(256), 0, sA, c->d_in, c->m, c->m_offset, c->seed,
                            c->vx, c->g, c->vargL);
         hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(1024), 0, sA, c->vargL, c->m, c->acc + HB_ACC_SUMVARGL);
     }
-    hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(1024), 0, sA, c->r, c->u, c->n, c->acc);
+    if (last) hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(1024), 0, sA, c->r, c->u, c->n, c->acc);
     HB_HIP(hipGetLastError());
     return HB_OK;
 }
@@ -2794,8 +2805,13 @@ int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
     *c->h_in = *in;
     HB_HIP(hipMemcpyAsync(c->d_in, c->h_in, sizeof(hb_sweep_in), hipMemcpyHostToDevice, c->stream));
     if (timed) return enqueue_sweep_kernels(c, in->model_index, in->n_fold, true);
-    if (!c->use_graph) return c->pipeline ? enqueue_sweep_pipeline(c, in->model_index, in->n_fold)
-                                          : enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
+    const int pb = c->rng_pe ? c->rng_pb : 0, pe = c->rng_pe ? c->rng_pe : c->npanels;
+    const bool first = c->rng_pe ? c->rng_first : true, last = c->rng_pe ? c->rng_last : true;
+    auto enqueue = [&]() {
+        return c->pipeline ? enqueue_sweep_pipeline(c, in->model_index, in->n_fold, pb, pe, first, last)
+                           : enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
+    };
+    if (!c->use_graph) return enqueue();
     if (c->graph_model == -1) { // stale: something the graphs point at has moved
         for (auto &ge : c->gcache) {
             if (ge.e) (void)hipGraphExecDestroy(ge.e);
@@ -2808,19 +2824,20 @@ int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
     }
     c->gexec = nullptr;
     for (auto &ge : c->gcache)
-        if (ge.model == in->model_index && ge.fold == in->n_fold && ge.pipeline == c->pipeline && ge.Lv == c->Lv && ge.D == c->D) c->gexec = ge.e;
+        if (ge.model == in->model_index && ge.fold == in->n_fold && ge.pipeline == c->pipeline && ge.Lv == c->Lv && ge.D == c->D &&
+            ge.pb == pb && ge.pe == pe)
+            c->gexec = ge.e;
     if (!c->gexec) {
         HB_HIP(hipStreamSynchronize(c->stream));
         HB_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-        int rc = c->pipeline ? enqueue_sweep_pipeline(c, in->model_index, in->n_fold)
-                             : enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
+        int rc = enqueue();
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(c->stream, &g);
         if (rc) return rc;
         if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         hipGraphExec_t ge = nullptr;
         HB_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        c->gcache.push_back({in->model_index, in->n_fold, c->pipeline, c->Lv, c->D, g, ge});
+        c->gcache.push_back({in->model_index, in->n_fold, c->pipeline, c->Lv, c->D, pb, pe, g, ge});
         c->gexec = ge;
     }
     HB_HIP(hipGraphLaunch(c->gexec, c->stream));

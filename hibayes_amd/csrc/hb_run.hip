@@ -84,6 +84,7 @@ struct hb_run {
     int iter = 0, count = 0, nzct = 0;
     long long NnzSnp = 0;
     double mu_sum = 0, vara_sum = 0, vare_sum = 0, hsq_sum = 0, events_sum = 0, miss_sum = 0, redo_sum = 0;
+    int sync_blocks = 1;       // runs of mat-vec groups per sweep, an exchange after each (hb_bayes_args.sync_blocks)
     bool adaptive_geo = false; // choose (Lv, D) per sweep from the previous sweep's moves (BayesB/C)
     int geo_cur = 0;           // 0: (2, 7), 1: (2, 2)
     double last_events_pp = 0;
@@ -190,6 +191,7 @@ int hb_run::setup(const hb_bayes_args *args)
         a.rank = hb_comm_rank(a.comm);
     }
     sharded = world > 1 || a.comm != nullptr; // (a one-rank communicator still runs the exchange path)
+    sync_blocks = std::max(1, std::min(64, (int)a.sync_blocks));
     m_global = (world > 1 || a.m_global > 0) ? a.m_global : m;
     if (world > 1 && ((!a.allreduce && !a.comm) || m_global < m))
         return hb_fail(HB_ERR_INVALID, "hb_bayes_run: sharded run needs a communicator (comm or allreduce) and m_global");
@@ -519,10 +521,6 @@ int hb_run::step()
     in.lambda2 = lambda2;
     in.count_pip = (iter >= nburn) && !always_in;
     in.store = (iter >= nburn) && ((iter + 1 - nburn) % thin == 0);
-    if (sharded) {
-        HB_HIP(hipMemcpyAsync(r0, c->r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
-        HB_HIP(hipMemcpyAsync(u0, c->u, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
-    }
     hb_sweep_out so{};
     // geometry by regime (point-mass models, when the context is ours or its owner asked for it): while many markers move
     // every move costs one band row per block of the band, so a narrow band wins; once few move, the wide band with its
@@ -539,21 +537,32 @@ int hb_run::step()
             geo_cur = want;
         }
     }
-    rc = hb_ctx_sweep_begin(c, &in);
-    if (rc) return rc;
-    if (sharded) {
-        // once per sweep: sum the shards' residual deltas (n doubles; u moves by the negative) and the 16 scalar sums — all
-        // enqueued on the sweep stream behind the sweep itself; the iteration's only host synchronisation is the fetch below
-        rc = hbk_delta_pack(c, r0, u0, xbuf);
+    // The sweep, in sync_blocks runs of mat-vec groups (1: the whole sweep). After each run the shards sum their residual
+    // deltas (n doubles; u moves by the negative) — and, after the last one, the 16 scalar sums — all enqueued on the sweep
+    // stream behind the run itself; the iteration's only host synchronisation is the fetch below.
+    for (int b = 0; b < sync_blocks; b++) {
+        if (sharded) {
+            HB_HIP(hipMemcpyAsync(r0, c->r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+            HB_HIP(hipMemcpyAsync(u0, c->u, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+        }
+        rc = hb_ctx_sweep_range(c, &in, b, sync_blocks);
         if (rc) return rc;
-        HB_HIP(hipMemcpyAsync(xbuf + (size_t)n, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
-        rc = exchange();
-        if (rc) return rc;
-        rc = hbk_delta_unpack(c, r0, u0, xbuf);
-        if (rc) return rc;
-        HB_HIP(hipMemcpyAsync(c->acc, xbuf + (size_t)n, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
-        rc = hbk_reduce_ru(c);
-        if (rc) return rc;
+        if (sharded) {
+            const bool last = b == sync_blocks - 1;
+            rc = hbk_delta_pack(c, r0, u0, xbuf);
+            if (rc) return rc;
+            // (the sums ride along every time — the message has one shape — but only the last run's are the sweep's)
+            HB_HIP(hipMemcpyAsync(xbuf + (size_t)n, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
+            rc = exchange();
+            if (rc) return rc;
+            rc = hbk_delta_unpack(c, r0, u0, xbuf);
+            if (rc) return rc;
+            if (last) {
+                HB_HIP(hipMemcpyAsync(c->acc, xbuf + (size_t)n, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
+                rc = hbk_reduce_ru(c);
+                if (rc) return rc;
+            }
+        }
     }
     rc = hb_ctx_sweep_end(c, &so);
     if (rc) return rc;

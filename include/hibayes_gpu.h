@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 2
+#define HB_ABI_VERSION 3
 #define HB_MAX_FOLD 8
 
 typedef enum {
@@ -141,6 +141,11 @@ typedef struct hb_bayes_args {
     /* in-library RCCL collective (takes precedence over `allreduce`); with world == 1 the exchange path still runs,
      * which is how a one-GPU box exercises it */
     hb_comm *comm;
+    /* the sharded sweep's `sync_every_blocks` knob (ABI 3): the shards exchange their residual deltas this many
+     * times per sweep, after equal runs of mat-vec groups, instead of once at its end (0 or 1). Inside a run a shard still does
+     * not see the other shards' moves; more exchanges = less of that staleness (and of the bias it causes where the shards'
+     * markers are correlated), at one all-reduce and one pipeline drain each. Unsharded, the chain does not depend on it. */
+    int32_t sync_blocks;
 } hb_bayes_args;
 
 /* number of doubles exchanged per sweep for n individuals: the residual delta (u moves by its negative) + 16 scalar sums */

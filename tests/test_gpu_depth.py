@@ -142,3 +142,20 @@ def test_geometry_by_regime_is_the_same_chain(big):
     # a cold start puts ~26 markers per panel into the model (narrow band); by the end ~1 per panel moves (wide band)
     assert r["timing"]["mean_events"] > 2.6 * 64 / 4
     assert geo_end[:3] in ((1, 2, 7), (1, 2, 2))
+
+
+@pytest.mark.parametrize("model,Pi,fold,blocks", [("BayesCpi", [0.95, 0.05], None, 4), ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], 3),
+                                                  ("BayesRR", [0.95, 0.05], None, 5)])
+def test_a_sweep_in_blocks_is_the_same_chain(big, model, Pi, fold, blocks):
+    """hb_bayes_args.sync_blocks cuts a sweep into runs of whole mat-vec groups (each run a self-contained pipeline: chain,
+    mat-vec launches, updates, drain); unsharded nothing is exchanged between them, and the chain must be the oracle's draw
+    for draw — which checks the range machinery (first / last run, version slots, absolute group indices) by itself."""
+    X, y = big["X"], big["y"]
+    if model == "BayesRR":
+        X = X[:, :8192]
+    kw = dict(niter=8, nburn=2, thin=2, seed=4242)
+    if fold is not None:
+        kw["fold"] = fold
+    ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, **kw)
+    r = H.Bayes(y, X, model, Pi, verbose=False, sync_every_blocks=blocks, **kw)
+    _compare(r, ref)

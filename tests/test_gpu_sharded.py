@@ -153,3 +153,64 @@ def test_sharded_posterior_against_the_single_gpu_posterior():
             report.append("%s %s: correlation of posterior-mean effects %.4f" % (kind, model, cc))
             assert cc > (0.97 if kind == "wide" else 0.7), report[-1]
     print("\n".join(report))
+
+
+def _worker_sync(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hibayes_amd as H
+    from hibayes_amd.dist import TorchComm, shard_range
+    comm = TorchComm(device=torch.device("cuda", 0))
+    y, X = _stat_data("wide")
+    lo, hi = shard_range(X.shape[1], rank, world)
+    out = {}
+    for blocks in (1, 4):
+        for seed in (1, 2):
+            f = H.Bayes(y, np.asfortranarray(X[:, lo:hi]), "BayesRR", [0.95, 0.05], seed=seed, comm=comm, m_global=X.shape[1],
+                        m_offset=lo, panel=64, sync_every_blocks=blocks, niter=1500, nburn=500, thin=5, verbose=False, store_alpha=False)
+            out[(blocks, seed)] = (f["Vg"], f["Ve"], f["g"])
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sync_every_blocks_tightens_the_sharded_sweep():
+    """hb_bayes_args.sync_blocks (SURVEY §8e's sync_every_blocks): the shards exchange their residual deltas several times per
+    sweep. BayesRR on the 'wide' data is the case a once-per-sweep exchange biases most (every marker moves, two dense shards
+    fit the same residual: Vg about -18 %, Ve about +30 %). Checked: the replicas stay in lock-step, and with 4 exchanges per
+    sweep the residual variance — the quantity the stale residual inflates — is within a few per cent of the single-GPU
+    posterior (+3 % measured). What the knob does NOT do is remove the bias of a partially synchronous sweep: two blocks
+    updated at once against the same residual both fit the signal they share, and Vg goes from -18 % through zero (between 2
+    and 3 exchanges on these data) to +23 % at 4 and beyond at 8 (a numpy emulation of the scheme shows the same sign change),
+    so the test bounds Vg and DESIGN.md §8 recommends 2 exchanges, 1 for the sparse models."""
+    import torch.multiprocessing as mp
+    import hibayes_amd as H
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker_sync, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=860) for _ in ps)
+    for p in ps:
+        p.join(timeout=30)
+    y, X = _stat_data("wide")
+    one = [H.Bayes(y, X, "BayesRR", [0.95, 0.05], seed=s, panel=64, niter=1500, nburn=500, thin=5, verbose=False, store_alpha=False)
+           for s in (11, 12)]
+    vg1, ve1 = np.mean([f["Vg"] for f in one]), np.mean([f["Ve"] for f in one])
+    bias = {}
+    for blocks in (1, 4):
+        for seed in (1, 2):
+            assert res[0][(blocks, seed)][0] == res[1][(blocks, seed)][0] and res[0][(blocks, seed)][1] == res[1][(blocks, seed)][1]
+            assert np.array_equal(res[0][(blocks, seed)][2], res[1][(blocks, seed)][2])          # g = X g_last: replicated
+        vg = np.mean([res[0][(blocks, s)][0] for s in (1, 2)])
+        ve = np.mean([res[0][(blocks, s)][1] for s in (1, 2)])
+        bias[blocks] = ((vg - vg1) / vg1, (ve - ve1) / ve1)
+    print("single GPU: Vg %.4g Ve %.4g; sharded, 1 exchange per sweep: %+.1f %% / %+.1f %%; 4 exchanges: %+.1f %% / %+.1f %%" % (
+        vg1, ve1, 100 * bias[1][0], 100 * bias[1][1], 100 * bias[4][0], 100 * bias[4][1]))
+    assert abs(bias[1][1]) > 0.15                      # the inflated residual variance this knob exists for is really there ...
+    assert abs(bias[4][1]) < 0.3 * abs(bias[1][1])     # ... and four exchanges per sweep remove most of it
+    assert abs(bias[4][0]) < 0.4                       # Vg: -18 % -> about +23 % (documented sign change), bounded
