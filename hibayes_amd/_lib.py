@@ -128,7 +128,7 @@ SYMBOLS = [
     "hb_ctx_marker_stats", "hb_ctx_build_gram", "hb_ctx_download_gram", "hb_ctx_set_residual",
     "hb_ctx_get_residual", "hb_ctx_set_effects", "hb_ctx_get_effects", "hb_ctx_dot", "hb_ctx_residual_sums",
     "hb_ctx_residual_shift", "hb_ctx_set_covariates", "hb_ctx_cov_dot", "hb_ctx_cov_axpy", "hb_ctx_set_levels",
-    "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_blocks_setup", "hb_ctx_blocks_step", "hb_ctx_blocks_state", "hb_ctx_sweep", "hb_ctx_get_counters", "hb_ctx_set_windows",
+    "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_blocks_setup", "hb_ctx_blocks_step", "hb_ctx_blocks_state", "hb_ctx_sweep", "hb_ctx_sweep_range", "hb_ctx_sweep_end", "hb_ctx_get_counters", "hb_ctx_set_windows",
     "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec",
     "hb_ctx_download_gram_band", "hb_ctx_set_adaptive", "hb_ctx_get_pipeline", "hb_ctx_get_events", "hb_ctx_pipeline_note", "hb_ctx_matmul",
     "hb_comm_unique_id", "hb_comm_init", "hb_comm_world", "hb_comm_rank", "hb_comm_destroy",
@@ -206,6 +206,8 @@ def lib():
     L.hb_ctx_blocks_step.argtypes = [vp, dbl, vp, vp, vp, dbl, dbl]
     L.hb_ctx_blocks_state.argtypes = [vp, vp, vp, vp, vp]
     L.hb_ctx_sweep.argtypes = [vp, C.POINTER(SweepIn), C.POINTER(SweepOut)]
+    L.hb_ctx_sweep_range.argtypes = [vp, C.POINTER(SweepIn), i32, i32]
+    L.hb_ctx_sweep_end.argtypes = [vp, C.POINTER(SweepOut)]
     L.hb_ctx_get_counters.argtypes = [vp, vp, vp, vp]
     L.hb_ctx_set_windows.argtypes = [vp, vp, i32]
     L.hb_ctx_get_windows.argtypes = [vp, vp]

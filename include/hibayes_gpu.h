@@ -342,6 +342,13 @@ typedef struct hb_sweep_out {
 } hb_sweep_out;
 
 int hb_ctx_sweep(hb_ctx *c, const hb_sweep_in *in, hb_sweep_out *out);
+/* The same sweep in pieces, for a caller that exchanges residual deltas between them (hb_bayes_args.sync_blocks does exactly
+ * this): block b of nblocks enqueues the panels of its share of the mat-vec groups as a self-contained pipeline — block 0 also
+ * prepares the sweep, the last block closes it — and returns without waiting; hb_ctx_sweep_end() then fetches the sweep's sums.
+ * The residual may be modified on the context's stream between two blocks (hb_ctx_set_residual / an all-reduce on it).
+ * nblocks == 1 is hb_ctx_sweep() split into begin and end. */
+int hb_ctx_sweep_range(hb_ctx *c, const hb_sweep_in *in, int32_t block, int32_t nblocks);
+int hb_ctx_sweep_end(hb_ctx *c, hb_sweep_out *out);
 /* nzrate counters (m, as doubles), alpha sum / sum of squares over stored records */
 int hb_ctx_get_counters(hb_ctx *c, double *nzrate, double *alpha_sum, double *alpha_sq);
 int hb_ctx_set_windows(hb_ctx *c, const uint32_t *windindx, int32_t nw);
