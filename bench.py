@@ -326,7 +326,8 @@ def main():
     curve_main = list(getattr(measure, "curve", []))
     curve_main.append({"sweeps": "timed region", "moves_per_sweep": round(mean_events, 1), "sweeps_per_s": round(world * K / elapsed, 2)})
     # the dominant kernel on its own: the sweep's mat-vec launches, back to back, HIP events on their stream
-    avg_ms, launches, cols = ctx.time_matvec(reps=3)
+    ctx.time_matvec(reps=1)                                   # (untimed: clocks and TLBs as in the steady state of a run)
+    avg_ms, launches, cols = ctx.time_matvec(reps=5)
     alg_bytes = float(n) * cols  # one read of the launch's int8 genotypes (SURVEY.md §8 d: n*m per sweep)
     ach = alg_bytes / (avg_ms * 1e-3) / 1e9
     # HBM bytes per launch: from the separate rocprofv3 --pmc FETCH_SIZE pass kept under profiles/ (counters cannot be read
