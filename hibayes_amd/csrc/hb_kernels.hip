@@ -1020,6 +1020,9 @@ struct persist_view {
 };
 
 #define HB_LBMAX 20
+#ifndef HB_FOLD_GATHER
+#define HB_FOLD_GATHER 1 /* the fold's moves gathered with one LDS pass + v_readlane */
+#endif
 #ifndef HB_DECIDE_PAR
 #define HB_DECIDE_PAR 1
 #endif
@@ -1095,11 +1098,25 @@ __device__ __forceinline__ void fold_forward(double *corrL, int R, const int32_t
         int gv[LB][FW];
         int kk[FW];
         double dl[FW];
+        if (HB_FOLD_GATHER && FW >= 8) { // (the wide batches of the narrow bands: dense sweeps; two moves at a time gain nothing)
+            // the batch's moves in ONE pass over LDS: lane f reads move e0 + f, every lane then takes them lane by lane
+            // (v_readlane: wave-uniform row addresses without a read-and-wait per move); a lane past the list holds row 0, delta 0
+            const int lane_ = t & 63, e = e0 + lane_;
+            const bool have = lane_ < FW && e < nev;
+            const int ixl = have ? ev_ix[e] : 0;
+            const double dll = have ? ev_del[e] : 0.0;
 #pragma unroll
-        for (int f = 0; f < FW; f++) {
-            const int e = min(e0 + f, nev - 1);
-            kk[f] = __builtin_amdgcn_readfirstlane(ev_ix[e] & 0xffff); // wave-uniform: the row addresses below are scalar
-            dl[f] = (e0 + f < nev) ? ev_del[e] : 0.0;
+            for (int f = 0; f < FW; f++) {
+                kk[f] = __builtin_amdgcn_readlane(ixl, f) & 0xffff;
+                dl[f] = readlane_f64(dll, f);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < FW; f++) {
+                const int e = min(e0 + f, nev - 1);
+                kk[f] = __builtin_amdgcn_readfirstlane(ev_ix[e] & 0xffff); // wave-uniform: the row addresses below are scalar
+                dl[f] = (e0 + f < nev) ? ev_del[e] : 0.0;
+            }
         }
         // block l of panel p + l starts at ((p + l)(Lb + 1) + l) P P: consecutive l are (Lb + 2) P P apart
         const int32_t *blk = gram + ((size_t)(p + 1) * (Lb + 1) + 1) * PP;
@@ -1834,7 +1851,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
             } else if (nev > 0) { // batch shape by band width: as many loads in flight as the registers allow
-                if (pv.Lb <= 2) fold_forward<2, 16>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                // (a kernel specialised for one band width — NPL == Lb — carries only that width's fold: the others would
+                // be dead code that still costs registers in the loop every panel runs)
+                if (NPL > 12) fold_forward<HB_LBMAX, 2>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                else if (NPL > 0 && NPL <= 2) fold_forward<2, 16>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                else if (pv.Lb <= 2) fold_forward<2, 16>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
                 else if (pv.Lb <= 5) fold_forward<5, 8>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
                 else if (pv.Lb <= 12) fold_forward<12, 2>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
                 else fold_forward<HB_LBMAX, 2>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
