@@ -271,7 +271,9 @@ def main():
 
             def _init():
                 try:
-                    box["comm"] = RcclComm.from_torch(local_rank)
+                    rc = RcclComm.from_torch(local_rank)
+                    rc.selftest()          # one all-reduce with a known answer, still under the deadline
+                    box["comm"] = rc
                 except Exception as e:  # noqa: BLE001
                     box["err"] = e
 

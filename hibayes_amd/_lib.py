@@ -131,7 +131,7 @@ SYMBOLS = [
     "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_blocks_setup", "hb_ctx_blocks_step", "hb_ctx_blocks_state", "hb_ctx_sweep", "hb_ctx_sweep_range", "hb_ctx_sweep_end", "hb_ctx_get_counters", "hb_ctx_set_windows",
     "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec",
     "hb_ctx_download_gram_band", "hb_ctx_set_adaptive", "hb_ctx_get_pipeline", "hb_ctx_get_events", "hb_ctx_pipeline_note", "hb_ctx_matmul",
-    "hb_comm_unique_id", "hb_comm_init", "hb_comm_world", "hb_comm_rank", "hb_comm_destroy",
+    "hb_comm_unique_id", "hb_comm_init", "hb_comm_world", "hb_comm_rank", "hb_comm_selftest", "hb_comm_destroy",
     "hb_run_create", "hb_run_step", "hb_run_state", "hb_run_ctx", "hb_run_finish", "hb_run_destroy",
 ]
 
@@ -185,6 +185,7 @@ def lib():
     L.hb_comm_init.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
     L.hb_comm_world.argtypes = [vp]
     L.hb_comm_rank.argtypes = [vp]
+    L.hb_comm_selftest.argtypes = [vp]
     L.hb_comm_destroy.argtypes = [vp]
     L.hb_comm_destroy.restype = None
     L.hb_ctx_pipeline_note.argtypes = [vp]

@@ -53,6 +53,8 @@ struct hb_comm {
     int rank = 0, world = 1, device = 0;
 };
 
+int hb_comm_allreduce_f64(hb_comm *c, double *buf, size_t count, hipStream_t st);
+
 extern "C" {
 
 int hb_comm_unique_id(void *id128)
@@ -99,6 +101,32 @@ int hb_comm_world(const hb_comm *c)
 }
 
 int hb_comm_rank(const hb_comm *c) { return c ? c->rank : -1; }
+
+// One small all-reduce with a known answer (every rank contributes rank + 1 in 16 doubles), synchronised: a caller can
+// run it under its own deadline right after hb_comm_init() and fall back to another collective if the fabric does not
+// deliver, instead of finding out inside the first sweep.
+int hb_comm_selftest(hb_comm *c)
+{
+    if (!c || !c->comm) return hb_fail(HB_ERR_COMM, "hb_comm_selftest: no communicator");
+    HB_HIP(hipSetDevice(c->device));
+    double h[16], *d = nullptr;
+    for (double &v : h) v = (double)(c->rank + 1);
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&d), sizeof(h)));
+    hipStream_t st = nullptr;
+    HB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HB_HIP(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, st));
+    int rc = hb_comm_allreduce_f64(c, d, 16, st);
+    if (!rc) {
+        HB_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+        HB_HIP(hipStreamSynchronize(st));
+        const double want = 0.5 * c->world * (c->world + 1);
+        for (double v : h)
+            if (v != want) rc = hb_fail(HB_ERR_COMM, "hb_comm_selftest: the all-reduce returned a wrong sum");
+    }
+    (void)hipStreamDestroy(st);
+    (void)hipFree(d);
+    return rc;
+}
 
 void hb_comm_destroy(hb_comm *c)
 {

@@ -126,6 +126,11 @@ class RcclComm:
         side = TorchComm(device=torch.device("cuda", device_index) if on_gpu else torch.device("cpu"), group=group)
         return cls(rank, world, device_index, share=share, side=side)
 
+    def selftest(self):
+        """One small all-reduce with a known answer through the library's communicator (raises if the sum is wrong)."""
+        from ._lib import check
+        check(self.L.hb_comm_selftest(self.handle))
+
     def max_int(self, v):
         return int(v) if self.world == 1 else self.side.max_int(v)
 

@@ -65,6 +65,7 @@ int hb_comm_unique_id(void *id_out /* HB_COMM_ID_BYTES */);
 int hb_comm_init(hb_comm **out, const void *id, int32_t rank, int32_t world, int32_t device);
 int hb_comm_world(const hb_comm *c);   /* ranks RCCL reports for the communicator */
 int hb_comm_rank(const hb_comm *c);
+int hb_comm_selftest(hb_comm *c);     /* one 16-double all-reduce with a known answer, synchronised (run it under a deadline) */
 void hb_comm_destroy(hb_comm *c);
 typedef struct hb_ctx hb_ctx; /* device context of one genotype shard, see the engine API below */
 /* called once per iteration from the calling thread; non-zero return stops the run

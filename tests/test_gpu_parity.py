@@ -304,6 +304,7 @@ def test_in_library_rccl_exchange_world_1_is_the_plain_chain(demo):
     from hibayes_amd.dist import RcclComm
     comm = RcclComm(0, 1, 0)
     assert comm.L.hb_comm_world(comm.handle) == 1
+    comm.selftest()           # hb_comm_selftest: one all-reduce with a known answer (what bench.py runs under its deadline)
     kw = dict(niter=60, nburn=20, thin=5, seed=99, verbose=False)
     a = H.Bayes(demo["y"], demo["M"], "BayesCpi", [0.95, 0.05], comm=comm, **kw)
     b = H.Bayes(demo["y"], demo["M"], "BayesCpi", [0.95, 0.05], **kw)
