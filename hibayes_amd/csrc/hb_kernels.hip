@@ -1020,6 +1020,9 @@ struct persist_view {
 };
 
 #define HB_LBMAX 20
+#ifndef HB_APPLY_PREFIX
+#define HB_APPLY_PREFIX 1 /* a wave applies only the prefix of a round's moves that can touch it */
+#endif
 #ifndef HB_FOLD_GATHER
 #define HB_FOLD_GATHER 1 /* the fold's moves gathered with one LDS pass + v_readlane */
 #endif
@@ -1726,13 +1729,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int nev1 = cnts[0];
                 // everybody still undecided applies the round's moves (those of earlier markers) to its own rhs
                 double rhs_new = rhs;
+                // (the round's moves are listed in marker order, and a move only touches later markers: a wave needs the moves of
+                // the markers before its last one — a prefix of the list, on average half of it)
+                int nap = nev1;
+#if HB_APPLY_PREFIX
+                {
+                    const int nr = nev1 - nev0; // <= 64: one lane per move
+                    const int kl = lane < nr ? (ev_ix[nev0 + lane] & 0xffff) : 0x7fffffff;
+                    nap = nev0 + __popcll(__ballot(kl < ((t | 63))));
+                }
+#endif
                 if (undec && !inr) {
-                    for (int e0 = nev0; e0 < nev1; e0 += 8) {
+                    for (int e0 = nev0; e0 < nap; e0 += 8) {
                         int rec[8], gv[8];
                         double dl[8];
 #pragma unroll
                         for (int q8 = 0; q8 < 8; q8++) {
-                            const int e = min(e0 + q8, nev1 - 1);
+                            const int e = min(e0 + q8, nap - 1);
                             rec[q8] = ev_ix[e];
                             dl[q8] = ev_del[e];
                         }
@@ -1745,7 +1758,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         }
 #pragma unroll
                         for (int q8 = 0; q8 < 8; q8++) {
-                            const bool ap = e0 + q8 < nev1 && (rec[q8] & 0xffff) < t;
+                            const bool ap = e0 + q8 < nap && (rec[q8] & 0xffff) < t;
                             rhs_new = ap ? fma(-(double)gv[q8], dl[q8], rhs_new) : rhs_new;
                         }
                     }
