@@ -3069,23 +3069,31 @@ int hbk_time_matvec(hb_ctx *c, int D, int reps, int as_pipeline, double *avg_us,
     const int ngroups = (c->npanels + D - 1) / D;
     HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * HB_NFLAGS, c->stream));
     if (c->precise == 2) launch_quant0(c, c->stream);
-    for (int warm = 0; warm < 2; warm++) {
-        if (warm) HB_HIP(hipEventRecord(e0, c->stream));
-        for (int r = 0; r < (warm ? reps : 1); r++) {
-            for (int g = 0; g < ngroups; g++) {
-                const int p0 = g * D, p1 = std::min(c->npanels, p0 + D);
-                launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, as_pipeline != 0, nullptr,
-                           g > 0 ? (g - 1) * D * c->P : 0, g > 0 ? D * c->P : 0, g);
-            }
-            if (as_pipeline) launch_reduce(c, (ngroups - 1) * D * c->P, (c->npanels - (ngroups - 1) * D) * c->P, c->stream, ngroups - 1);
-        }
+    // one pass over the sweep's launches, captured into a graph as the sweep itself is (the launches then follow each other
+    // as closely as they do in a run), replayed once untimed and `reps` times between the two events
+    HB_HIP(hipStreamSynchronize(c->stream));
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HB_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    for (int gi = 0; gi < ngroups; gi++) {
+        const int p0 = gi * D, p1 = std::min(c->npanels, p0 + D);
+        launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, as_pipeline != 0, nullptr,
+                   gi > 0 ? (gi - 1) * D * c->P : 0, gi > 0 ? D * c->P : 0, gi);
     }
+    if (as_pipeline) launch_reduce(c, (ngroups - 1) * D * c->P, (c->npanels - (ngroups - 1) * D) * c->P, c->stream, ngroups - 1);
+    HB_HIP(hipStreamEndCapture(c->stream, &g));
+    HB_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HB_HIP(hipGraphLaunch(ge, c->stream));
+    HB_HIP(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; r++) HB_HIP(hipGraphLaunch(ge, c->stream));
     HB_HIP(hipEventRecord(e1, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
     float ms = 0;
     HB_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = (double)ms * 1e3 / ((double)reps * ngroups);
     if (launches) *launches = ngroups;
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return HB_OK;
