@@ -1656,6 +1656,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         int r1 = cg[lane], r2 = cg[(ncr > 1 ? 64 : 0) + lane]; // rows k + 1 and k + 2 in flight (two deep: a read takes ~100 cycles)
                         double gnx = (double)r1;
                         r1 = r2;
+                        if (K1 == 1 && (model == 1 || model == 2 || model == 5) && hotm == vmask) {
+                            // BayesRR / A / L: every marker is in the model and stays there (thr = -inf), so a step is the
+                            // conditional mean, its change, one broadcast and one fused multiply-add — no test, no class
+                            for (int k = 0; k < ncr; k++) {
+                                const double gcur = gnx;
+                                r2 = cg[min(k + 2, ncr - 1) * 64 + lane];
+                                double gn = fma(crhs, cinvv[0], csdz[0]);
+                                if (model == 5 && fabs(gn) < 1e-6) gn = 1e-6;
+                                const double dk = readlane_f64(gn - cgold, k);
+                                crhs = fma(-gcur, dk, crhs);
+                                gnx = (double)r1;
+                                r1 = r2;
+                            }
+                        } else
                         for (int k = 0; k < ncr; k++) {
                             const double gcur = gnx;
                             r2 = cg[min(k + 2, ncr - 1) * 64 + lane];
