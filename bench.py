@@ -152,7 +152,7 @@ def cpu_baseline(ctx, y, args, Pi, fold):
 
 PIPELINE = {  # (pipeline, look-ahead groups, panels per mat-vec launch): see DESIGN.md §2
     "BayesCpi": (1, 2, 7), "BayesC": (1, 2, 7), "BayesB": (1, 2, 7), "BayesBpi": (1, 2, 7),
-    "BayesR": (1, 2, 1), "BayesRR": (1, 1, 1), "BayesA": (1, 1, 1), "BayesL": (1, 1, 1),
+    "BayesR": (1, 2, 1), "BayesRR": (1, 2, 1), "BayesA": (1, 2, 1), "BayesL": (1, 2, 1),
 }
 
 

@@ -36,7 +36,7 @@ CASES = [  # model, Pi, fold, expected default geometry (pipeline, look-ahead gr
     ("BayesCpi", [0.95, 0.05], None, (1, 2, 7)),
     ("BayesB", [0.8, 0.2], None, (1, 2, 7)),
     ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1)),
-    ("BayesRR", [0.95, 0.05], None, (1, 1, 1)),
+    ("BayesRR", [0.95, 0.05], None, (1, 2, 1)),
 ]
 
 
