@@ -39,7 +39,10 @@ def parse():
     ap.add_argument("--burnin", type=int, default=300,
                     help="MCMC burn-in sweeps run as part of the set-up, before the warm-up steps: the chain starts with ~5 %% of the "
                          "markers in the model and needs a few hundred sweeps to reach the regime a 20 000-iteration run spends its time in")
-    ap.add_argument("--burnin-secondary", type=int, default=30)
+    ap.add_argument("--burnin-secondary", type=int, default=300)
+    ap.add_argument("--stamped", type=int, default=10,
+                    help="sweeps run right after the timed region with every block of every mat-vec launch stamped on the device's "
+                         "100 MHz clock (hb_ctx_matvec_stamps): the in-situ launch duration the roofline is computed from")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (gloo: development runs on one GPU)")
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--m", type=int, default=int(os.environ.get("HB_BENCH_M", "500000")),
@@ -89,10 +92,12 @@ def synth_phenotype(ctx, n, m, m_offset, m_global, seed, comm, model):
     return xb + rng.normal(0.0, np.sqrt(0.5), n)
 
 
-def cpu_baseline(ctx, y, args, Pi, fold):
+def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
     """Times oracle/hb_oracle.c (the faithful port of src/Bayes.cpp: double column-major X, serial
     marker loop, BLAS-1 shaped dot/axpy) on the first --cpu-m markers of the same data, then scales
-    to m markers (cost per sweep is exactly linear in m: one independent column per marker)."""
+    to m markers (cost per sweep is exactly linear in m: one independent column per marker).
+    g_warm: the GPU chain's effects after its timed region — the port starts from them, i.e. in the same
+    stationary regime (markers in the model = daxpy count) the GPU figure is quoted in."""
     from oracle import oracle as O
     mc = min(args.cpu_m, args.m)
     X8 = ctx.download(0, mc)
@@ -105,8 +110,9 @@ def cpu_baseline(ctx, y, args, Pi, fold):
     out = {}
     it = 1 + args.cpu_sweeps
     # nburn = niter - 1: sweeps run exactly as in the reference loop, one stored record
+    gi = None if g_warm is None else np.ascontiguousarray(g_warm[:mc])
     r = O.bayes(y, Xd, args.model, Pi, fold=fold, niter=it, nburn=it - 1, thin=1, threads=1,
-                rng=O.RNG_PHILOX, seed=args.seed)
+                rng=O.RNG_PHILOX, seed=args.seed, g_init=gi)
     out[1] = r["iters_done"] / r["loop_seconds"] * (mc / float(args.m))
     one_thread_s = r["loop_seconds"]
     # threaded dot/axpy (what a threaded BLAS would give the reference, README.md:18; BASELINE.md §3: threads = 1 and = all
@@ -117,23 +123,27 @@ def cpu_baseline(ctx, y, args, Pi, fold):
         def _child(q):
             os.environ["OMP_WAIT_POLICY"] = "passive"
             rr = O.bayes(y, Xd, args.model, Pi, fold=fold, niter=it, nburn=it - 1, thin=1, threads=thr,
-                         rng=O.RNG_PHILOX, seed=args.seed)
+                         rng=O.RNG_PHILOX, seed=args.seed, g_init=gi)
             q.put(rr["iters_done"] / rr["loop_seconds"])
 
         q = mp.get_context("fork").Queue()
         p = mp.get_context("fork").Process(target=_child, args=(q,))
         p.start()
-        p.join(timeout=max(20.0, 3.0 * one_thread_s))
+        limit = max(20.0, 3.0 * one_thread_s)
+        p.join(timeout=limit)
         if p.is_alive():
-            p.terminate()
+            p.kill()      # (SIGKILL: a team of spinning OpenMP threads does not always honour SIGTERM in time)
             p.join()
-            return None
-        return q.get() * (mc / float(args.m)) if not q.empty() else None
+            return "slower than %.0f s for %d sweeps (%.1f s on one thread): stopped" % (limit, it, one_thread_s)
+        return q.get() * (mc / float(args.m)) if not q.empty() else "no result"
 
-    for thr in sorted(set([min(cores, 16), cores]) - {1}):
+    slow = {}
+    for thr in sorted(set([min(cores, 16), min(cores, 64), cores]) - {1}):
         v = timed(thr)
-        if v is not None:
+        if isinstance(v, float):
             out[thr] = v
+        else:
+            slow[str(thr)] = v
     best_thr = max(out, key=lambda k: out[k])
     cpu_model = ""
     try:
@@ -146,8 +156,31 @@ def cpu_baseline(ctx, y, args, Pi, fold):
     return {"value": out[best_thr], "unit": "sweeps/s", "cores": best_thr, "kind": "port",
             "sample": "oracle/hb_oracle.c (double col-major X, serial marker loop, OpenMP inside dot/axpy) on the first %d of %d "
                       "markers, n=%d, %d sweeps, scaled by m_sample/m" % (mc, args.m, args.n, 1 + args.cpu_sweeps),
-            "value_1thread": out[1], "by_threads": {str(k): v for k, v in sorted(out.items())}, "host_cores": cores,
+            "value_1thread": out[1], "by_threads": {str(k): v for k, v in sorted(out.items())}, "not_finished": slow,
+            "regime": "warm start from the GPU chain's effects after its timed region" if gi is not None else "cold start",
+            "host_cores": cores,
             "cpu_model": cpu_model}
+
+
+def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic):
+    """roofline of the dominant kernel. achieved = algorithmic bytes per launch (n x columns per launch: one read of the launch's
+    int8 genotypes, SURVEY.md §8 d) / the average duration of the sweep's full-width mat-vec launches AS THE SWEEP RUNS THEM
+    (device-clock stamps of every block, chain and update rows beside them); `isolated` is the same launch shape replayed without
+    update rows and chain between two HIP events (round 2's figure)."""
+    alg = float(n) * cols
+    avg_ms = insitu["avg_ms"] if insitu else iso_ms
+    ach = alg / (avg_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": "k_dotq" if args.precise == 2 else "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": alg, "avg_launch_ms": avg_ms,
+         "launches_per_sweep": insitu["launches_per_sweep"] if insitu else launches, "columns_per_launch": cols,
+         "measured": "in situ: device-clock stamps of every block of every mat-vec launch over %d sweeps following the timed region"
+                     % insitu["sweeps"] if insitu else "isolated replay (HIP events)",
+         "isolated": {"avg_launch_ms": iso_ms, "achieved": alg / (iso_ms * 1e-3) / 1e9, "frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "what": "the same launches without update rows and chain, graph replay between two HIP events"}}
+    if insitu:
+        r["in_situ"] = {k: insitu[k] for k in ("min_ms", "max_ms", "sum_ms", "span_ms", "blocks_per_launch", "full_width_launches",
+                                               "ms_per_step_of_the_stamped_sweeps")}
+    return r
 
 
 PIPELINE = {  # (pipeline, look-ahead groups, panels per mat-vec launch): see DESIGN.md §2
@@ -164,6 +197,7 @@ def prior(model):
 
 def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, m_global, comm, torch, note, burn=0):
     """burn set-up sweeps, W warm-up iterations, then exactly K iterations between barriers; returns the result dict pieces."""
+    measure.insitu = None
     from hibayes_amd._lib import BayesArgs, RunInfo, check
     n, m = args.n, args.m
     Pi, fold = prior(model)
@@ -236,6 +270,31 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
         elapsed = float(t.item())
     info = RunInfo()
     check(L.hb_run_state(run, ct.byref(info)))
+    # ---- in-situ duration of the dominant kernel: the SAME run goes on for a few sweeps with every block of every mat-vec
+    # launch stamped (device clock, 100 MHz); chain workgroup and update rows beside them exactly as in the timed region ----
+    insitu = None
+    if args.stamped > 0 and args.precise == 2:
+        ctx.set_profiling(8)
+        check(L.hb_run_step(run, 1, ct.byref(fin)))     # (re-captures the sweep with the stamp pointers: untimed)
+        sync()
+        acc = {"avg_ms": 0.0, "sum_ms": 0.0, "span_ms": 0.0, "min_ms": 1e9, "max_ms": 0.0}
+        t2 = time.perf_counter()
+        wall = 0.0
+        for _ in range(args.stamped):
+            tw = time.perf_counter()
+            check(L.hb_run_step(run, 1, ct.byref(fin)))
+            sync()
+            wall += time.perf_counter() - tw
+            st = ctx.matvec_stamps()
+            for k in ("avg_ms", "sum_ms", "span_ms"):
+                acc[k] += st[k] / args.stamped
+            acc["min_ms"], acc["max_ms"] = min(acc["min_ms"], st["min_ms"]), max(acc["max_ms"], st["max_ms"])
+        insitu = dict(acc, launches_per_sweep=st["launches_all"], full_width_launches=st["launches"], blocks_per_launch=st["blocks"],
+                      columns_per_launch=st["cols_per_launch"], sweeps=args.stamped, ms_per_step_of_the_stamped_sweeps=wall / args.stamped * 1e3)
+        ctx.set_profiling(0)
+        note("%s: %d stamped sweeps: k_dotq %.2f us per launch in situ (%d launches, stream span %.3f ms, sweep %.3f ms)"
+             % (model, args.stamped, acc["avg_ms"] * 1e3, st["launches_all"], acc["span_ms"], wall / args.stamped * 1e3))
+    measure.insitu = insitu
     L.hb_run_destroy(run)
     del keep
     ev = (info.mean_events * info.iter - info0.mean_events * info0.iter) / max(1, K)   # over the timed sweeps only
@@ -325,12 +384,16 @@ def main():
     K, W = args.steps, args.warmup
     elapsed, mean_events, nnz, misses = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
                                         m_global, comm, torch, note, burn=args.burnin)
+    g_main = ctx.get_effects()[0]
     curve_main = list(getattr(measure, "curve", []))
     curve_main.append({"sweeps": "timed region", "moves_per_sweep": round(mean_events, 1), "sweeps_per_s": round(world * K / elapsed, 2)})
-    # the dominant kernel on its own: the sweep's mat-vec launches, back to back, HIP events on their stream
+    insitu_main = measure.insitu
+    # the dominant kernel on its own (kept beside the in-situ figure as roofline.isolated): the sweep's mat-vec launches without
+    # update rows and without the chain, back to back, HIP events on their stream
     ctx.time_matvec(reps=1)                                   # (untimed: clocks and TLBs as in the steady state of a run)
-    avg_ms, launches, cols = ctx.time_matvec(reps=5)
+    iso_ms, launches, cols = ctx.time_matvec(reps=5)
     alg_bytes = float(n) * cols  # one read of the launch's int8 genotypes (SURVEY.md §8 d: n*m per sweep)
+    avg_ms = insitu_main["avg_ms"] if insitu_main else iso_ms
     ach = alg_bytes / (avg_ms * 1e-3) / 1e9
     # HBM bytes per launch: from the separate rocprofv3 --pmc FETCH_SIZE pass kept under profiles/ (counters cannot be read
     # from inside this process); reported only when this run has the same n, panel and launch width as that pass
@@ -341,9 +404,7 @@ def main():
             traffic = pm["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
-    roof = {"bound": "hbm", "kernel": "k_dotq" if args.precise == 2 else "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": alg_bytes,
-            "avg_launch_ms": avg_ms, "launches_per_sweep": launches, "columns_per_launch": cols}
+    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, traffic)
     note("mat-vec timing pass done")
 
     # one unit = one pass over m_ref markers (the metric's m = 500k); all ranks together pass over m_global markers per step
@@ -379,15 +440,21 @@ def main():
         y2 = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, args.secondary)
         el2, ev2, nnz2, miss2 = measure(H, L, ctx, y2, args.secondary, K2, W2, args, rank, local_rank, world, m_offset,
                                  m_global, comm, torch, note, burn=args.burnin_secondary)
+        ins2 = measure.insitu
+        ctx.time_matvec(reps=1)
+        iso2, launches2, cols2 = ctx.time_matvec(reps=2)
+        curve2 = list(getattr(measure, "curve", []))
+        curve2.append({"sweeps": "timed region", "moves_per_sweep": round(ev2, 1), "sweeps_per_s": round(K2 / el2, 2)})
         res["secondary"] = {"model": args.secondary, "value": K2 / el2, "unit": "sweeps/s", "steps": K2, "warmup": W2,
+                            "roofline": roofline_block(args, n, cols2, launches2, ins2, iso2, None),
                             "ms_per_step": el2 / K2 * 1e3, "achieved_frac_of_hbm_peak": K2 / el2 * n * m / 1e9 / HBM_PEAK_GBPS,
                             "mcmc_burn_in_sweeps_before_warmup": args.burnin_secondary,
                           "mean_changed_markers_per_sweep": ev2, "row_cache_misses_per_sweep": miss2, "NumNZSnp_last": nnz2,
-                            "regime_curve": list(getattr(measure, "curve", [])),
+                            "regime_curve": curve2,
                             "pipeline": {"persistent_chain": geo2[0], "lookahead_groups": geo2[1], "panels_per_matvec": geo2[2]}}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
-            res["cpu_baseline"] = cpu_baseline(ctx, y, args, Pi, fold)
+            res["cpu_baseline"] = cpu_baseline(ctx, y, args, Pi, fold, g_main)
         except Exception as e:  # the baseline is a reported side number, never the measured path
             res["cpu_baseline"] = {"error": repr(e)}
     ctx.close()

@@ -120,6 +120,13 @@ class SweepTiming(C.Structure):
     ]
 
 
+class LaunchStats(C.Structure):
+    _fields_ = [
+        ("launches", C.c_int32), ("launches_all", C.c_int32), ("blocks", C.c_int32), ("cols_per_launch", C.c_int32),
+        ("avg_ms", C.c_double), ("min_ms", C.c_double), ("max_ms", C.c_double), ("sum_ms", C.c_double), ("span_ms", C.c_double),
+    ]
+
+
 # every symbol include/hibayes_gpu.h declares
 SYMBOLS = [
     "hb_abi_version", "hb_version", "hb_last_error", "hb_device_count", "hb_exchange_count", "hb_bayes_run",
@@ -129,7 +136,7 @@ SYMBOLS = [
     "hb_ctx_get_residual", "hb_ctx_set_effects", "hb_ctx_get_effects", "hb_ctx_dot", "hb_ctx_residual_sums",
     "hb_ctx_residual_shift", "hb_ctx_set_covariates", "hb_ctx_cov_dot", "hb_ctx_cov_axpy", "hb_ctx_set_levels",
     "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_blocks_setup", "hb_ctx_blocks_step", "hb_ctx_blocks_state", "hb_ctx_sweep", "hb_ctx_sweep_range", "hb_ctx_sweep_end", "hb_ctx_get_counters", "hb_ctx_set_windows",
-    "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec",
+    "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec", "hb_ctx_matvec_stamps",
     "hb_ctx_download_gram_band", "hb_ctx_set_adaptive", "hb_ctx_get_pipeline", "hb_ctx_get_events", "hb_ctx_pipeline_note", "hb_ctx_matmul",
     "hb_comm_unique_id", "hb_comm_init", "hb_comm_world", "hb_comm_rank", "hb_comm_selftest", "hb_comm_destroy",
     "hb_run_create", "hb_run_step", "hb_run_state", "hb_run_ctx", "hb_run_finish", "hb_run_destroy",
@@ -218,6 +225,7 @@ def lib():
     L.hb_ctx_set_pipeline.argtypes = [vp, i32, i32, i32]
     L.hb_ctx_set_adaptive.argtypes = [vp, i32]
     L.hb_ctx_time_matvec.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(i32), C.POINTER(i32)]
+    L.hb_ctx_matvec_stamps.argtypes = [vp, C.POINTER(LaunchStats)]
     L.hb_run_create.argtypes = [C.POINTER(BayesArgs), C.POINTER(vp)]
     L.hb_run_step.argtypes = [vp, i32, C.POINTER(i32)]
     L.hb_run_state.argtypes = [vp, C.POINTER(RunInfo)]

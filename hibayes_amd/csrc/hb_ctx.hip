@@ -255,7 +255,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
     void *ptrs[] = {c->X, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->dots, c->ev_count, c->ev_idx,
-                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
+                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     blocks_free(c);
@@ -995,6 +995,22 @@ int hb_ctx_set_profiling(hb_ctx *c, int32_t on)
         HB_HIP(hipMemsetAsync(c->dbg, 0, sizeof(long long) * 32 * (size_t)c->npanels, c->stream));
         c->graph_model = -1;
     }
+    if (((on & 8) != 0) != (c->lstamp != nullptr)) {
+        // bit 3: every block of every mat-vec launch of a sweep records the 100 MHz clock at its start and end
+        // (hb_ctx_matvec_stamps): the in-situ duration of the pipeline's launches, chain and update rows running beside them
+        if (on & 8) {
+            const size_t cnt = (size_t)(c->npanels + 1) * HB_LSTAMP_BLOCKS * 2;
+            HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->lstamp), sizeof(unsigned long long) * cnt));
+            HB_HIP(hipMemsetAsync(c->lstamp, 0, sizeof(unsigned long long) * cnt, c->stream));
+            c->lstamp_nblk.assign((size_t)c->npanels + 1, 0);
+            c->lstamp_cols.assign((size_t)c->npanels + 1, 0);
+        } else {
+            HB_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->lstamp);
+            c->lstamp = nullptr;
+        }
+        c->graph_model = -1;
+    }
     if (((on & 4) != 0) != c->chain_alone) {
         // bit 2: the persistent pipeline's kernels with the mat-vec launches first and the chain workgroup alone afterwards —
         // no co-residency needed, so it also runs where kernels serialise (rocprofv3 --pmc). The sweeps it runs are NOT the
@@ -1003,6 +1019,52 @@ int hb_ctx_set_profiling(hb_ctx *c, int32_t on)
         if (c->chain_alone) c->concurrent = true; // (the probe's verdict does not apply to this mode)
         c->graph_model = -1;
     }
+    return HB_OK;
+}
+
+int hb_ctx_matvec_stamps(hb_ctx *c, hb_launch_stats *o)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_matvec_stamps");
+    if (rc) return rc;
+    if (!o) return hb_fail(HB_ERR_INVALID, "hb_ctx_matvec_stamps: null argument");
+    if (!c->lstamp) return hb_fail(HB_ERR_INVALID, "hb_ctx_matvec_stamps: call hb_ctx_set_profiling(c, 8) before the sweep");
+    HB_HIP(hipStreamSynchronize(c->stream));
+    *o = hb_launch_stats{};
+    std::vector<unsigned long long> h((size_t)HB_LSTAMP_BLOCKS * 2);
+    unsigned long long first = ~0ull, last = 0;
+    double sum = 0, mn = 1e300, mx = 0;
+    int nl = 0;
+    for (int g = 0; g <= c->npanels; g++) {
+        const int nb = c->lstamp_nblk[g];
+        if (nb <= 0) continue;
+        const bool full = c->lstamp_cols[g] == (c->pipeline ? c->D : 1) * c->P; // (the sweep's last launch may be narrower)
+        HB_HIP(hipMemcpy(h.data(), c->lstamp + (size_t)g * HB_LSTAMP_BLOCKS * 2, sizeof(unsigned long long) * 2 * nb, hipMemcpyDeviceToHost));
+        unsigned long long s0 = ~0ull, e1 = 0;
+        for (int b = 0; b < nb; b++) {
+            if (h[2 * b] == 0) continue; // (a block that did not run in the last sweep)
+            s0 = std::min(s0, h[2 * b]);
+            e1 = std::max(e1, h[2 * b + 1]);
+        }
+        if (e1 == 0) continue;
+        const double ms = (double)(e1 - s0) * 1e-5; // 100 MHz ticks -> ms
+        first = std::min(first, s0);
+        last = std::max(last, e1);
+        o->launches_all++;
+        if (!full) continue;
+        sum += ms;
+        mn = std::min(mn, ms);
+        mx = std::max(mx, ms);
+        o->blocks = nb;
+        nl++;
+    }
+    if (!nl) return hb_fail(HB_ERR_INVALID, "hb_ctx_matvec_stamps: no stamped launch (the fixed-point mat-vec of the pipeline only)");
+    o->launches = nl;
+    o->avg_ms = sum / nl;
+    o->min_ms = mn;
+    o->max_ms = mx;
+    o->sum_ms = sum;
+    o->span_ms = (double)(last - first) * 1e-5;
+    o->cols_per_launch = (c->pipeline ? c->D : 1) * c->P;
     return HB_OK;
 }
 

@@ -19,6 +19,7 @@ int hb_fail(int status, const std::string &msg);
 
 // layout of the per-sweep scalar block the kernels accumulate into / the host reads back
 #define HB_ND 7 /* int8 digits of the fixed-point residual: 55 bits + sign */
+#define HB_LSTAMP_BLOCKS 2048
 
 enum {
     HB_ACC_SUMG2 = 0,
@@ -109,6 +110,10 @@ struct hb_ctx {
     std::vector<double> blk_cpc; // C_i . C_i
     double *scratch = nullptr; // small device scratch (>= 4096 doubles)
     long long *dbg = nullptr;  // optional chain-kernel cycle stamps, 32 per panel
+    // optional (hb_ctx_set_profiling bit 3): start / end of every block of every mat-vec launch of the last sweep on the
+    // constant 100 MHz clock, [launch][HB_LSTAMP_BLOCKS][2]; lstamp_nblk[launch] = blocks the launch had (0: not launched)
+    unsigned long long *lstamp = nullptr;
+    std::vector<int> lstamp_nblk, lstamp_cols;
 
     uint32_t *wind = nullptr;
     uint8_t *wflag = nullptr;

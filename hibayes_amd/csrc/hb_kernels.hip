@@ -420,6 +420,7 @@ struct dq_view {
     double *fin_out;
     const int *fin_exp;
     int fin_ncols;
+    unsigned long long *stamp; // optional (hb_ctx_set_profiling bit 3): [block][2] = wall_clock64() at the block's start and end
 };
 
 template <bool NT>
@@ -453,9 +454,8 @@ __global__ __launch_bounds__(64) void k_dotq_fin(const long long *__restrict__ a
     if (col < ncols) hbq_finalize(acc, stride, col, *pexp, out);
 }
 
-__global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
+__device__ __forceinline__ void dotq_block(const dq_view &v, const upd_view &uq, char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     int b = blockIdx.x;
     if (b < v.nupd) { // residual update of an earlier group: 256 rows per block, lists staged in the (unused) tile buffers
@@ -519,6 +519,21 @@ __global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
     for (int k = 0; k < HB_ND; k++)
         __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * 64 + lane, (long long)acc[k], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Every block's role is decided by its index (see above). With v.stamp set — the in-situ measurement of bench.py: the launches
+// of a real sweep, chain and update rows beside them — each block also records the constant 100 MHz clock at its start and end;
+// the launch's duration is then max(end) - min(start) over its blocks, what a kernel trace reports for it.
+__global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long t0 = 0;
+    if (v.stamp) t0 = wall_clock64();
+    dotq_block(v, uq, smem);
+    if (v.stamp && threadIdx.x == 0) {
+        v.stamp[2 * (size_t)blockIdx.x] = t0;
+        v.stamp[2 * (size_t)blockIdx.x + 1] = wall_clock64();
+    }
 }
 
 // Sweep start of the fixed-point path: max |yadj| -> mb[0] and the exponent of slot 0, then slot 0's digit planes.
@@ -2518,7 +2533,14 @@ static void launch_dotq(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st
     v.fin_out = c->dsum + fin_col0;
     v.fin_exp = c->gexp + fin_gidx;
     v.fin_ncols = fin_ncols;
-    hipLaunchKernelGGL(k_dotq, dim3(v.nupd + v.nfin + ncg * nsplit), dim3(64), HBQ_LDS, st, v, uq);
+    const int nblk = v.nupd + v.nfin + ncg * nsplit;
+    v.stamp = nullptr;
+    if (c->lstamp && gidx >= 0 && gidx <= c->npanels && nblk <= HB_LSTAMP_BLOCKS) {
+        v.stamp = c->lstamp + (size_t)gidx * HB_LSTAMP_BLOCKS * 2;
+        c->lstamp_nblk[gidx] = nblk;
+        c->lstamp_cols[gidx] = ncols;
+    }
+    hipLaunchKernelGGL(k_dotq, dim3(nblk), dim3(64), HBQ_LDS, st, v, uq);
 }
 
 static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, bool pipeline = false,

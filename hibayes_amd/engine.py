@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import CtxParams, SweepIn, SweepOut, SweepTiming, HB_MAX_FOLD, check, lib
+from ._lib import CtxParams, LaunchStats, SweepIn, SweepOut, SweepTiming, HB_MAX_FOLD, check, lib
 
 MODEL_INDEX = {"BayesRR": 1, "BayesA": 2, "BayesB": 3, "BayesBpi": 3, "BayesC": 4, "BayesCpi": 4,
                "BayesL": 5, "BayesR": 6}
@@ -242,6 +242,12 @@ class Context:
         ms, nl, nc = C.c_double(), C.c_int32(), C.c_int32()
         check(self.L.hb_ctx_time_matvec(self.h, reps, C.byref(ms), C.byref(nl), C.byref(nc)))
         return ms.value, nl.value, nc.value
+
+    def matvec_stamps(self):
+        """In-situ statistics of the mat-vec launches of the last sweep (set_profiling(8) first); see hb_launch_stats."""
+        st = LaunchStats()
+        check(self.L.hb_ctx_matvec_stamps(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in LaunchStats._fields_}
 
     def set_profiling(self, on):
         check(self.L.hb_ctx_set_profiling(self.h, int(on)))

@@ -368,7 +368,22 @@ int hb_ctx_last_timing(hb_ctx *c, hb_sweep_timing *t);
 /* measurement helper: the panel mat-vec launches of one sweep, issued back to back exactly as the sweep issues them
  * (same columns per launch), timed with HIP events on the context's stream; average milliseconds per launch */
 int hb_ctx_time_matvec(hb_ctx *c, int32_t reps, double *avg_ms, int32_t *launches_per_sweep, int32_t *cols_per_launch);
+/* on: bit 0 HIP-event timing of the per-panel kernels (hb_ctx_last_timing), bit 1 cycle stamps inside the chain kernel,
+ * bit 2 chain-alone diagnostic, bit 3 in-situ stamps of the mat-vec launches (hb_ctx_matvec_stamps) */
 int hb_ctx_set_profiling(hb_ctx *c, int32_t on);
+/* In-situ duration of the dominant kernel. With hb_ctx_set_profiling(c, 8) every block of every mat-vec launch of a sweep
+ * records the device's constant 100 MHz clock at its start and at its end — the launches of the REAL sweep, with the chain
+ * workgroup and the update rows running beside them, not an isolated replay. A launch's duration is max(end) - min(start)
+ * over its blocks (what a kernel trace reports); the statistics are over the launches of the last sweep. span_ms = first
+ * launch's start to last launch's end, so launches * avg_ms <= span_ms <= the sweep's wall time. */
+typedef struct hb_launch_stats {
+    int32_t launches;        /* full-width mat-vec launches of the last sweep (the statistics are over these) */
+    int32_t launches_all;    /* ... all of them (the last launch of a sweep may cover fewer columns) */
+    int32_t blocks;          /* blocks of the last launch looked at (update rows + finalize + tiles) */
+    int32_t cols_per_launch;
+    double avg_ms, min_ms, max_ms, sum_ms, span_ms;
+} hb_launch_stats;
+int hb_ctx_matvec_stamps(hb_ctx *c, hb_launch_stats *out);
 
 #ifdef __cplusplus
 }

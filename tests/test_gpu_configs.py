@@ -99,7 +99,9 @@ def test_config4_shard_shape_bayescpi_n50k_m250k_pipeline_vs_serial():
         same_chain(a, b, 1e-9, "config 4 shard: pipeline vs serial")
 
 
-def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=2):
+def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=2, dense=0.0):
+    """dense > 0: the chain starts from an installed state with that fraction of the markers in the model (g_init on both
+    sides): crowded rounds, row-cache misses and band folds of hundreds of moves per mat-vec group from the first panel on."""
     need = n * m / 1e9 + 8
     if host_free_gb() < need:
         pytest.skip("host has %.0f GB available, the live oracle needs %.0f GB for the int8 genotypes" % (host_free_gb(), need))
@@ -108,6 +110,12 @@ def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=
         c.generate(20240901, mono_every=1000)
         y = synth_y(c, n, m, 17)
         c.set_pipeline(*geo)
+        if dense > 0:
+            rs = np.random.default_rng(23)
+            g0 = np.zeros(m)
+            on = rs.choice(m, int(dense * m), replace=False)
+            g0[on] = rs.normal(0, 0.01, on.size)
+            kw["g_init"] = g0
         r = H.Bayes(y, None, model, Pi, verbose=False, precise=precise, ctx=c, store_alpha=False, **kw)
         invariants(c, y, r)
         g_gpu, trk, _ = c.get_effects()
@@ -125,6 +133,19 @@ def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=
 
 def test_config3_bayescpi_n50k_m500k_draw_for_draw_against_live_oracle():
     _full_size_vs_oracle(50000, 500000, "BayesCpi", [0.95, 0.05], None, (1, 2, 7), 0)
+
+
+def test_config3_bayesr_n50k_m500k_draw_for_draw_against_live_oracle():
+    """BASELINE.json configs[2] is BayesR at n=50k, m=500k: its own model, at its own size and default geometry, against the
+    live oracle (reference src/Bayes.cpp:743-815) — 2 sweeps from cold, ~47 moves per panel."""
+    _full_size_vs_oracle(50000, 500000, "BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 0)
+
+
+@pytest.mark.parametrize("model,Pi,fold,geo", [("BayesCpi", [0.95, 0.05], None, (1, 2, 7)),
+                                                ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1))])
+def test_config3_dense_installed_state_against_live_oracle(model, Pi, fold, geo):
+    """The same size from an installed state with 5 % of the markers in the model (25 000 certain movers in the first sweep)."""
+    _full_size_vs_oracle(50000, 500000, model, Pi, fold, geo, 0, niter=2, dense=0.05)
 
 
 def test_config5_shard_shape_bayesb_n200k_m125k_draw_for_draw_against_live_oracle():
