@@ -211,7 +211,7 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
     if fold is not None:
         fv = np.array(fold)
         a.fold, a.n_fold = fv.ctypes.data, fv.size
-    a.niter, a.nburn, a.thin = burn + W + K + 5, 0, 5  # every sweep counts PIP, every 5th is a stored record
+    a.niter, a.nburn, a.thin = burn + W + K + args.stamped + 8, 0, 5  # every sweep counts PIP, every 5th is a stored record
     a.outfreq, a.verbose = 0, 0
     a.seed, a.device, a.precise, a.store_alpha = args.seed, local_rank, args.precise, 0
     a.ctx = ctx.h

@@ -1,0 +1,442 @@
+// hb_chain_group.hpp — k_chain_group: the persistent chain workgroup of the sparse regime (BayesB / BayesC), one step per
+// MAT-VEC GROUP instead of one per panel. Included by hb_kernels.hip (it uses that file's views and hand-off helpers).
+//
+// Why. k_chain_persist pays its fixed path — opening barrier, ring bookkeeping, DMA issue, ~600 instructions per wave — once
+// per panel of 512 markers, 977 times a sweep, although in the stationary regime of a point-mass model fewer than one marker
+// per panel moves: the chain was bound by its own instruction stream (round 2: 1 340 instructions per wave and panel, half
+// of them scalar bookkeeping), not by the work the moves themselves need. Here a step covers the D panels of one mat-vec
+// launch (3 584 markers at D = 7): thread t holds marker t of each of the D panels in registers, so the fixed path is paid
+// 140 times a sweep, and what remains per group is three dependent memory round trips:
+//   1. the group's dots and filter words (the kernel polls its own dots: dsum[] is NaN-prefilled, every value lands whole);
+//   2. the exact per-marker data of the CANDIDATES (in the model, or q at its entry threshold) and, in the same trip, the
+//      Gram entries among them (single int32 entries of the band blocks: candidates of different panels of the group meet in
+//      block l = panel distance);
+//   3. the Gram rows of the markers that moved: onto the group's later markers (then the violation check: a marker pushed
+//      over its threshold by a move joins the candidates and the round is repeated — the result is always the exact
+//      sequential chain) and forward into the correction ring of the next Lv groups.
+// The serial pass itself (wave 0, one candidate per lane, in marker order) is LDS-only.
+// Same chain as k_chain / k_chain_persist: same decisions and move lists; effects differ in the last bits only through the
+// order in which corrections are summed (tests: draw for draw against the oracle, tests/test_gpu_depth.py).
+//
+// Reference: the per-marker conditionals are src/Bayes.cpp:627-717 (BayesB / BayesC) — restated as thresholds by k_pre.
+#pragma once
+
+#define HBG_DM 8 /* panels per group the register arrays are sized for (hb_pipeline_geometry caps D at 8) */
+
+template <int K1>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
+                                                                                                 persist_view pv)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int P = v.P, S = P >> 6;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int lgP = 31 - __clz(P);
+    const int D = pv.D, np = pv.npanels;
+    const int R = (pv.Lv + 1) * D; // correction ring: this group's panels and those of the next Lv groups
+    const size_t PP = (size_t)P * P;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    double *corr = reinterpret_cast<double *>(smem);            // [R][P]
+    double *cs_d = corr + (size_t)R * P;                        // one round's candidates: rhs, gold, thr[K1], invv[K1], sdz[K1]
+    double *res_g = cs_d + (2 + 3 * K1) * 64;                   // ... their new effects
+    double *ev_del = res_g + 64;                                // the round's moves: change of effect
+    double *red = ev_del + 64;                                  // [16]
+    int *cs_pos = reinterpret_cast<int *>(red + 16);            // candidate -> position in the group (panel * P + marker)
+    int *res_c = cs_pos + 64;                                   // ... new classes
+    int *ev_pos = res_c + 64;                                   // the round's moves: position
+    int *cg = ev_pos + 64;                                      // [64][64] Gram entries among the round's candidates (k < c)
+    int *wcnt = cg + 64 * 64;                                   // [HBG_DM][8] candidates per (panel of the group, wave)
+    int *misc = wcnt + 64;                                      // [0] moves of the round, [1] position the round ends at, [2] abort, [8..15] violations per wave, [16..23] moves published per panel
+    for (int l = 0; l < R; l++) corr[(size_t)l * P + t] = 0.0;
+    if (t < 64) { wcnt[t] = 0; if (t < 32) misc[t] = 0; }
+
+    const int model = pin->model_index;
+    const int count_pip = pin->count_pip, store = pin->store;
+    double wacc = 0.0;
+    int nact = 0, cacc[K1 + 1];
+#pragma unroll
+    for (int c = 0; c <= K1; c++) cacc[c] = 0;
+    int evacc = 0, redoacc = 0;
+    double mbr = v.mb ? v.mb[0] : 0.0;
+    int gcount = pv.p0 / D;
+    bool ok = true;
+    __syncthreads();
+
+    int gslot = 0; // ring slot of the group's first panel
+    for (int gp0 = pv.p0; ok && gp0 < np; gp0 += D) {
+        const int Dg = min(D, np - gp0);
+        // ---- (1) the group's dots, filter words and owed corrections ----
+        double r0[HBG_DM];
+        float fl[HBG_DM];
+        {
+            double dj[HBG_DM];
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < HBG_DM; i++) {
+                dj[i] = 0.0;
+                fl[i] = __int_as_float(0x7fc00000);
+                if (i < Dg) {
+                    const size_t j = (size_t)(gp0 + i) * P + t;
+                    dj[i] = ld_sc1(&v.dsum[j]);
+                    fl[i] = pv.thr0f[j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < HBG_DM; i++) bad |= (i < Dg) && __double_as_longlong(dj[i]) == -1ll;
+            if (__any(bad)) { // the mat-vec has not delivered (all of) this group yet: re-read what is missing
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    bad = false;
+#pragma unroll
+                    for (int i = 0; i < HBG_DM; i++) {
+                        if (i < Dg && __double_as_longlong(dj[i]) == -1ll) {
+                            dj[i] = ld_sc1(&v.dsum[(size_t)(gp0 + i) * P + t]);
+                            bad |= __double_as_longlong(dj[i]) == -1ll;
+                        }
+                    }
+                    if (!__any(bad)) break;
+                    if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
+                        if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); misc[2] = 1; }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < HBG_DM; i++) {
+                r0[i] = 0.0;
+                if (i < Dg) {
+                    double *cp = corr + (size_t)(gslot + i) * P + t;
+                    r0[i] = dj[i] - *cp;
+                    *cp = 0.0; // the slot belongs to a panel Lv + 1 groups ahead from now on
+                    nact += (fl[i] == fl[i]) ? 1 : 0;
+                }
+            }
+        }
+        int pos_lo = 0;      // markers of the group before this position are decided
+        unsigned forced = 0; // (bit i: marker i * P + t was pushed over its threshold by a move of a rolled-back round)
+        double absd_grp = 0.0;
+        for (;;) {
+            // ---- (2) the round's candidates, ranked in marker order ----
+            unsigned iscm = 0;
+            unsigned long long rkp = 0; // rank of marker i * P + t among its wave's candidates of panel i: 8 bits per i
+#pragma unroll
+            for (int i = 0; i < HBG_DM; i++) {
+                bool isc = false;
+                if (i < Dg) {
+                    const bool active = fl[i] == fl[i], hot = fl[i] == -__int_as_float(0x7f800000);
+                    isc = (i * P + t) >= pos_lo && active && (hot || ((forced >> i) & 1u) || r0[i] * r0[i] >= pv.candf * (double)fl[i]);
+                }
+                const unsigned long long cm = __ballot(isc);
+                rkp |= (unsigned long long)__popcll(cm & lt) << (8 * i);
+                iscm |= isc ? 1u << i : 0u;
+                if (lane == 0) wcnt[i * 8 + wave] = __popcll(cm);
+            }
+            if (t == 0) misc[1] = Dg * P;
+            __syncthreads(); // B1
+            if (misc[2]) { ok = false; break; }
+            int total, myscan;
+            {   // exclusive scan of the (panel, wave) counts in every wave: lane = panel * 8 + wave
+                const int cnt = wcnt[lane];
+                int inc = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += up;
+                }
+                total = __builtin_amdgcn_readlane(inc, 63);
+                myscan = inc - cnt;
+            }
+            if (total == 0) break; // nobody (left) in the group can move
+            const int ncr = min(total, 64);
+            unsigned inrm = 0;
+            unsigned long long rk = 0; // rank in the round of marker i * P + t, 8 bits per i (valid where inrm has the bit)
+            // a thread almost never holds more than one candidate: the loop body (the exact per-marker data, one round trip)
+            // exists once, the marker's registers are picked with selects
+            for (unsigned left = iscm; __any(left != 0u);) {
+                const bool mine = left != 0u;
+                const int i = mine ? __ffs((int)left) - 1 : 0;
+                left &= left - 1u;
+                double r0i = r0[0];
+#pragma unroll
+                for (int x = 1; x < HBG_DM; x++) r0i = (i == x) ? r0[x] : r0i;
+                const int basew = __shfl(myscan, i * 8 + wave, 64); // candidates before this (panel, wave)
+                const int rank = basew + (int)((rkp >> (8 * i)) & 0xffull);
+                if (mine && rank == 64) misc[1] = i * P + t;
+                if (mine && rank < 64) {
+                    const size_t j = (size_t)(gp0 + i) * P + t;
+                    const double gold = v.g[j], xx = v.xpx[j];
+                    cs_d[rank] = (gold != 0.0) ? fma(xx, gold, r0i) : r0i;
+                    cs_d[64 + rank] = gold;
+#pragma unroll
+                    for (int c = 0; c < K1; c++) {
+                        cs_d[(2 + c) * 64 + rank] = v.thr[(size_t)c * v.m_pad + j];
+                        cs_d[(2 + K1 + c) * 64 + rank] = v.invv[(size_t)c * v.m_pad + j];
+                        cs_d[(2 + 2 * K1 + c) * 64 + rank] = v.sdz[(size_t)c * v.m_pad + j];
+                    }
+                    cs_pos[rank] = i * P + t;
+                    rk |= (unsigned long long)rank << (8 * i);
+                    inrm |= 1u << i;
+                }
+            }
+            __syncthreads(); // B2
+            const int pos_hi = misc[1];
+            // ---- (3) Gram entries among the round's candidates: cg[k][c] = x_k . x_c for k < c, zero elsewhere ----
+            for (int idx = t; idx < ncr * 64; idx += P) {
+                const int k = idx >> 6, c = idx & 63;
+                int gval = 0;
+                if (k < c && c < ncr) {
+                    const int a = cs_pos[k], b = cs_pos[c];
+                    const int pa = a >> lgP, ia = a & (P - 1), pb = b >> lgP, ib = b & (P - 1);
+                    gval = v.gram[((size_t)(gp0 + pb) * (pv.Lg + 1) + (pb - pa)) * PP + (size_t)ia * P + ib];
+                }
+                cg[idx] = gval;
+            }
+            __syncthreads(); // B3
+            // ---- (4) the exact serial chain over the round's candidates: wave 0, one candidate per lane, in marker order ----
+            if (wave == 0) {
+                const bool lv = lane < ncr;
+                double crhs = lv ? cs_d[lane] : 0.0;
+                const double cgold = lv ? cs_d[64 + lane] : 0.0;
+                double cthr[K1], cinvv[K1], csdz[K1];
+#pragma unroll
+                for (int c = 0; c < K1; c++) {
+                    cthr[c] = lv ? cs_d[(2 + c) * 64 + lane] : HB_INF;
+                    cinvv[c] = lv ? cs_d[(2 + K1 + c) * 64 + lane] : 0.0;
+                    csdz[c] = lv ? cs_d[(2 + 2 * K1 + c) * 64 + lane] : 0.0;
+                }
+                const int cp = lv ? cs_pos[lane] : 0;
+                auto decide = [&](double rhsv, int &cls, double &gn) {
+                    const double q = rhsv * rhsv;
+                    double gsel = fma(rhsv, cinvv[0], csdz[0]);
+                    cls = q >= cthr[0] ? 1 : 0;
+#pragma unroll
+                    for (int c = 1; c < K1; c++) {
+                        const bool ge = q >= cthr[c];
+                        cls += ge ? 1 : 0;
+                        gsel = ge ? fma(rhsv, cinvv[c], csdz[c]) : gsel;
+                    }
+                    gn = (q >= cthr[0]) ? gsel : 0.0;
+                    if (K1 == 1 && model == 5 && fabs(gn) < 1e-6) gn = 1e-6; // src/Bayes.cpp:728
+                };
+                int rnext = cg[lane]; // row k of cg, one step ahead
+                for (int k = 0; k < ncr; k++) {
+                    const int rcur = rnext;
+                    rnext = cg[min(k + 1, ncr - 1) * 64 + lane];
+                    int cls;
+                    double gn;
+                    decide(crhs, cls, gn);
+                    const double dk = readlane_f64(gn - cgold, k);
+                    crhs = fma(-(double)rcur, dk, crhs); // (row k is zero at and before lane k; a marker that stays adds an exact zero)
+                }
+                int cls;
+                double gn;
+                decide(crhs, cls, gn); // lane k's rhs was not touched after its own step: its outcome, for all lanes at once
+                const double dmine = lv ? gn - cgold : 0.0;
+                const unsigned long long moved = __ballot(lv && dmine != 0.0);
+                if (lv && dmine != 0.0) {
+                    const int pos = __popcll(moved & lt);
+                    ev_pos[pos] = cp;
+                    ev_del[pos] = dmine;
+                }
+                res_c[lane] = cls;
+                res_g[lane] = gn;
+                if (lane == 0) misc[0] = __popcll(moved);
+            }
+            __syncthreads(); // B4
+            const int nmoves = misc[0];
+            // ---- (5) the round's moves onto the later markers of the group; the forward rows are requested in the same trip ----
+            double rnew[HBG_DM];
+#pragma unroll
+            for (int i = 0; i < HBG_DM; i++) rnew[i] = r0[i];
+            // (row addresses are "wave-uniform pointer"[t]: scalar base + one vector offset, no 64-bit vector arithmetic)
+            const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP; // block l = 0 of the group's first panel
+            const size_t pstep = (size_t)(pv.Lg + 2) * PP;                   // block l of panel p -> block l + 1 of panel p + 1
+#pragma unroll 1
+            for (int e0 = 0; e0 < nmoves; e0 += 2) {
+                int gv[2][HBG_DM];
+                int pae[2], iae[2];
+                double dl[2];
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    const int e = min(e0 + f, nmoves - 1);
+                    const int a = __builtin_amdgcn_readfirstlane(ev_pos[e]);
+                    pae[f] = a >> lgP;
+                    iae[f] = a & (P - 1);
+                    dl[f] = (e0 + f < nmoves) ? ev_del[e] : 0.0;
+                }
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    // panel i of the group meets the mover (panel pae) in its block l = i - pae: block address
+                    // gblk0 + (i (Lg + 1) + i - pae) PP = (gblk0 - pae PP) + i (Lg + 2) PP
+                    uintptr_t row = (uintptr_t)gblk0 + ((size_t)iae[f] * P) * 4 - ((size_t)pae[f] * PP) * 4;
+#pragma unroll
+                    for (int i = 0; i < HBG_DM; i++) {
+                        gv[f][i] = 0;
+                        if (i >= pae[f] && i < Dg) gv[f][i] = reinterpret_cast<const int32_t *>(row)[t]; // (uniform)
+                        row += pstep * 4;
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+#pragma unroll
+                    for (int i = 0; i < HBG_DM; i++) {
+                        // marker (i, t) takes the move of (pae, iae) if it comes later in the order
+                        const bool later = i > pae[f] || (i == pae[f] && t > iae[f]);
+                        if (i < Dg && later) rnew[i] = fma(-(double)gv[f][i], dl[f], rnew[i]);
+                    }
+                }
+            }
+            // ---- (6) did every marker the round passed over really stay below its threshold? ----
+            unsigned violm = 0;
+#pragma unroll
+            for (int i = 0; i < HBG_DM; i++) {
+                if (i < Dg) {
+                    const int pos = i * P + t;
+                    const bool viol = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && rnew[i] * rnew[i] >= (double)fl[i]; // (NaN filter: false)
+                    violm |= viol ? 1u << i : 0u;
+                }
+            }
+            {
+                const unsigned long long vm = __ballot(violm != 0u);
+                if (lane == 0) misc[8 + wave] = vm != 0ull;
+            }
+            __syncthreads(); // B5
+            bool anyv = false;
+            {
+                int w8[8];
+                hb_read8(misc + 8, w8);
+#pragma unroll
+                for (int w = 0; w < 8; w++) anyv |= w8[w] != 0;
+            }
+            if (anyv) { // roll the round back: the markers that crossed join the candidates
+                forced |= violm;
+                if (t == 0) redoacc++;
+                continue;
+            }
+            // ---- (7) commit the round ----
+#pragma unroll
+            for (int i = 0; i < HBG_DM; i++) r0[i] = rnew[i];
+            for (unsigned left = inrm; left != 0u; left &= left - 1u) { // (divergent: a handful of threads)
+                const int i = __ffs((int)left) - 1;
+                const int rnk = (int)((rk >> (8 * i)) & 0xffull);
+                const size_t j = (size_t)(gp0 + i) * P + t;
+                const int cls_f = res_c[rnk];
+                const double g_f = res_g[rnk];
+                v.g[j] = g_f;
+                v.tracker[j] = (uint8_t)cls_f;
+                if (count_pip && cls_f != 0) {
+                    __hip_atomic_fetch_add(&v.nzrate[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v.wind) v.wflag[v.wind[j] - 1u] = 1;
+                }
+                if (store && g_f != 0.0) {
+                    unsafeAtomicAdd(&v.alpha_sum[j], g_f);
+                    unsafeAtomicAdd(&v.alpha_sq[j], g_f * g_f);
+                }
+                if (cls_f > 0) wacc += (model == 6) ? g_f * g_f / pin->fold[cls_f] : g_f * g_f;
+#pragma unroll
+                for (int c = 1; c <= K1; c++) cacc[c] += cls_f == c ? 1 : 0;
+            }
+            evacc += nmoves;
+            // the moves, appended to their panels' lists (write-through: the update rows of this group read them)
+            if (wave == S - 1 && nmoves > 0) {
+                const bool have = lane < nmoves;
+                const int a = have ? ev_pos[lane] : 0;
+                const double dlt = have ? ev_del[lane] : 0.0;
+                const int pa = a >> lgP, ia = a & (P - 1);
+                int myidx = 0, addme = 0;
+#pragma unroll
+                for (int i = 0; i < HBG_DM; i++) {
+                    if (i < Dg) {
+                        const unsigned long long mi = __ballot(have && pa == i);
+                        if (have && pa == i) myidx = misc[16 + i] + __popcll(mi & lt);
+                        if (lane == i) addme = __popcll(mi);
+                    }
+                }
+                if (have) {
+                    st_sc1(&v.ev_idx[(size_t)(gp0 + pa) * P + myidx], ia);
+                    st_sc1(&v.ev_delta[(size_t)(gp0 + pa) * P + myidx], dlt);
+                }
+                if (lane < HBG_DM) misc[16 + lane] += addme;
+                absd_grp += wave_sum(fabs(dlt));
+            }
+            // ---- (8) ... and forward, into the corrections owed to the panels of the next Lv groups ----
+            {
+                const int nfw = min(pv.Lv * D, np - (gp0 + D)); // panels ahead that need it (<= 0: none)
+                const size_t pstep = (size_t)(pv.Lg + 2) * PP;
+#pragma unroll 1
+                for (int e = 0; e < nmoves && nfw > 0; e++) {
+                    const int a = __builtin_amdgcn_readfirstlane(ev_pos[e]);
+                    const int pae = a >> lgP, iae = a & (P - 1);
+                    const double dl = ev_del[e];
+                    // panel q = gp0 + D + x meets the mover (panel gp0 + pae) in its block l = D + x - pae
+                    const int32_t *row0 = v.gram + ((size_t)(gp0 + D) * (pv.Lg + 1) + (D - pae)) * PP + (size_t)iae * P;
+#pragma unroll 1
+                    for (int q0 = 0; q0 < nfw; q0 += 8) {
+                        int gv[8];
+                        const int32_t *row = row0 + (size_t)q0 * pstep;
+#pragma unroll
+                        for (int qq = 0; qq < 8; qq++) {
+                            gv[qq] = 0;
+                            if (q0 + qq < nfw) gv[qq] = row[t]; // (uniform)
+                            row += pstep;
+                        }
+                        int sl = gslot + D + q0;
+                        sl = sl >= R ? sl - R : sl;
+#pragma unroll
+                        for (int qq = 0; qq < 8; qq++) {
+                            if (q0 + qq < nfw) {
+                                double *cp = corr + (size_t)sl * P + t; // this thread's own word: no synchronisation needed
+                                *cp = fma((double)gv[qq], dl, *cp);
+                            }
+                            sl = (sl + 1 == R) ? 0 : sl + 1;
+                        }
+                    }
+                }
+            }
+            pos_lo = pos_hi;
+            if (pos_lo >= Dg * P) break;
+        }
+        if (!ok) break;
+        // ---- end of the group: counts, bound on max |yadj|, chain_done (the update rows of this group wait for it) ----
+        if (wave == S - 1) {
+            if (lane < Dg) {
+                const int c = misc[16 + lane];
+                if (c) st_sc1(&v.ev_count[gp0 + lane], c);
+                misc[16 + lane] = 0;
+            }
+            if (v.mb) {
+                mbr = fma(v.xabs, absd_grp, mbr);
+                if (lane == 0) st_sc1(&v.mb[1 + gcount], mbr);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(gp0 + Dg));
+        }
+        gcount++;
+        gslot += D;
+        gslot = gslot >= R ? gslot - R : gslot;
+    }
+    // ---- sweep totals for the hyper-parameter draws ----
+    __syncthreads();
+    const double wsum = block_sum(wacc, red);
+    if (t == 0) {
+        v.acc[HB_ACC_SUMG2] += wsum;
+        v.acc[HB_ACC_EVENTS] += (double)evacc;
+        v.acc[HB_ACC_REDO] += (double)redoacc;
+    }
+    int nin = 0;
+#pragma unroll
+    for (int c = 1; c <= K1; c++) {
+        nin += cacc[c];
+        const double cs = block_sum((double)cacc[c], red);
+        if (t == 0 && c < HB_MAX_FOLD) v.acc[HB_ACC_COUNT0 + c] += cs;
+    }
+    {
+        const double cs = block_sum((double)(nact - nin), red); // class 0: the polymorphic markers that are not in the model
+        if (t == 0) v.acc[HB_ACC_COUNT0] += cs;
+    }
+    if (t == 0 && !ok) { // aborted: the host must see it (fetch_acc checks the flag), then release every waiter
+        st_flag(pv.flags + HB_FLAG_ABORT, 1u);
+        st_flag(pv.flags + HB_FLAG_CHAIN_DONE, 0x7fffffffu);
+    }
+}

@@ -121,6 +121,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_LOOKAHEAD")) c->Lv = atoi(e);
     if (const char *e = getenv("HB_DOTGROUP")) c->D = atoi(e);
     if (const char *e = getenv("HB_GRAPH")) c->use_graph = atoi(e) != 0;
+    if (const char *e = getenv("HB_CHAIN")) c->chain_kind = std::strcmp(e, "panel") == 0 ? 0 : 1;
     if (const char *e = getenv("HB_KAPPA")) c->kappa = atof(e);
     if (const char *e = getenv("HB_DOT_LDS")) c->dot_lds = std::min(65536, std::max(0, atoi(e)));
     if (const char *e = getenv("HB_CANDF")) c->candf = std::min(1.0, std::max(0.0, atof(e)));

@@ -1986,6 +1986,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+#include "hb_chain_group.hpp"
+
 // ---------------------------------------------------------------------------------------------
 // k_warm: the chain workgroup's memory traffic, pulled into ITS L2 ahead of time by other compute units.
 // One compute unit gets ~18 bytes per clock out of HBM however many loads it keeps in flight (its miss queue is the limit;
@@ -2479,6 +2481,7 @@ int hbk_init_attrs()
     HB_PERSIST_ATTR(1, 0); HB_PERSIST_ATTR(1, 1); HB_PERSIST_ATTR(1, 17); HB_PERSIST_ATTR(1, 20);
     HB_PERSIST_ATTR(3, 0); HB_PERSIST_ATTR(3, 2);
     HB_PERSIST_ATTR(7, 0); HB_PERSIST_ATTR(7, 2);
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2811,7 +2814,15 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // chain_done (their update rows find empty event lists), the chain afterwards with the device to itself; the stamped span
     // (tools/chain_timeline.py with CT_ALONE=1) is then what the chain costs without the mat-vec's memory traffic beside it.
     const bool alone = c->chain_alone || getenv("HB_CHAIN_ALONE") != nullptr;
+    // the point-mass models run the group-granular chain (hb_chain_group.hpp); HB_CHAIN=panel keeps the per-panel one
+    const bool group_chain = kp == 1 && (model == 3 || model == 4) && c->chain_kind == 1 && !c->chain_alone && !c->dbg;
     auto launch_the_chain = [&](hipStream_t st) -> int {
+        if (group_chain) {
+            hipLaunchKernelGGL((k_chain_group<1>), dim3(1), dim3(c->P), persist_smem(c->P), st, c->d_in, cv, pv);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_group launch: ") + hipGetErrorString(e));
+            return HB_OK;
+        }
         hipError_t e = kp == 1 ? launch_chain_persist<1>(c, cv, pv, st) : kp == 3 ? launch_chain_persist<3>(c, cv, pv, st)
                                                                                  : launch_chain_persist<7>(c, cv, pv, st);
         if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_persist launch: ") + hipGetErrorString(e));
@@ -2822,7 +2833,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // the L2 warmers (k_warm): a third branch of the graph, 4 workgroups per XCD of which only the chain's XCD's stay
     int warm = 4;
     if (const char *e = getenv("HB_WARM")) warm = std::max(0, std::min(16, atoi(e)));
-    if (alone) warm = 0;
+    if (alone || group_chain) warm = 0;
     if (warm) {
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         int ahead = D + 4;
