@@ -21,6 +21,19 @@
 // Reference: the per-marker conditionals are src/Bayes.cpp:627-717 (BayesB / BayesC) — restated as thresholds by k_pre.
 #pragma once
 
+#if HB_STAMPS
+#define HBG_STAMP(i) do { if (v.dbg && t == 0) v.dbg[(size_t)gcount * 32 + (i)] = clock64(); } while (0)
+#define HBG_STAMP_ONCE(i) do { if (v.dbg && t == 0 && nround == 0) v.dbg[(size_t)gcount * 32 + (i)] = clock64(); } while (0)
+#define HBG_STAMP_VAL(i, x) do { if (v.dbg && t == 0) v.dbg[(size_t)gcount * 32 + (i)] = (x); } while (0)
+#else
+#define HBG_STAMP(i) do { } while (0)
+#define HBG_STAMP_ONCE(i) do { } while (0)
+#define HBG_STAMP_VAL(i, x) do { } while (0)
+#endif
+#define HBG_FW 14 /* panels ahead a move is folded into: Lv * D <= (Lv + 1) * D - 1 - (D - 1) <= 20 - ... (hb_pipeline_geometry); checked at launch */
+#ifndef HBG_CH
+#define HBG_CH 3  /* moves whose rows are requested together */
+#endif
 #define HBG_DM 8 /* panels per group the register arrays are sized for (hb_pipeline_geometry caps D at 8) */
 
 template <int K1>
@@ -65,24 +78,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int gslot = 0; // ring slot of the group's first panel
     for (int gp0 = pv.p0; ok && gp0 < np; gp0 += D) {
         const int Dg = min(D, np - gp0);
+        HBG_STAMP(0);
         // ---- (1) the group's dots, filter words and owed corrections ----
         double r0[HBG_DM];
         float fl[HBG_DM];
         {
             double dj[HBG_DM];
             bool bad = false;
+            // (branch-free: a panel past the group's end re-reads the last one — a load behind a branch is waited for on the spot,
+            // and eight dependent round trips is what this opening would then cost)
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) {
-                dj[i] = 0.0;
-                fl[i] = __int_as_float(0x7fc00000);
-                if (i < Dg) {
-                    const size_t j = (size_t)(gp0 + i) * P + t;
-                    dj[i] = ld_sc1(&v.dsum[j]);
-                    fl[i] = pv.thr0f[j];
-                }
+                const size_t j = (size_t)(gp0 + min(i, Dg - 1)) * P + t;
+                dj[i] = ld_sc1(&v.dsum[j]);
+                fl[i] = pv.thr0f[j];
             }
 #pragma unroll
+            for (int i = 0; i < HBG_DM; i++) fl[i] = i < Dg ? fl[i] : __int_as_float(0x7fc00000);
+#pragma unroll
             for (int i = 0; i < HBG_DM; i++) bad |= (i < Dg) && __double_as_longlong(dj[i]) == -1ll;
+            HBG_STAMP_VAL(11, bad ? 1 : 0);
             if (__any(bad)) { // the mat-vec has not delivered (all of) this group yet: re-read what is missing
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
@@ -113,6 +128,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
+        HBG_STAMP(1);
+        int nround = 0, nmv_grp = 0;
+        (void)nround; (void)nmv_grp;
         int pos_lo = 0;      // markers of the group before this position are decided
         unsigned forced = 0; // (bit i: marker i * P + t was pushed over its threshold by a move of a rolled-back round)
         double absd_grp = 0.0;
@@ -147,6 +165,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 total = __builtin_amdgcn_readlane(inc, 63);
                 myscan = inc - cnt;
             }
+            HBG_STAMP_ONCE(2);
+            if (nround == 0) HBG_STAMP_VAL(12, total);
             if (total == 0) break; // nobody (left) in the group can move
             const int ncr = min(total, 64);
             unsigned inrm = 0;
@@ -180,6 +200,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
             __syncthreads(); // B2
+            HBG_STAMP_ONCE(3);
             const int pos_hi = misc[1];
             // ---- (3) Gram entries among the round's candidates: cg[k][c] = x_k . x_c for k < c, zero elsewhere ----
             for (int idx = t; idx < ncr * 64; idx += P) {
@@ -193,6 +214,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 cg[idx] = gval;
             }
             __syncthreads(); // B3
+            HBG_STAMP_ONCE(4);
             // ---- (4) the exact serial chain over the round's candidates: wave 0, one candidate per lane, in marker order ----
             if (wave == 0) {
                 const bool lv = lane < ncr;
@@ -244,21 +266,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (lane == 0) misc[0] = __popcll(moved);
             }
             __syncthreads(); // B4
+            HBG_STAMP_ONCE(5);
             const int nmoves = misc[0];
-            // ---- (5) the round's moves onto the later markers of the group; the forward rows are requested in the same trip ----
-            double rnew[HBG_DM];
+            // ---- (5) the round's moves onto the later markers of the group AND forward, all rows of up to HBG_CH moves in one
+            // trip (a lone compute unit's loads take microseconds beside the streaming mat-vec: the number of dependent trips is
+            // what a group costs). The forward contributions are summed in registers and reach the correction ring only when the
+            // round is committed. ----
+            double rnew[HBG_DM], fw[HBG_FW];
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) rnew[i] = r0[i];
+#pragma unroll
+            for (int x = 0; x < HBG_FW; x++) fw[x] = 0.0;
             // (row addresses are "wave-uniform pointer"[t]: scalar base + one vector offset, no 64-bit vector arithmetic)
             const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP; // block l = 0 of the group's first panel
             const size_t pstep = (size_t)(pv.Lg + 2) * PP;                   // block l of panel p -> block l + 1 of panel p + 1
+            const int nfw = max(0, min(pv.Lv * D, np - (gp0 + D)));        // panels ahead that are owed the corrections
+            const bool have_fw = nfw > 0;
 #pragma unroll 1
-            for (int e0 = 0; e0 < nmoves; e0 += 2) {
-                int gv[2][HBG_DM];
-                int pae[2], iae[2];
-                double dl[2];
+            for (int e0 = 0; e0 < nmoves; e0 += HBG_CH) {
+                int gv[HBG_CH][HBG_DM], gf[HBG_CH][HBG_FW];
+                int pae[HBG_CH], iae[HBG_CH];
+                double dl[HBG_CH];
 #pragma unroll
-                for (int f = 0; f < 2; f++) {
+                for (int f = 0; f < HBG_CH; f++) {
                     const int e = min(e0 + f, nmoves - 1);
                     const int a = __builtin_amdgcn_readfirstlane(ev_pos[e]);
                     pae[f] = a >> lgP;
@@ -266,25 +296,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     dl[f] = (e0 + f < nmoves) ? ev_del[e] : 0.0;
                 }
 #pragma unroll
-                for (int f = 0; f < 2; f++) {
-                    // panel i of the group meets the mover (panel pae) in its block l = i - pae: block address
-                    // gblk0 + (i (Lg + 1) + i - pae) PP = (gblk0 - pae PP) + i (Lg + 2) PP
-                    uintptr_t row = (uintptr_t)gblk0 + ((size_t)iae[f] * P) * 4 - ((size_t)pae[f] * PP) * 4;
+                for (int f = 0; f < HBG_CH; f++) {
+                    // panel i of the group meets the mover (panel pae) in its block l = i - pae, at
+                    // gblk0 + (i (Lg + 1) + i - pae) PP = (gblk0 - pae PP) + i (Lg + 2) PP; the panels ahead continue the same walk.
+                    // Branch-free: a panel before the mover's or past the group's end reads a neighbouring valid row instead (its
+                    // value is not used) — behind a branch every load would be waited for on the spot.
+                    const int32_t *row = gblk0 + (size_t)iae[f] * P + (size_t)pae[f] * (pstep - PP); // i = pae
 #pragma unroll
                     for (int i = 0; i < HBG_DM; i++) {
-                        gv[f][i] = 0;
-                        if (i >= pae[f] && i < Dg) gv[f][i] = reinterpret_cast<const int32_t *>(row)[t]; // (uniform)
-                        row += pstep * 4;
+                        gv[f][i] = row[t];
+                        row += (i >= pae[f] && i + 1 < Dg) ? pstep : 0; // (scalar select)
+                    }
+                    // (no panel ahead at the end of the sweep: the loads stay, on an address that exists; their values are not used)
+                    row = have_fw ? gblk0 + (size_t)iae[f] * P + (size_t)D * pstep - (size_t)pae[f] * PP : gblk0; // first panel ahead
+#pragma unroll
+                    for (int x = 0; x < HBG_FW; x++) {
+                        gf[f][x] = row[t];
+                        row += (x + 1 < nfw) ? pstep : 0;
                     }
                 }
 #pragma unroll
-                for (int f = 0; f < 2; f++) {
+                for (int f = 0; f < HBG_CH; f++) {
 #pragma unroll
                     for (int i = 0; i < HBG_DM; i++) {
                         // marker (i, t) takes the move of (pae, iae) if it comes later in the order
                         const bool later = i > pae[f] || (i == pae[f] && t > iae[f]);
                         if (i < Dg && later) rnew[i] = fma(-(double)gv[f][i], dl[f], rnew[i]);
                     }
+#pragma unroll
+                    for (int x = 0; x < HBG_FW; x++) fw[x] = (x < nfw) ? fma((double)gf[f][x], dl[f], fw[x]) : fw[x];
                 }
             }
             // ---- (6) did every marker the round passed over really stay below its threshold? ----
@@ -302,6 +342,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (lane == 0) misc[8 + wave] = vm != 0ull;
             }
             __syncthreads(); // B5
+            HBG_STAMP_ONCE(6);
             bool anyv = false;
             {
                 int w8[8];
@@ -360,40 +401,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (lane < HBG_DM) misc[16 + lane] += addme;
                 absd_grp += wave_sum(fabs(dlt));
             }
-            // ---- (8) ... and forward, into the corrections owed to the panels of the next Lv groups ----
-            {
-                const int nfw = min(pv.Lv * D, np - (gp0 + D)); // panels ahead that need it (<= 0: none)
-                const size_t pstep = (size_t)(pv.Lg + 2) * PP;
-#pragma unroll 1
-                for (int e = 0; e < nmoves && nfw > 0; e++) {
-                    const int a = __builtin_amdgcn_readfirstlane(ev_pos[e]);
-                    const int pae = a >> lgP, iae = a & (P - 1);
-                    const double dl = ev_del[e];
-                    // panel q = gp0 + D + x meets the mover (panel gp0 + pae) in its block l = D + x - pae
-                    const int32_t *row0 = v.gram + ((size_t)(gp0 + D) * (pv.Lg + 1) + (D - pae)) * PP + (size_t)iae * P;
-#pragma unroll 1
-                    for (int q0 = 0; q0 < nfw; q0 += 8) {
-                        int gv[8];
-                        const int32_t *row = row0 + (size_t)q0 * pstep;
+            HBG_STAMP_ONCE(7);
+            // ---- (8) ... and the forward sums into the corrections owed to the panels of the next Lv groups ----
+            if (nmoves > 0) {
+                int sl = gslot + D;
+                sl = sl >= R ? sl - R : sl;
 #pragma unroll
-                        for (int qq = 0; qq < 8; qq++) {
-                            gv[qq] = 0;
-                            if (q0 + qq < nfw) gv[qq] = row[t]; // (uniform)
-                            row += pstep;
-                        }
-                        int sl = gslot + D + q0;
-                        sl = sl >= R ? sl - R : sl;
-#pragma unroll
-                        for (int qq = 0; qq < 8; qq++) {
-                            if (q0 + qq < nfw) {
-                                double *cp = corr + (size_t)sl * P + t; // this thread's own word: no synchronisation needed
-                                *cp = fma((double)gv[qq], dl, *cp);
-                            }
-                            sl = (sl + 1 == R) ? 0 : sl + 1;
-                        }
-                    }
+                for (int x = 0; x < HBG_FW; x++) {
+                    if (x < nfw) corr[(size_t)sl * P + t] += fw[x]; // this thread's own word: no synchronisation needed
+                    sl = (sl + 1 == R) ? 0 : sl + 1;
                 }
             }
+            HBG_STAMP_ONCE(8);
+            nmv_grp += nmoves;
+            nround++;
             pos_lo = pos_hi;
             if (pos_lo >= Dg * P) break;
         }
@@ -412,6 +433,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(gp0 + Dg));
         }
+        HBG_STAMP(9);
+        HBG_STAMP_VAL(10, nmv_grp);
+        HBG_STAMP_VAL(13, nround);
         gcount++;
         gslot += D;
         gslot = gslot >= R ? gslot - R : gslot;

@@ -2815,7 +2815,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // (tools/chain_timeline.py with CT_ALONE=1) is then what the chain costs without the mat-vec's memory traffic beside it.
     const bool alone = c->chain_alone || getenv("HB_CHAIN_ALONE") != nullptr;
     // the point-mass models run the group-granular chain (hb_chain_group.hpp); HB_CHAIN=panel keeps the per-panel one
-    const bool group_chain = kp == 1 && (model == 3 || model == 4) && c->chain_kind == 1 && !c->chain_alone && !c->dbg;
+    const bool group_chain = kp == 1 && (model == 3 || model == 4) && c->chain_kind == 1 && !c->chain_alone && Lv * D <= HBG_FW && D <= HBG_DM;
     auto launch_the_chain = [&](hipStream_t st) -> int {
         if (group_chain) {
             hipLaunchKernelGGL((k_chain_group<1>), dim3(1), dim3(c->P), persist_smem(c->P), st, c->d_in, cv, pv);

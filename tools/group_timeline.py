@@ -1,0 +1,63 @@
+"""Where k_chain_group's time goes: cycle stamps per mat-vec group for one sweep in the stationary regime.
+   tools/build_variant.sh stamps "-DHB_STAMPS=1"; python tools/group_timeline.py [model] [burn] [n m]"""
+import os, sys, ctypes as ct
+_v = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hibayes_amd", "variants", "stamps.so")
+if "HIBAYES_GPU_LIB" not in os.environ and os.path.exists(_v):
+    os.environ["HIBAYES_GPU_LIB"] = _v
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import hibayes_amd as H
+from hibayes_amd._lib import BayesArgs, check, RunInfo
+import bench as B
+
+model = sys.argv[1] if len(sys.argv) > 1 else "BayesCpi"
+burn = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 50000
+m = int(sys.argv[4]) if len(sys.argv) > 4 else 500000
+L = H.lib()
+ctx = H.Context(n, m, seed=20240901)
+ctx.generate(20240901, 1000)
+y = B.synth_phenotype(ctx, n, m, 0, m, 20240901, None, model)
+geo = B.PIPELINE[model]
+ctx.set_pipeline(*geo)
+ctx.build_gram()
+ctx.set_adaptive(True)
+Pi, fold = B.prior(model)
+a = BayesArgs()
+a.n, a.m = n, m
+yv = np.ascontiguousarray(y); a.y = yv.ctypes.data
+a.model = model.encode()
+pv = np.array(Pi); a.Pi, a.n_pi = pv.ctypes.data, pv.size
+if fold is not None:
+    fv = np.array(fold); a.fold, a.n_fold = fv.ctypes.data, fv.size
+a.niter, a.nburn, a.thin = burn + 20, 0, 5
+a.seed, a.precise, a.ctx = 20240901, 2, ctx.h
+run = ct.c_void_p(); check(L.hb_run_create(ct.byref(a), ct.byref(run)))
+fin = ct.c_int32()
+check(L.hb_run_step(run, burn, ct.byref(fin)))
+ctx.set_profiling(2)
+check(L.hb_run_step(run, 3, ct.byref(fin)))
+P = ctx.panel; npan = (m + P - 1) // P
+D = ctx.pipeline()[2]
+ng = (npan + D - 1) // D
+st = np.zeros(32 * npan, dtype=np.int64)
+L.hb_ctx_debug_stamps.argtypes = [ct.c_void_p, ct.c_void_p]
+check(L.hb_ctx_debug_stamps(ctx.h, st.ctypes.data))
+st = st.reshape(npan, 32)[:ng]
+info = RunInfo(); check(L.hb_run_state(run, ct.byref(info)))
+nmv, cand, rounds = st[:, 10], st[:, 12], st[:, 13]
+per = np.append(st[1:, 0] - st[:-1, 0], st[-1, 9] - st[-1, 0])
+cyc = float(st[-1, 9] - st[0, 0])
+print("%s geometry %s: %d groups, %d moves, %d candidates; chain span %d cycles" % (model, ctx.pipeline(), ng, nmv.sum(), cand.sum(), cyc))
+for name, sel in (("quiet", cand == 0), ("candidates, no move", (cand > 0) & (nmv == 0)), ("1-4 moves", (nmv >= 1) & (nmv <= 4)),
+                  ("5-12 moves", (nmv >= 5) & (nmv <= 12)), (">12 moves", nmv > 12)):
+    k = sel.sum()
+    if not k:
+        continue
+    s = st[sel]
+    seg = lambda a, b: np.where((s[:, a] > 0) & (s[:, b] > 0), s[:, b] - s[:, a], 0).mean()
+    print("  %-20s groups %4d period %7.0f cyc (%.1f %% of the sweep) waited for dots %3.0f %% rounds %.2f cand %.1f" % (
+        name, k, per[sel].mean(), 100 * per[sel].sum() / cyc, 100 * s[:, 11].mean(), rounds[sel].mean(), cand[sel].mean()))
+    print("      dots %6.0f | rank %6.0f | exact data %6.0f | gram gather %6.0f | serial %6.0f | fold+verify %6.0f | commit+publish %6.0f | forward %6.0f | later rounds+end %6.0f" % (
+        seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4), seg(4, 5), seg(5, 6), seg(6, 7), seg(7, 8), seg(8, 9)))
+print("moves/sweep %.0f" % info.mean_events)
