@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--precise", type=int, default=2,
                     help="panel mat-vec arithmetic: 2 = exact fixed point (7 int8 digit planes of the fp64 residual, int32 dot4 "
                          "accumulation; fp64-grade, the library default), 1 = fp64 FMA, 0 = fp32 image of the residual")
+    ap.add_argument("--bits", type=int, default=int(os.environ.get("HB_BENCH_BITS", "2")), choices=[2, 8],
+                    help="resident genotype layout the sweep reads: 8 = int8 columns (SURVEY §8 a1), 2 = 2 bits per genotype (§8 f1: "
+                         "PLINK's density, expanded in registers inside the mat-vec; a quarter of the bytes; same chain bit for bit)")
     ap.add_argument("--seed", type=int, default=20240901)
     ap.add_argument("--cpu-m", type=int, default=8000, help="markers of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-sweeps", type=int, default=4)
@@ -162,21 +165,27 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
             "cpu_model": cpu_model}
 
 
-def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic):
+def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8):
     """roofline of the dominant kernel. achieved = algorithmic bytes per launch (n x columns per launch: one read of the launch's
     int8 genotypes, SURVEY.md §8 d) / the average duration of the sweep's full-width mat-vec launches AS THE SWEEP RUNS THEM
     (device-clock stamps of every block, chain and update rows beside them); `isolated` is the same launch shape replayed without
     update rows and chain between two HIP events (round 2's figure)."""
-    alg = float(n) * cols
+    alg8 = float(n) * cols               # SURVEY §8 d: one byte per genotype (the int8 contract)
+    alg = alg8 * bits / 8.0              # what the resident layout holds: the bytes this kernel has to move
     avg_ms = insitu["avg_ms"] if insitu else iso_ms
     ach = alg / (avg_ms * 1e-3) / 1e9
-    r = {"bound": "hbm", "kernel": "k_dotq" if args.precise == 2 else "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    r = {"bound": "hbm", "kernel": ("k_dotq2" if bits == 2 else "k_dotq") if args.precise == 2 else "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": alg, "avg_launch_ms": avg_ms,
          "launches_per_sweep": insitu["launches_per_sweep"] if insitu else launches, "columns_per_launch": cols,
          "measured": "in situ: device-clock stamps of every block of every mat-vec launch over %d sweeps following the timed region"
                      % insitu["sweeps"] if insitu else "isolated replay (HIP events)",
          "isolated": {"avg_launch_ms": iso_ms, "achieved": alg / (iso_ms * 1e-3) / 1e9, "frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                       "what": "the same launches without update rows and chain, graph replay between two HIP events"}}
+    r["resident_bits_per_genotype"] = bits
+    if bits != 8:  # both denominators: the resident bytes above (the kernel's real HBM roofline), and SURVEY §8 d's n x m bytes
+        r["at_one_byte_per_genotype"] = {"bytes_per_launch": alg8, "achieved": alg8 / (avg_ms * 1e-3) / 1e9,
+                                         "frac": alg8 / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                         "what": "the same launch priced at SURVEY §8 d's n x m bytes (int8 contract): genotypes per second, not bytes moved"}
     if insitu:
         r["in_situ"] = {k: insitu[k] for k in ("min_ms", "max_ms", "sum_ms", "span_ms", "blocks_per_launch", "full_width_launches",
                                                "ms_per_step_of_the_stamped_sweeps")}
@@ -380,6 +389,13 @@ def main():
         ctx.set_adaptive(True)  # narrow band while many markers move (burn-in), this geometry once few do (the timed region)
     gram_s = ctx.build_gram()
     note("Gram blocks built (%.2fs)" % gram_s)
+    pack_s = 0.0
+    if args.bits == 2 and args.precise == 2:
+        t0 = time.time()
+        ctx.set_layout(2, keep_int8=False)   # packed on the device from the int8 columns, which are then dropped
+        pack_s = time.time() - t0
+        note("genotypes packed to 2 bits, int8 copy dropped (%.2fs)" % pack_s)
+    bits = ctx.layout()[0]
 
     K, W = args.steps, args.warmup
     elapsed, mean_events, nnz, misses = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
@@ -404,7 +420,7 @@ def main():
             traffic = pm["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
-    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, traffic)
+    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, traffic if bits == 8 else None, bits)
     note("mat-vec timing pass done")
 
     # one unit = one pass over m_ref markers (the metric's m = 500k); all ranks together pass over m_global markers per step
@@ -416,8 +432,8 @@ def main():
         "value": value, "unit": "sweeps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
         "vs_baseline": None, "dtype": DTYPE[args.precise], "data": "synthetic",
-        "config": {"workload": "%s marker sweep, n=%d individuals x m=%d int8 markers per GPU (m_global=%d), "
-                               "panel=%d, pipeline=%s" % (args.model, n, m, m_global, ctx.panel, (geo,)),
+        "config": {"workload": "%s marker sweep, n=%d individuals x m=%d markers per GPU (m_global=%d), genotypes resident at %d bits, "
+                               "panel=%d, pipeline=%s" % (args.model, n, m, m_global, bits, ctx.panel, (geo,)),
                    "model": args.model, "n": n, "m_per_gpu": m, "m_global": m_global, "panel": ctx.panel,
                    "pipeline": {"persistent_chain": geo[0], "lookahead_groups": geo[1], "panels_per_matvec": geo[2],
                                 "geometry_by_regime": bool(adaptive),
@@ -426,7 +442,7 @@ def main():
                    "collective": comm.rccl_note if comm is not None else "none",
                    "mcmc_burn_in_sweeps_before_warmup": args.burnin,
                    "mean_changed_markers_per_sweep": mean_events, "row_cache_misses_per_sweep": misses, "NumNZSnp_last": nnz,
-                   "setup_seconds": {"generate": gen_s, "gram": gram_s}},
+                   "resident_genotype_bits": bits, "setup_seconds": {"generate": gen_s, "gram": gram_s, "pack_2bit": pack_s}},
         "achieved_GBps": (K / elapsed) * n * m_global / 1e9, "achieved_frac_of_hbm_peak": (K / elapsed) * n * m_global / 1e9 / (HBM_PEAK_GBPS * world),
         "roofline": roof,
         "regime_curve": curve_main,   # sweeps/s is set by the serial chain, i.e. by how many markers change per sweep
@@ -446,7 +462,7 @@ def main():
         curve2 = list(getattr(measure, "curve", []))
         curve2.append({"sweeps": "timed region", "moves_per_sweep": round(ev2, 1), "sweeps_per_s": round(K2 / el2, 2)})
         res["secondary"] = {"model": args.secondary, "value": K2 / el2, "unit": "sweeps/s", "steps": K2, "warmup": W2,
-                            "roofline": roofline_block(args, n, cols2, launches2, ins2, iso2, None),
+                            "roofline": roofline_block(args, n, cols2, launches2, ins2, iso2, None, bits),
                             "ms_per_step": el2 / K2 * 1e3, "achieved_frac_of_hbm_peak": K2 / el2 * n * m / 1e9 / HBM_PEAK_GBPS,
                             "mcmc_burn_in_sweeps_before_warmup": args.burnin_secondary,
                           "mean_changed_markers_per_sweep": ev2, "row_cache_misses_per_sweep": miss2, "NumNZSnp_last": nnz2,

@@ -58,6 +58,7 @@ class BayesArgs(C.Structure):
         ("g_init", C.c_void_p),
         ("comm", C.c_void_p),
         ("sync_blocks", C.c_int32),
+        ("genotype_bits", C.c_int32),
     ]
 
 
@@ -136,7 +137,7 @@ SYMBOLS = [
     "hb_ctx_get_residual", "hb_ctx_set_effects", "hb_ctx_get_effects", "hb_ctx_dot", "hb_ctx_residual_sums",
     "hb_ctx_residual_shift", "hb_ctx_set_covariates", "hb_ctx_cov_dot", "hb_ctx_cov_axpy", "hb_ctx_set_levels",
     "hb_ctx_level_sums", "hb_ctx_level_axpy", "hb_ctx_blocks_setup", "hb_ctx_blocks_step", "hb_ctx_blocks_state", "hb_ctx_sweep", "hb_ctx_sweep_range", "hb_ctx_sweep_end", "hb_ctx_get_counters", "hb_ctx_set_windows",
-    "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec", "hb_ctx_matvec_stamps",
+    "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec", "hb_ctx_matvec_stamps", "hb_ctx_set_layout", "hb_ctx_get_layout",
     "hb_ctx_download_gram_band", "hb_ctx_set_adaptive", "hb_ctx_get_pipeline", "hb_ctx_get_events", "hb_ctx_pipeline_note", "hb_ctx_matmul",
     "hb_comm_unique_id", "hb_comm_init", "hb_comm_world", "hb_comm_rank", "hb_comm_selftest", "hb_comm_destroy",
     "hb_run_create", "hb_run_step", "hb_run_state", "hb_run_ctx", "hb_run_finish", "hb_run_destroy",
@@ -225,6 +226,8 @@ def lib():
     L.hb_ctx_set_pipeline.argtypes = [vp, i32, i32, i32]
     L.hb_ctx_set_adaptive.argtypes = [vp, i32]
     L.hb_ctx_time_matvec.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(i32), C.POINTER(i32)]
+    L.hb_ctx_set_layout.argtypes = [vp, i32, i32]
+    L.hb_ctx_get_layout.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.hb_ctx_matvec_stamps.argtypes = [vp, C.POINTER(LaunchStats)]
     L.hb_run_create.argtypes = [C.POINTER(BayesArgs), C.POINTER(vp)]
     L.hb_run_step.argtypes = [vp, i32, C.POINTER(i32)]

@@ -30,6 +30,8 @@ int hbk_cov_step(hb_ctx *c, int i, double v, double vare, double z, double *beta
 int hbk_lev_step(hb_ctx *c, int term, int q0, int qr, const double *zz, double *estR, const double *z, double vare, double *vrtmp,
                  double *vr, double s2r_dfr, double chis);
 int hbk_xmat(hb_ctx *c, const int *didx, const double *dval, int nnz, double *dout);
+int hbk_pack2(hb_ctx *c);
+int hbk_unpack2(hb_ctx *c, int col0, int ncols, int8_t *dst);
 
 static thread_local std::string g_err;
 
@@ -121,6 +123,8 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_LOOKAHEAD")) c->Lv = atoi(e);
     if (const char *e = getenv("HB_DOTGROUP")) c->D = atoi(e);
     if (const char *e = getenv("HB_GRAPH")) c->use_graph = atoi(e) != 0;
+    if (const char *e = getenv("HB_DOTQ2_CPL")) c->dotq2_cpl = atoi(e) == 1 ? 1 : 2;
+    if (const char *e = getenv("HB_DOTQ2_TILES")) c->dotq2_tiles = std::max(1, atoi(e));
     if (const char *e = getenv("HB_CHAIN")) c->chain_kind = std::strcmp(e, "panel") == 0 ? 0 : 1;
     if (const char *e = getenv("HB_KAPPA")) c->kappa = atof(e);
     if (const char *e = getenv("HB_DOT_LDS")) c->dot_lds = std::min(65536, std::max(0, atoi(e)));
@@ -254,7 +258,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
-    void *ptrs[] = {c->X, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
+    void *ptrs[] = {c->X, c->X2, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->dots, c->ev_count, c->ev_idx,
                     c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
     for (void *p : ptrs)
@@ -283,11 +287,23 @@ static void invalidate(hb_ctx *c)
 {
     c->gram_ready = false;
     c->stats_ready = false;
+    if (c->layout == 2) { // new genotypes: the packed copy is stale
+        c->layout = 8;
+        c->graph_model = -1;
+    }
+}
+
+static int need_int8(hb_ctx *c, const char *who)
+{
+    if (!c->X) return hb_fail(HB_ERR_INVALID, std::string(who) + ": the context holds its genotypes in the 2-bit layout only (hb_ctx_set_layout(c, 8, 1) unpacks them)");
+    return HB_OK;
 }
 
 int hb_ctx_upload_genotype_i8(hb_ctx *c, const int8_t *X, int64_t ld, int32_t col0, int32_t ncols)
 {
     int rc = check_cols(c, col0, ncols, "hb_ctx_upload_genotype_i8");
+    if (rc) return rc;
+    rc = need_int8(c, "hb_ctx_upload_genotype_i8");
     if (rc) return rc;
     if (!X || ld < c->n) return hb_fail(HB_ERR_INVALID, "hb_ctx_upload_genotype_i8: bad source");
     HB_HIP(hipMemcpy2DAsync(c->X + (int64_t)col0 * c->ld, (size_t)c->ld, X, (size_t)ld, (size_t)c->n, (size_t)ncols,
@@ -300,6 +316,8 @@ int hb_ctx_upload_genotype_i8(hb_ctx *c, const int8_t *X, int64_t ld, int32_t co
 int hb_ctx_upload_genotype_f64(hb_ctx *c, const double *X, int64_t ld, int32_t col0, int32_t ncols)
 {
     int rc = check_cols(c, col0, ncols, "hb_ctx_upload_genotype_f64");
+    if (rc) return rc;
+    rc = need_int8(c, "hb_ctx_upload_genotype_f64");
     if (rc) return rc;
     if (!X || ld < c->n) return hb_fail(HB_ERR_INVALID, "hb_ctx_upload_genotype_f64: bad source");
     const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(ncols, (int64_t)(64 << 20) / std::max(1, c->n)));
@@ -336,6 +354,8 @@ int hb_ctx_upload_bed(hb_ctx *c, const uint8_t *bed, int64_t nbytes, int32_t nin
 {
     int rc = check_cols(c, col0, ncols, "hb_ctx_upload_bed");
     if (rc) return rc;
+    rc = need_int8(c, "hb_ctx_upload_bed");
+    if (rc) return rc;
     const int64_t bpc = ((int64_t)nind + 3) / 4;
     if (!bed || nbytes < 3 + bpc * ((int64_t)col0 + ncols)) return hb_fail(HB_ERR_INVALID, "hb_ctx_upload_bed: file image too short");
     if (bed[0] != 0x6c || bed[1] != 0x1b || bed[2] != 0x01)
@@ -364,6 +384,8 @@ int hb_ctx_generate_genotype(hb_ctx *c, uint64_t seed, int32_t mono_every)
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_generate_genotype");
     if (rc) return rc;
+    rc = need_int8(c, "hb_ctx_generate_genotype");
+    if (rc) return rc;
     rc = hbk_generate(c, seed, mono_every);
     if (rc) return rc;
     HB_HIP(hipStreamSynchronize(c->stream));
@@ -375,6 +397,23 @@ int hb_ctx_download_genotype(hb_ctx *c, int8_t *X, int64_t ld, int32_t col0, int
 {
     int rc = check_cols(c, col0, ncols, "hb_ctx_download_genotype");
     if (rc) return rc;
+    if (!c->X) { // 2-bit only: unpack a slab at a time into a scratch buffer
+        const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(ncols, (int64_t)(256 << 20) / c->ld));
+        int8_t *tmp = nullptr;
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)chunk * c->ld));
+        hipError_t e = hipSuccess;
+        for (int c0 = 0; c0 < ncols && e == hipSuccess && rc == HB_OK; c0 += chunk) {
+            const int nc = std::min(chunk, ncols - c0);
+            rc = hbk_unpack2(c, col0 + c0, nc, tmp);
+            if (rc == HB_OK) e = hipStreamSynchronize(c->stream);
+            if (rc == HB_OK && e == hipSuccess)
+                e = hipMemcpy2D(X + (int64_t)c0 * ld, (size_t)ld, tmp, (size_t)c->ld, (size_t)c->n, (size_t)nc, hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(tmp);
+        if (rc) return rc;
+        if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("hb_ctx_download_genotype: ") + hipGetErrorString(e));
+        return HB_OK;
+    }
     HB_HIP(hipMemcpy2D(X, (size_t)ld, c->X + (int64_t)col0 * c->ld, (size_t)c->ld, (size_t)c->n, (size_t)ncols,
                        hipMemcpyDeviceToHost));
     return HB_OK;
@@ -398,8 +437,12 @@ int hb_ctx_marker_stats(hb_ctx *c, double *xpx, double *vx, double *sumvx, int32
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_marker_stats");
     if (rc) return rc;
-    rc = hbk_stats(c);
-    if (rc) return rc;
+    if (c->X || !c->stats_ready) { // (2-bit only: xpx / vx were computed before the int8 copy was dropped and stay valid)
+        rc = need_int8(c, "hb_ctx_marker_stats");
+        if (rc) return rc;
+        rc = hbk_stats(c);
+        if (rc) return rc;
+    }
     std::vector<double> hv(c->m);
     HB_HIP(hipMemcpy(hv.data(), c->vx, sizeof(double) * c->m, hipMemcpyDeviceToHost));
     if (vx) std::memcpy(vx, hv.data(), sizeof(double) * c->m);
@@ -410,6 +453,61 @@ int hb_ctx_marker_stats(hb_ctx *c, double *xpx, double *vx, double *sumvx, int32
         for (double v : hv) z += (v == 0.0);
         *nvar0 = z;
     }
+    return HB_OK;
+}
+
+int hb_ctx_set_layout(hb_ctx *c, int32_t bits, int32_t keep_int8)
+{
+    int rc = check_cols(c, 0, 0, "hb_ctx_set_layout");
+    if (rc) return rc;
+    if (bits == 0) bits = 8;
+    if (bits != 8 && bits != 2) return hb_fail(HB_ERR_INVALID, "hb_ctx_set_layout: bits must be 8 or 2");
+    HB_HIP(hipStreamSynchronize(c->stream));
+    if (bits == 8) {
+        if (!c->X) { // unpack the dropped int8 copy
+            HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->X), (size_t)c->ld * c->m_pad));
+            HB_HIP(hipMemsetAsync(c->X, 0, (size_t)c->ld * c->m_pad, c->stream));
+            rc = hbk_unpack2(c, 0, c->m_pad, c->X);
+            if (rc) return rc;
+            HB_HIP(hipStreamSynchronize(c->stream));
+        }
+        if (c->layout != 8) c->graph_model = -1;
+        c->layout = 8;
+        return HB_OK;
+    }
+    if (c->precise != 2)
+        return hb_fail(HB_ERR_UNSUPPORTED, "the 2-bit resident layout needs the fixed-point mat-vec (precise = 2)");
+    if (c->layout != 2) {
+        rc = need_int8(c, "hb_ctx_set_layout");
+        if (rc) return rc;
+        if (!c->stats_ready) {
+            rc = hbk_stats(c);
+            if (rc) return rc;
+        }
+        if (c->xmin < 0 || c->xmax > 3)
+            return hb_fail(HB_ERR_UNSUPPORTED, "the 2-bit resident layout needs genotype codes 0..3 (this matrix holds " + std::to_string(c->xmin) +
+                                                   ".." + std::to_string(c->xmax) + "): keep the int8 layout");
+        c->ld2 = (c->ld + 511) / 512 * 128;
+        if (!c->X2) HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->X2), (size_t)c->ld2 * c->m_pad));
+        rc = hbk_pack2(c);
+        if (rc) return rc;
+        HB_HIP(hipStreamSynchronize(c->stream));
+        c->layout = 2;
+        c->graph_model = -1;
+    }
+    if (!keep_int8 && c->X) {
+        (void)hipFree(c->X);
+        c->X = nullptr;
+        c->graph_model = -1;
+    }
+    return HB_OK;
+}
+
+int hb_ctx_get_layout(const hb_ctx *c, int32_t *bits, int32_t *int8_resident)
+{
+    if (!c) return hb_fail(HB_ERR_INVALID, "hb_ctx_get_layout: null context");
+    if (bits) *bits = c->layout;
+    if (int8_resident) *int8_resident = c->X != nullptr;
     return HB_OK;
 }
 
@@ -440,6 +538,12 @@ int hb_ctx_build_gram(hb_ctx *c, double *seconds)
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_build_gram");
     if (rc) return rc;
+    if (!c->X) { // the int8 copy was dropped: unpack it for the build, drop it again afterwards
+        rc = hb_ctx_set_layout(c, 8, 1);
+        if (rc == HB_OK) rc = hb_ctx_build_gram(c, seconds);
+        if (rc == HB_OK) rc = hb_ctx_set_layout(c, 2, 0);
+        return rc;
+    }
     c->Lg = c->L; // the band this build stores
     const size_t need = (size_t)c->m_pad * (size_t)c->P * (size_t)(c->Lg + 1);
     if (need > c->gram_cap) {

@@ -60,6 +60,11 @@ struct hb_ctx {
     hipEvent_t ev_fork = nullptr;
 
     int8_t *X = nullptr;
+    // 2-bit resident layout (hb_dotq2.hpp; hb_ctx_set_layout): layout == 2 makes the sweep's kernels read X2; X may then be dropped
+    uint32_t *X2 = nullptr;
+    int64_t ld2 = 0;     // bytes per column of X2 = 128 * ceil(ld / 512)
+    int layout = 8;      // 8: int8 columns, 2: 2-bit columns
+    int dotq2_cpl = 2, dotq2_tiles = 512; // k_dotq2 launch shape (HB_DOTQ2_CPL, HB_DOTQ2_TILES)
     double *xpx = nullptr, *vx = nullptr, *g = nullptr, *vargL = nullptr;
     double *alpha_sum = nullptr, *alpha_sq = nullptr;
     uint8_t *tracker = nullptr;

@@ -154,7 +154,20 @@ struct upd_view {
     int8_t *rq;                  // digit planes of the output slot (null: other paths)
     const double *mbv;           // bound on max |yadj| after these moves
     int *vexp_out;               // exponent of the output slot
+    const uint32_t *X2;          // non-null: the genotypes in the 2-bit resident layout (hb_dotq2.hpp), ld2w words per column
+    int64_t ld2w;
 };
+
+// four consecutive individuals (row0 a multiple of 4) of one column, one genotype per byte: from the int8 matrix, or expanded in
+// registers from the 2-bit resident layout (individual 16 w + 4 k + b sits in bits [8 b + 2 k, 8 b + 2 k + 1] of word w)
+__device__ __forceinline__ int hb_ld4(const int8_t *X, int64_t ld, const uint32_t *X2, int64_t ld2w, int64_t col, int64_t row0)
+{
+    if (X2) {
+        const unsigned w = X2[col * ld2w + (row0 >> 4)];
+        return (int)((w >> ((row0 & 12) >> 1)) & 0x03030303u);
+    }
+    return *reinterpret_cast<const int *>(X + col * ld + row0);
+}
 
 // exponent E with bound * 2^E < 2^54 (0 for an all-zero or non-finite bound)
 __device__ __forceinline__ int hb_fix_exp(double bound)
@@ -228,11 +241,11 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
         }
         __syncthreads();
         if (!mine) continue;
-        const int8_t *xp = q.X + (int64_t)p * q.P * ld + row0;
+        const int64_t col0 = (int64_t)p * q.P;
         for (int e = 0; e < nev; e += 8) {
             int w[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) w[k] = *reinterpret_cast<const int *>(xp + (int64_t)s_ix[min(e + k, nev - 1)] * ld);
+            for (int k = 0; k < 8; k++) w[k] = hb_ld4(q.X, ld, q.X2, q.ld2w, col0 + s_ix[min(e + k, nev - 1)], row0);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const double d = (e + k < nev) ? s_dl[e + k] : 0.0;
@@ -420,6 +433,8 @@ struct dq_view {
     double *fin_out;
     const int *fin_exp;
     int fin_ncols;
+    const uint8_t *X2;     // 2-bit resident layout (k_dotq2): first column of this launch, ld2 bytes per column
+    int64_t ld2;
     unsigned long long *stamp; // optional (hb_ctx_set_profiling bit 3): [block][2] = wall_clock64() at the block's start and end
 };
 
@@ -535,6 +550,8 @@ __global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
         v.stamp[2 * (size_t)blockIdx.x + 1] = wall_clock64();
     }
 }
+
+#include "hb_dotq2.hpp"
 
 // Sweep start of the fixed-point path: max |yadj| -> mb[0] and the exponent of slot 0, then slot 0's digit planes.
 // One workgroup (n is a few hundred KB).
@@ -2362,7 +2379,7 @@ __global__ __launch_bounds__(256) void k_bed_decode(const uint8_t *__restrict__ 
 }
 
 // out[row] = sum_j x[row][j] alpha[j]  (e -= X*alpha, reference src/Bayes.cpp:971); block = 1024 rows x 256 columns
-__global__ __launch_bounds__(256) void k_xalpha(const int8_t *__restrict__ X, int64_t ld, int m_pad,
+__global__ __launch_bounds__(256) void k_xalpha(const int8_t *__restrict__ X, int64_t ld, const uint32_t *__restrict__ X2, int64_t ld2w, int m_pad,
                                                 const double *__restrict__ alpha, double *__restrict__ out)
 {
     const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -2372,7 +2389,7 @@ __global__ __launch_bounds__(256) void k_xalpha(const int8_t *__restrict__ X, in
     for (int j = j0; j < j1; j++) {
         const double al = alpha[j];
         if (al == 0.0) continue;
-        const int w = *reinterpret_cast<const int *>(X + (int64_t)j * ld + row0);
+        const int w = hb_ld4(X, ld, X2, ld2w, j, row0);
         a0 = fma((double)(int8_t)(w), al, a0);
         a1 = fma((double)(int8_t)(w >> 8), al, a1);
         a2 = fma((double)(int8_t)(w >> 16), al, a2);
@@ -2389,7 +2406,7 @@ __global__ __launch_bounds__(256) void k_xalpha(const int8_t *__restrict__ X, in
 // point-mass models keep ~0.1-5 % of the markers in the model), so the work is n x nnz x 8 instead of n x m x 8.
 // thread = 4 rows x 8 records (32 fp64 accumulators, no atomics); the column index and its 8 effects are wave-uniform.
 #define HB_XM_RB 8
-__global__ __launch_bounds__(256) void k_xmat(const int8_t *__restrict__ X, int64_t ld, const int *__restrict__ idx,
+__global__ __launch_bounds__(256) void k_xmat(const int8_t *__restrict__ X, int64_t ld, const uint32_t *__restrict__ X2, int64_t ld2w, const int *__restrict__ idx,
                                               const double *__restrict__ val, int nnz, double *__restrict__ out, int64_t ldo)
 {
     const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -2402,7 +2419,7 @@ __global__ __launch_bounds__(256) void k_xmat(const int8_t *__restrict__ X, int6
     for (int e0 = 0; e0 < nnz; e0 += 4) {
         int w[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) w[k] = *reinterpret_cast<const int *>(X + (int64_t)idx[min(e0 + k, nnz - 1)] * ld + row0);
+        for (int k = 0; k < 4; k++) w[k] = hb_ld4(X, ld, X2, ld2w, idx[min(e0 + k, nnz - 1)], row0);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (e0 + k < nnz) { // uniform
@@ -2424,7 +2441,7 @@ __global__ __launch_bounds__(256) void k_xmat(const int8_t *__restrict__ X, int6
 
 int hbk_xmat(hb_ctx *c, const int *didx, const double *dval, int nnz, double *dout)
 {
-    hipLaunchKernelGGL(k_xmat, dim3((unsigned)((c->ld / 4 + 255) / 256)), dim3(256), 0, c->stream, c->X, c->ld, didx, dval, nnz, dout, c->ld);
+    hipLaunchKernelGGL(k_xmat, dim3((unsigned)((c->ld / 4 + 255) / 256)), dim3(256), 0, c->stream, c->X, c->ld, c->layout == 2 ? c->X2 : nullptr, c->ld2 / 4, didx, dval, nnz, dout, c->ld);
     HB_HIP(hipGetLastError());
     return HB_OK;
 }
@@ -2512,9 +2529,54 @@ static void dotq_geometry(const hb_ctx *c, int ncols, int *ncg, int *NS, int *ns
     *nsplit = (nst + *NS - 1) / *NS;
 }
 
+// the same launch on the 2-bit resident layout (hb_dotq2.hpp): about two long-lived waves per compute unit
+static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st, int gidx, const upd_view *upd, int fin_col0,
+                         int fin_ncols, int fin_gidx)
+{
+    int cpl = (ncols % 128 == 0) ? c->dotq2_cpl : 1;
+    const int nst = (int)((c->ld + Q2_RS - 1) / Q2_RS);
+    const int ncg = ncols / (64 * cpl);
+    const int ns = std::max(1, std::min(nst, (int)((double)c->dotq2_tiles / ncg + 0.5)));
+    const int NS = (nst + ns - 1) / ns, nsplit = (nst + NS - 1) / NS;
+    upd_view uq{};
+    if (upd) uq = *upd;
+    dq_view v{};
+    v.X = nullptr;
+    v.X2 = reinterpret_cast<const uint8_t *>(c->X2) + (int64_t)col0 * c->ld2;
+    v.ld2 = c->ld2;
+    v.ld = c->ld;
+    v.rq = c->rq + (size_t)slot * HB_ND * c->ld;
+    v.vexp_in = c->vexp + slot;
+    v.gexp_out = c->gexp + gidx;
+    v.accq = c->accq + col0;
+    v.accstride = c->m_pad;
+    v.nstages = nst;
+    v.NS = NS;
+    v.ncg = ncg;
+    v.nupd = (uq.p1 > uq.p0) ? (int)(c->ld / 256) : 0;
+    v.nfin = fin_ncols > 0 ? (fin_ncols + 63) / 64 : 0;
+    v.fin_acc = c->accq + fin_col0;
+    v.fin_out = c->dsum + fin_col0;
+    v.fin_exp = c->gexp + fin_gidx;
+    v.fin_ncols = fin_ncols;
+    const int nblk = v.nupd + v.nfin + ncg * nsplit;
+    v.stamp = nullptr;
+    if (c->lstamp && gidx >= 0 && gidx <= c->npanels && nblk <= HB_LSTAMP_BLOCKS) {
+        v.stamp = c->lstamp + (size_t)gidx * HB_LSTAMP_BLOCKS * 2;
+        c->lstamp_nblk[gidx] = nblk;
+        c->lstamp_cols[gidx] = ncols;
+    }
+    if (cpl == 2) hipLaunchKernelGGL((k_dotq2<2>), dim3(nblk), dim3(64), 2 * (16 * HBQ_SLOT + Q2_DP * 1024), st, v, uq);
+    else hipLaunchKernelGGL((k_dotq2<1>), dim3(nblk), dim3(64), 2 * (8 * HBQ_SLOT + Q2_DP * 1024), st, v, uq);
+}
+
 static void launch_dotq(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st, int gidx, const upd_view *upd, int fin_col0,
                         int fin_ncols, int fin_gidx)
 {
+    if (c->layout == 2) {
+        launch_dotq2(c, col0, ncols, slot, st, gidx, upd, fin_col0, fin_ncols, fin_gidx);
+        return;
+    }
     int ncg, NS, nsplit;
     dotq_geometry(c, ncols, &ncg, &NS, &nsplit);
     upd_view uq{};
@@ -2603,7 +2665,8 @@ static upd_view make_upd(hb_ctx *c, int p0, int p1, int sin, int sout, unsigned 
     const bool fx = c->precise == 2;
     return upd_view{c->X, c->P, p0, p1, c->ev_count, c->ev_idx, c->ev_delta, c->r + (size_t)sin * c->ld,
                     c->r + (size_t)sout * c->ld, c->u, c->r32 + (size_t)sout * c->ld, flags,
-                    fx ? c->rq + (size_t)sout * HB_ND * c->ld : nullptr, c->mb + 1 + mbi, c->vexp + sout};
+                    fx ? c->rq + (size_t)sout * HB_ND * c->ld : nullptr, c->mb + 1 + mbi, c->vexp + sout,
+                    c->layout == 2 ? c->X2 : nullptr, c->ld2 / 4};
 }
 
 struct phase_timer {
@@ -3100,7 +3163,24 @@ int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out)
 {
     HB_HIP(hipMemsetAsync(dev_out, 0, sizeof(double) * (size_t)c->ld, c->stream));
     const dim3 grid((unsigned)((c->ld / 4 + 255) / 256), (unsigned)((c->m_pad + 255) / 256));
-    hipLaunchKernelGGL(k_xalpha, grid, dim3(256), 0, c->stream, c->X, c->ld, c->m_pad, dev_alpha, dev_out);
+    hipLaunchKernelGGL(k_xalpha, grid, dim3(256), 0, c->stream, c->X, c->ld, c->layout == 2 ? c->X2 : nullptr, c->ld2 / 4, c->m_pad, dev_alpha, dev_out);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_pack2(hb_ctx *c)
+{
+    const int64_t ld2w = c->ld2 / 4;
+    hipLaunchKernelGGL(k_pack2, dim3((unsigned)((ld2w + 255) / 256), (unsigned)c->m_pad), dim3(256), 0, c->stream, c->X, c->ld, c->X2, ld2w, c->m_pad);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_unpack2(hb_ctx *c, int col0, int ncols, int8_t *dst)
+{
+    const int64_t ld2w = c->ld2 / 4;
+    hipLaunchKernelGGL(k_unpack2, dim3((unsigned)((c->ld / 16 + 255) / 256), (unsigned)ncols), dim3(256), 0, c->stream,
+                       c->X2 + (int64_t)col0 * ld2w, ld2w, dst, c->ld, ncols);
     HB_HIP(hipGetLastError());
     return HB_OK;
 }

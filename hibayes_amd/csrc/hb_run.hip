@@ -347,6 +347,12 @@ int hb_run::setup(const hb_bayes_args *args)
         rc = hb_ctx_build_gram(c, &gram_seconds);
         if (rc) return rc;
     }
+    if (a.genotype_bits == 2 && own_ctx) { // the Gram blocks (built from the int8 columns) are in place: pack, drop the int8 copy
+        rc = hb_ctx_set_layout(c, 2, 0);
+        if (rc) return rc;
+    } else if (a.genotype_bits != 0 && a.genotype_bits != 8 && a.genotype_bits != 2) {
+        return hb_fail(HB_ERR_INVALID, "hb_bayes_run: genotype_bits must be 0, 8 or 2");
+    }
     {   // geometry by regime: only from the wide-band geometry of the point-mass models, whose stored band serves the narrow one
         int32_t gp = 0, gl = 0, gd = 0, gb = 0;
         (void)hb_ctx_get_pipeline(c, &gp, &gl, &gd, &gb);

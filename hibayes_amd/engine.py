@@ -74,6 +74,15 @@ class Context:
         check(self.L.hb_ctx_marker_stats(self.h, xpx.ctypes.data, vx.ctypes.data, C.byref(s), C.byref(z)))
         return xpx, vx, s.value, z.value
 
+    def set_layout(self, bits=2, keep_int8=True):
+        """Resident genotype layout the sweep reads: 8 (int8 columns) or 2 (2 bits per genotype, a quarter of the bytes)."""
+        check(self.L.hb_ctx_set_layout(self.h, int(bits), 1 if keep_int8 else 0))
+
+    def layout(self):
+        b, k = C.c_int32(), C.c_int32()
+        check(self.L.hb_ctx_get_layout(self.h, C.byref(b), C.byref(k)))
+        return b.value, bool(k.value)
+
     def set_adaptive(self, on=True):
         """Let Bayes() choose the geometry of each sweep of a point-mass model from the number of moves of the previous one."""
         check(self.L.hb_ctx_set_adaptive(self.h, 1 if on else 0))

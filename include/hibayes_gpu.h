@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 3
+#define HB_ABI_VERSION 4
 #define HB_MAX_FOLD 8
 
 typedef enum {
@@ -147,6 +147,12 @@ typedef struct hb_bayes_args {
      * not see the other shards' moves; more exchanges = less of that staleness (and of the bias it causes where the shards'
      * markers are correlated), at one all-reduce and one pipeline drain each. Unsharded, the chain does not depend on it. */
     int32_t sync_blocks;
+    /* resident genotype layout of the sweep (ABI 4): 0 or 8 = int8 columns; 2 = 2 bits per genotype, PLINK's
+     * own density (reference src/read_bed.cpp:116-167), expanded to bytes in registers inside the mat-vec — a
+     * quarter of the bytes per sweep. Needs genotype codes 0..3 and the fixed-point mat-vec (precise = 2); same chain bit for bit
+     * (the dot products are exact integers either way). A context the run creates drops its int8 copy once the Gram blocks
+     * are built; with a pre-loaded ctx the layout is the context's (hb_ctx_set_layout). */
+    int32_t genotype_bits;
 } hb_bayes_args;
 
 /* number of doubles exchanged per sweep for n individuals: the residual delta (u moves by its negative) + 16 scalar sums */
@@ -248,6 +254,13 @@ int hb_ctx_upload_bed(hb_ctx *c, const uint8_t *bed, int64_t nbytes, int32_t nin
  * x ~ Binomial(2,p_j), every mono_every-th column forced monomorphic (0 = never) */
 int hb_ctx_generate_genotype(hb_ctx *c, uint64_t seed, int32_t mono_every);
 int hb_ctx_download_genotype(hb_ctx *c, int8_t *X, int64_t ld, int32_t col0, int32_t ncols);
+/* Resident layout the sweep's kernels read: bits = 8 (int8 columns) or 2 (2 bits per genotype: 16 individuals per 32-bit word,
+ * expanded in registers — hb_dotq2.hpp; codes must be 0..3). Packing happens on the device from the int8 columns. keep_int8 = 0
+ * frees the int8 copy afterwards (every kernel of the run — mat-vec, residual update, X*alpha, the GEBV sample matrix, genotype
+ * download — then reads the packed form; the Gram blocks must have been built for the widest geometry the run will use, a
+ * rebuild unpacks panel by panel into a scratch buffer). bits = 8 on a context that dropped its int8 copy unpacks it again. */
+int hb_ctx_set_layout(hb_ctx *c, int32_t bits, int32_t keep_int8);
+int hb_ctx_get_layout(const hb_ctx *c, int32_t *bits, int32_t *int8_resident);
 
 /* xpx_i = sum x^2, vx_i = var(x_i) (N-1), reference src/Bayes.cpp:310-317; integer-exact */
 int hb_ctx_marker_stats(hb_ctx *c, double *xpx, double *vx, double *sumvx, int32_t *nvar0);

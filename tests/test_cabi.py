@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_version_and_error_channel():
     lib = H.lib()
-    assert lib.hb_abi_version() == 3
+    assert lib.hb_abi_version() == 4
     assert b"gfx950" in lib.hb_version()
     assert lib.hb_device_count() >= 0
     assert lib.hb_exchange_count(50000) == 50016
@@ -38,17 +38,17 @@ def test_version_and_error_channel():
 
 def test_struct_layouts_match_the_header(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hibayes_gpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hibayes_gpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(hb_bayes_args),sizeof(hb_bayes_out),sizeof(hb_ctx_params),sizeof(hb_sweep_in),sizeof(hb_sweep_out),'
                    'sizeof(hb_sweep_timing),sizeof(hb_run_info),offsetof(hb_bayes_args,seed),offsetof(hb_bayes_args,ctx),'
-                   'offsetof(hb_bayes_out,alpha_sd));return 0;}\n')
+                   'offsetof(hb_bayes_out,alpha_sd),sizeof(hb_launch_stats),offsetof(hb_bayes_args,genotype_bits));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(_lib.BayesArgs), ctypes.sizeof(_lib.BayesOut), ctypes.sizeof(_lib.CtxParams),
             ctypes.sizeof(_lib.SweepIn), ctypes.sizeof(_lib.SweepOut), ctypes.sizeof(_lib.SweepTiming),
             ctypes.sizeof(_lib.RunInfo), _lib.BayesArgs.seed.offset, _lib.BayesArgs.ctx.offset,
-            _lib.BayesOut.alpha_sd.offset]
+            _lib.BayesOut.alpha_sd.offset, ctypes.sizeof(_lib.LaunchStats), _lib.BayesArgs.genotype_bits.offset]
     assert got == want
 
 

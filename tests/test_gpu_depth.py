@@ -94,6 +94,40 @@ def test_default_geometry_draw_for_draw_at_pipeline_depth(big, model, Pi, fold, 
         _compare(r2, ref)
 
 
+@pytest.mark.parametrize("model,Pi,fold,geo", CASES)
+@pytest.mark.parametrize("panel,mcols", [(512, 32768), (64, 4096)])
+def test_two_bit_resident_layout_is_the_same_chain(big, model, Pi, fold, geo, panel, mcols):
+    """genotype_bits = 2 (2 bits per genotype resident, expanded in registers: hb_dotq2.hpp; the format is PLINK's,
+    reference src/read_bed.cpp:116-167): the digit-plane dot products are the same exact integers as on int8 columns, so the
+    chain is the int8 chain BIT FOR BIT — and the oracle's draw for draw. Through the one-call boundary (the run packs and drops
+    its int8 copy after the Gram build) and through a context whose layout was switched by hand, from a cold and a dense start."""
+    X, y = big["X"][:, :mcols], big["y"]
+    if model == "BayesRR":
+        panel = 0 if panel == 512 else panel
+        X = X[:, :min(mcols, 8192)]
+    m = X.shape[1]
+    kw = dict(fold=fold, niter=6, nburn=0, thin=1, seed=1357)
+    ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, **kw)
+    r8 = H.Bayes(y, X, model, Pi, verbose=False, panel=panel, **kw)
+    r2 = H.Bayes(y, X, model, Pi, verbose=False, panel=panel, genotype_bits=2, **kw)
+    _compare(r2, ref)
+    for k in ("alpha", "pip", "g", "pi"):
+        assert np.array_equal(r2[k], r8[k]), k
+    np.testing.assert_allclose(r2["e"], r8["e"], rtol=0, atol=1e-10)   # (X * alpha sums its column blocks with atomics: last bits)
+    assert np.array_equal(r2["MCMCsamples"]["alpha"], r8["MCMCsamples"]["alpha"])
+    rng = np.random.default_rng(9 + m)
+    g0 = np.where(rng.random(m) < 0.3, rng.normal(0, 0.03, m), 0.0)
+    refd = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, g_init=g0, **kw)
+    with H.Context(X.shape[0], m, panel=panel, seed=1357) as c:
+        c.upload(X)
+        c.set_pipeline(*geo)
+        c.build_gram()
+        c.set_layout(2, keep_int8=False)
+        rd = H.Bayes(y, None, model, Pi, verbose=False, g_init=g0, ctx=c, **kw)
+        assert c.layout() == (2, False)
+    _compare(rd, refd)
+
+
 @pytest.mark.parametrize("panel,geo", [(64, (1, 2, 7)), (512, (1, 2, 7)), (128, (1, 2, 1)), (256, (1, 1, 8)), (64, (0, 3, 1))])
 def test_every_band_gram_block_exact(panel, geo):
     rng = np.random.default_rng(panel + geo[2])

@@ -264,3 +264,60 @@ def test_bigmemory_file_to_device_without_a_host_copy(tmp_path, demo):
     r = H.Bayes(demo["y"], sub, "BayesCpi", [0.95, 0.05], niter=20, nburn=10, thin=2, seed=3, verbose=False)
     r2 = H.Bayes(demo["y"], demo["M"], "BayesCpi", [0.95, 0.05], niter=20, nburn=10, thin=2, seed=3, verbose=False)
     assert np.array_equal(r["alpha"], r2["alpha"])
+
+
+def test_two_bit_layout_pack_unpack_dot_and_products():
+    """SURVEY §8 f1 (second half): genotypes resident at PLINK's density, 2 bits each (reference src/read_bed.cpp:116-167 is
+    the format; hb_dotq2.hpp the packed word). Packing on the device, dropping the int8 copy, unpacking (genotype download),
+    the fixed-point mat-vec and X * alpha must all give what the int8 layout gives — the dot products bit for bit: they are
+    exact integers either way (checked against a Python big-integer dot product)."""
+    rng = np.random.default_rng(22)
+    for n, m, panel in ((777, 300, 64), (1300, 1100, 128)):   # ld = 1024 (two stages of 512) and 1536 (an odd multiple of 256)
+        X = rand_geno(rng, n, m)
+        r = rng.normal(0, 3.0, n)
+        r[rng.integers(0, n, 5)] *= 1e6
+        with H.Context(n, m, panel=panel, precise=2) as c:
+            c.upload(X)
+            c.set_residual(r, np.zeros(n))
+            d8 = c.dot()
+            xpx8, vx8, sumvx8, nvar08 = c.marker_stats()
+            c.set_layout(2, keep_int8=True)
+            assert c.layout() == (2, True)
+            assert np.array_equal(c.dot(), d8)                # identical integers -> identical doubles
+            c.set_layout(2, keep_int8=False)
+            assert c.layout() == (2, False)
+            d2 = c.dot()
+            assert np.array_equal(d2, d8)
+            assert np.array_equal(c.download(), X)            # unpacked on the device
+            E = 53 - int(np.floor(np.log2(np.abs(r).max())))
+            q = np.rint(np.ldexp(r, E))
+            exact = np.array([int(v) for v in (X.astype(object).T @ q.astype(np.int64).astype(object))], dtype=object)
+            assert np.array_equal(d2, np.array([float(v) * 2.0 ** -E for v in exact]))
+            alpha = np.zeros(m)
+            alpha[rng.integers(0, m, 40)] = rng.normal(0, 1, 40)
+            xa = np.zeros(n)
+            H._lib.check(c.L.hb_ctx_matvec(c.h, alpha.ctypes.data, xa.ctypes.data))
+            np.testing.assert_allclose(xa, X.astype(np.float64) @ alpha, rtol=0, atol=1e-9)
+            A = np.zeros((m, 3))
+            A[rng.integers(0, m, 30), rng.integers(0, 3, 30)] = rng.normal(0, 1, 30)
+            np.testing.assert_allclose(c.matmul(A), X.astype(np.float64) @ A, rtol=0, atol=1e-9)
+            xpx2, vx2, sumvx2, nvar02 = c.marker_stats()      # computed before the int8 copy was dropped: still valid
+            assert np.array_equal(xpx2, xpx8) and np.array_equal(vx2, vx8) and nvar02 == nvar08
+            with pytest.raises(H.HibayesError, match="2-bit layout only"):
+                c.upload(X)
+            c.set_layout(8)                                   # back: the int8 copy is unpacked again
+            assert c.layout() == (8, True) and np.array_equal(c.download(), X) and np.array_equal(c.dot(), d8)
+
+
+def test_two_bit_layout_refuses_what_it_cannot_hold():
+    rng = np.random.default_rng(23)
+    X = rand_geno(rng, 300, 200, signed=True)               # -1 / 0 / 1 coding (README.md:55-59): int8 layout only
+    with H.Context(300, 200, panel=64, precise=2) as c:
+        c.upload(X)
+        with pytest.raises(H.HibayesError, match="codes 0..3"):
+            c.set_layout(2)
+        assert c.layout() == (8, True)
+    with H.Context(300, 200, panel=64, precise=1) as c:
+        c.upload(np.abs(X))
+        with pytest.raises(H.HibayesError, match="precise = 2"):
+            c.set_layout(2)
