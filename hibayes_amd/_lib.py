@@ -159,6 +159,8 @@ def lib():
     # split over two runtimes (a stream of one handed to the other: "unhandled cuda error" from RCCL). So where torch is
     # importable it is loaded first — this library, the RCCL it dlopen()s and torch's tensors (TorchComm's exchange buffer)
     # then all sit on the same runtime — and every symbol is bound at load time, not at first call.
+    # (HIBAYES_NO_TORCH=1 skips it for a single-GPU process that will never import torch: seconds of start-up. The order cannot be
+    # repaired later — a torch imported after this library brings the second runtime — hence the default.)
     if not os.environ.get("HIBAYES_NO_TORCH"):
         try:
             import torch  # noqa: F401

@@ -394,6 +394,11 @@ def ibrm(formula, data=None, M=None, M_id=None, method="BayesCpi", map=None, Pi=
     if (windsize is not None or windnum is not None) and windindx is None:
         if method in ("BayesA", "BayesRR", "BayesL"):
             raise ValueError("can not implement GWAS analysis for the method: " + method)
+        if comm is not None and comm.world > 1:
+            # window ids are GLOBAL in a sharded run (the shards' window counts are summed by id, reference src/Bayes.cpp:836-843):
+            # windows cut from this rank's part of the map would number 1..nw_local on every rank and be added up under the
+            # same ids. Cut them on the global map (cutwind_by_bp / cutwind_by_num) and pass this rank's slice as windindx.
+            raise ValueError("sharded run: pass windindx (window ids cut on the GLOBAL map, this rank's slice) instead of windsize / windnum")
         chrom, bp = _map_columns(map)          # R/bayes.r:216-246
         from .windows import cutwind_by_bp, cutwind_by_num
         if windnum is not None:

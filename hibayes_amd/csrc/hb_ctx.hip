@@ -125,6 +125,9 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char *e = getenv("HB_DOTQ2_CPL")) c->dotq2_cpl = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("HB_DOTQ2_TILES")) c->dotq2_tiles = std::max(1, atoi(e));
+    if (const char *e = getenv("HB_DOTQ2_KIND")) c->dotq2_kind = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("HB_DOTQ2_NC")) c->dotq2_nc = std::max(4, atoi(e) / 4 * 4);
+    if (const char *e = getenv("HB_DOTQ2_RS")) c->dotq2_rs = atoi(e) == 256 ? 256 : 512;
     if (const char *e = getenv("HB_CHAIN")) c->chain_kind = std::strcmp(e, "panel") == 0 ? 0 : 1;
     if (const char *e = getenv("HB_KAPPA")) c->kappa = atof(e);
     if (const char *e = getenv("HB_DOT_LDS")) c->dot_lds = std::min(65536, std::max(0, atoi(e)));
@@ -545,6 +548,7 @@ int hb_ctx_build_gram(hb_ctx *c, double *seconds)
         return rc;
     }
     c->Lg = c->L; // the band this build stores
+    c->graph_model = -1; // the captured sweeps hold the old band's stride (and, after a re-allocation, its pointer)
     const size_t need = (size_t)c->m_pad * (size_t)c->P * (size_t)(c->Lg + 1);
     if (need > c->gram_cap) {
         if (c->gram) { (void)hipFree(c->gram); c->gram = nullptr; }
@@ -882,15 +886,16 @@ int hb_ctx_blocks_setup(hb_ctx *c, const double *cpc, const double *zz, const do
     const int nb = c->nc + c->lev_total + 2 * c->nr;
     if (nb == 0) return HB_OK;
     HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->blk), sizeof(double) * nb));
-    HB_HIP(hipMemset(c->blk, 0, sizeof(double) * nb));
+    HB_HIP(hipMemsetAsync(c->blk, 0, sizeof(double) * nb, c->stream)); // (on the context's stream: a null-stream memset is not ordered before it)
     HB_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_blk), sizeof(double) * nb));
     std::memset(c->h_blk, 0, sizeof(double) * nb);
     if (c->lev_total) {
         HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->blk_zz), sizeof(double) * c->lev_total));
         HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->blk_z), sizeof(double) * c->lev_total));
         HB_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_z), sizeof(double) * c->lev_total));
-        HB_HIP(hipMemcpy(c->blk_zz, zz, sizeof(double) * c->lev_total, hipMemcpyHostToDevice));
-        HB_HIP(hipMemcpy(c->blk + c->nc + c->lev_total, vrtmp0, sizeof(double) * c->nr, hipMemcpyHostToDevice));
+        HB_HIP(hipMemcpyAsync(c->blk_zz, zz, sizeof(double) * c->lev_total, hipMemcpyHostToDevice, c->stream));
+        HB_HIP(hipMemcpyAsync(c->blk + c->nc + c->lev_total, vrtmp0, sizeof(double) * c->nr, hipMemcpyHostToDevice, c->stream));
+        HB_HIP(hipStreamSynchronize(c->stream)); // (the caller's arrays may be temporaries)
     }
     c->blk_n = nb;
     return HB_OK;
@@ -969,7 +974,7 @@ int hb_ctx_sweep_range(hb_ctx *c, const hb_sweep_in *in, int block, int nblocks)
 {
     if (!c) return hb_fail(HB_ERR_INVALID, "hb_ctx_sweep_range: null context");
     if (nblocks <= 1) return block == 0 ? hb_ctx_sweep_begin(c, in) : HB_OK;
-    if (!c->pipeline) return block == 0 ? hb_ctx_sweep_begin(c, in) : HB_OK;
+    if (!c->pipeline || c->profiling) return block == 0 ? hb_ctx_sweep_begin(c, in) : HB_OK; // (the HIP-event timing mode runs the whole sweep with the per-panel kernels)
     const int G = (c->npanels + c->D - 1) / c->D;
     const int nb = std::min(nblocks, G);
     if (block >= nb) return HB_OK;

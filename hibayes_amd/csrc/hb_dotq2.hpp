@@ -18,13 +18,21 @@
 // by LDS-DMA, double-buffered, counted vmcnt.
 #pragma once
 
-#define Q2_RS 512   /* individuals per stage */
-#define Q2_DP 4     /* digit pieces per stage */
+#ifndef Q2_DIAG
+#define Q2_DIAG 0 /* timing diagnostics only (wrong results): 1 = no atomics at the tile's end, 2 = no dot4 (loads + reduction only) */
+#endif
+#define Q2_RS 512   /* individuals per stage of the default shape (the padded column length is a multiple of it) */
 
-template <int CPL>
+// RS: individuals per stage (512 or 256). A 1-KiB DMA piece holds 4096 / RS columns x RS individuals of the tile, or 1024 / RS
+// digit planes x RS individuals.
+template <int CPL, int RS>
 __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
 {
-    constexpr int NXP = 8 * CPL, XB = NXP * HBQ_SLOT, BUF = XB + Q2_DP * 1024, PER = NXP + Q2_DP;
+    constexpr int XPC = 4096 / RS, LPC = 64 / XPC;          // columns per tile piece, lanes per column in it
+    constexpr int NXP = 64 * CPL / XPC;                      // tile pieces per stage
+    constexpr int PPP = 1024 / RS, LPP = RS / 16;            // planes per digit piece, lanes per plane in it
+    constexpr int NDP = (HB_ND + PPP - 1) / PPP;             // digit pieces per stage
+    constexpr int XB = NXP * HBQ_SLOT, BUF = XB + NDP * 1024, PER = NXP + NDP;
     const int lane = threadIdx.x;
     const int cg = b % v.ncg, sp = b / v.ncg;
     if (b == 0 && lane == 0) *v.gexp_out = *v.vexp_in;
@@ -32,9 +40,10 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
     if (st0 >= st1) return;
     const int64_t ld2 = v.ld2, ld = v.ld;
     const uint8_t *xg = v.X2 + (int64_t)cg * (64 * CPL) * ld2;
-    const unsigned voff = (unsigned)((lane >> 3) * ld2 + (lane & 7) * 16);   // piece i: columns 8 i .. 8 i + 7, 128 bytes each
-    const unsigned doff = (unsigned)((lane >> 5) * ld + (lane & 31) * 16);   // digit piece j < 3: planes 2 j, 2 j + 1
-    const unsigned doff3 = (unsigned)((lane & 31) * 16);                      // digit piece 3: plane 6 (twice)
+    const unsigned voff = (unsigned)((lane / LPC) * ld2 + (lane % LPC) * 16);   // piece i: columns XPC i .. XPC i + XPC - 1
+    unsigned doff[NDP];                                                          // digit piece j: planes PPP j .. (clamped to the last)
+#pragma unroll
+    for (int j = 0; j < NDP; j++) doff[j] = (unsigned)(min(j * PPP + lane / LPP, HB_ND - 1) * ld + (lane % LPP) * 16);
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
     int acc[CPL][HB_ND];
 #pragma unroll
@@ -48,14 +57,13 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
                                                             (unsigned)__builtin_amdgcn_readfirstlane((int)u)));
     };
     auto issue = [&](int st, int buf) {
-        const int8_t *xs = uni_p(reinterpret_cast<const int8_t *>(xg) + (int64_t)st * (Q2_RS / 4));
-        const int8_t *ds = uni_p(v.rq + (int64_t)st * Q2_RS);
+        const int8_t *xs = uni_p(reinterpret_cast<const int8_t *>(xg) + (int64_t)st * (RS / 4));
+        const int8_t *ds = uni_p(v.rq + (int64_t)st * RS);
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)buf * BUF));
 #pragma unroll
-        for (int i = 0; i < NXP; i++) hbq_dma16<true>(voff, xs + (int64_t)(8 * i) * ld2, dst + i * HBQ_SLOT);
+        for (int i = 0; i < NXP; i++) hbq_dma16<true>(voff, xs + (int64_t)(XPC * i) * ld2, dst + i * HBQ_SLOT);
 #pragma unroll
-        for (int j = 0; j < 3; j++) hbq_dma16<false>(doff, ds + (int64_t)(2 * j) * ld, dst + XB + j * 1024);
-        hbq_dma16<false>(doff3, ds + (int64_t)6 * ld, dst + XB + 3 * 1024);
+        for (int j = 0; j < NDP; j++) hbq_dma16<false>(doff[j], ds, dst + XB + j * 1024);
     };
     issue(st0, 0);
     int buf = 0;
@@ -69,30 +77,44 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
         const char *bp = smem + buf * BUF;
         const hb_v4i *px[CPL];
 #pragma unroll
-        for (int c = 0; c < CPL; c++) px[c] = reinterpret_cast<const hb_v4i *>(bp + ((lane >> 3) + 8 * c) * HBQ_SLOT + (lane & 7) * (Q2_RS / 4));
+        for (int c = 0; c < CPL; c++) px[c] = reinterpret_cast<const hb_v4i *>(bp + (lane / XPC + (64 / XPC) * c) * HBQ_SLOT + (lane % XPC) * (RS / 4));
         const char *pd = bp + XB;
-#pragma unroll 2
-        for (int s = 0; s < Q2_RS / 64; s++) { // 64 individuals per 16-byte read of a column
-            hb_v4i x[CPL];
+        // software-pipelined by hand: the seven digit reads of chunk ch + 1 (and the column's next 16 bytes) are issued BEFORE
+        // the 28 dot4 of chunk ch — a wave parks 78 % of its cycles otherwise (rocprofv3 SQ_WAIT_ANY), every chunk waiting out
+        // its own LDS round trip behind the other waves' reads
+        hb_v4i dn[HB_ND], xq[CPL], xqn[CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; c++) x[c] = px[c][s];
+        for (int k = 0; k < HB_ND; k++) dn[k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS);
 #pragma unroll
-            for (int w = 0; w < 4; w++) { // 16 individuals per word
-                hb_v4i d[HB_ND];
+        for (int c = 0; c < CPL; c++) xqn[c] = px[c][0];
+#pragma unroll 4
+        for (int ch = 0; ch < RS / 16; ch++) { // 16 individuals per chunk; four chunks per 16-byte read of a column
+            hb_v4i d[HB_ND];
 #pragma unroll
-                for (int k = 0; k < HB_ND; k++) d[k] = *reinterpret_cast<const hb_v4i *>(pd + k * Q2_RS + (s * 4 + w) * 16);
+            for (int k = 0; k < HB_ND; k++) d[k] = dn[k];
+            const int w = ch & 3;
+            if (w == 0) {
 #pragma unroll
-                for (int c = 0; c < CPL; c++) {
-                    const unsigned xw = (unsigned)(w == 0 ? x[c].x : w == 1 ? x[c].y : w == 2 ? x[c].z : x[c].w);
-                    const int m0 = (int)(xw & 0x03030303u), m1 = (int)((xw >> 2) & 0x03030303u), m2 = (int)((xw >> 4) & 0x03030303u),
-                              m3 = (int)((xw >> 6) & 0x03030303u);
+                for (int c = 0; c < CPL; c++) xq[c] = xqn[c];
+            }
+            const int chn = min(ch + 1, RS / 16 - 1);
 #pragma unroll
-                    for (int k = 0; k < HB_ND; k++) {
-                        acc[c][k] = __builtin_amdgcn_sdot4(m0, d[k].x, acc[c][k], false);
-                        acc[c][k] = __builtin_amdgcn_sdot4(m1, d[k].y, acc[c][k], false);
-                        acc[c][k] = __builtin_amdgcn_sdot4(m2, d[k].z, acc[c][k], false);
-                        acc[c][k] = __builtin_amdgcn_sdot4(m3, d[k].w, acc[c][k], false);
-                    }
+            for (int k = 0; k < HB_ND; k++) dn[k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS + chn * 16);
+            if (w == 3) {
+#pragma unroll
+                for (int c = 0; c < CPL; c++) xqn[c] = px[c][min((ch >> 2) + 1, RS / 64 - 1)];
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const unsigned xw = (unsigned)(w == 0 ? xq[c].x : w == 1 ? xq[c].y : w == 2 ? xq[c].z : xq[c].w);
+                const int m0 = (int)(xw & 0x03030303u), m1 = (int)((xw >> 2) & 0x03030303u), m2 = (int)((xw >> 4) & 0x03030303u),
+                          m3 = (int)((xw >> 6) & 0x03030303u);
+#pragma unroll
+                for (int k = 0; k < HB_ND; k++) {
+                    acc[c][k] = __builtin_amdgcn_sdot4(m0, d[k].x, acc[c][k], false);
+                    acc[c][k] = __builtin_amdgcn_sdot4(m1, d[k].y, acc[c][k], false);
+                    acc[c][k] = __builtin_amdgcn_sdot4(m2, d[k].z, acc[c][k], false);
+                    acc[c][k] = __builtin_amdgcn_sdot4(m3, d[k].w, acc[c][k], false);
                 }
             }
         }
@@ -106,7 +128,7 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
                                    __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int CPL>
+template <int CPL, int RS>
 __global__ __launch_bounds__(64) void k_dotq2(dq_view v, upd_view uq)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -119,7 +141,137 @@ __global__ __launch_bounds__(64) void k_dotq2(dq_view v, upd_view uq)
         const int col = (b - v.nupd) * 64 + threadIdx.x;
         if (col < v.fin_ncols) hbq_finalize(v.fin_acc, v.accstride, col, *v.fin_exp, v.fin_out);
     } else {
-        dotq2_tile<CPL>(v, smem, b - v.nupd - v.nfin);
+        dotq2_tile<CPL, RS>(v, smem, b - v.nupd - v.nfin);
+    }
+    if (v.stamp && threadIdx.x == 0) {
+        v.stamp[2 * (size_t)blockIdx.x] = t0;
+        v.stamp[2 * (size_t)blockIdx.x + 1] = wall_clock64();
+    }
+}
+static constexpr int q2_lds(int cpl, int rs) { return 2 * ((64 * cpl / (4096 / rs)) * HBQ_SLOT + ((HB_ND + 1024 / rs - 1) / (1024 / rs)) * 1024); }
+
+// ---------------------------------------------------------------------------------------------
+// k_dotq2r: the same product with the INDIVIDUALS across the lanes and no LDS at all.
+// The lane = column tile above spends its time parked: seven wave-uniform (broadcast) LDS reads per 16 individuals, each a
+// queue behind every other wave's, then 28 v_dot4 (4 cycles each on gfx950, measured: tools/dot4_rate.hip) — 78 % of the wave
+// cycles wait (rocprofv3 --pmc SQ_WAIT_ANY / SQ_WAVE_CYCLES), and the LDS budget of the double-buffered tile caps the waves that
+// could hide it. Here a lane owns 64 consecutive individuals of a 4096-individual row block: their 7 x 64 digit bytes live in
+// 112 registers for the whole tile (distinct per lane: nothing is broadcast), a column is ONE coalesced 1-KiB global load per
+// wave (16 bytes = 64 individuals per lane, four columns in flight ahead), and the work between two waits is 4 x (16 mask
+// operations + 112 v_dot4). What it costs is a cross-lane reduction: 28 sums (4 columns x 7 planes) per batch, folded by a
+// halving butterfly (31 exchanges) so that lane v ends up with the total of sum v — about a fifth on top of the dot4 stream.
+// Integer sums are order-independent: the results are the same exact integers as k_dotq's and k_dotq2's.
+// ---------------------------------------------------------------------------------------------
+#define Q2R_RB 4096 /* individuals per row block (64 lanes x 64) */
+#define Q2R_CB 4    /* columns per batch */
+#ifndef Q2R_PF
+#define Q2R_PF 2    /* batches requested ahead */
+#endif
+
+__device__ __forceinline__ void dotq2r_tile(const dq_view &v, int b)
+{
+    const int lane = threadIdx.x;
+    const int cgi = b % v.ncg, rb = b / v.ncg; // column group (v.NS columns each), row block
+    if (b == 0 && lane == 0) *v.gexp_out = *v.vexp_in;
+    const int64_t ld2 = v.ld2, ld = v.ld;
+    const int NC = v.NS;
+    const int64_t rowbyte = (int64_t)rb * (Q2R_RB / 4) + lane * 16; // this lane's 16 bytes inside a packed column
+    const bool valid = rowbyte < ld2;
+    const uint8_t *xcol = v.X2 + (int64_t)cgi * NC * ld2 + (valid ? rowbyte : 0);
+    // the lane's digits: plane p, dword q = individuals 4 q .. 4 q + 3 of its 64 (past the column's end: whatever is there,
+    // the genotypes are zero)
+    int dig[HB_ND][16];
+    {
+        const int64_t r0 = min((int64_t)rb * Q2R_RB + lane * 64, ld - 64);
+#pragma unroll
+        for (int p = 0; p < HB_ND; p++) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                const hb_v4i t = *reinterpret_cast<const hb_v4i *>(v.rq + (int64_t)p * ld + r0 + q4 * 16);
+                dig[p][4 * q4] = t.x; dig[p][4 * q4 + 1] = t.y; dig[p][4 * q4 + 2] = t.z; dig[p][4 * q4 + 3] = t.w;
+            }
+        }
+    }
+    // columns in flight: Q2R_PF batches of Q2R_CB ahead of the one being computed (a load takes ~2 us beside the other
+    // waves' streams, a batch computes in ~1 us: one batch ahead leaves every batch waiting)
+    hb_v4i xr[Q2R_PF + 1][Q2R_CB];
+    auto fetch = [&](int slot, int cfirst) {
+#pragma unroll
+        for (int c = 0; c < Q2R_CB; c++)
+            xr[slot][c] = __builtin_nontemporal_load(reinterpret_cast<const hb_v4i *>(xcol + (int64_t)min(cfirst + c, NC - 1) * ld2));
+    };
+#pragma unroll
+    for (int f = 0; f < Q2R_PF; f++) fetch(f, f * Q2R_CB);
+    // (the ring is indexed statically: the batch loop is unrolled Q2R_PF + 1 times)
+    for (int cbase = 0; cbase < NC; cbase += (Q2R_PF + 1) * Q2R_CB) {
+#pragma unroll
+      for (int u = 0; u <= Q2R_PF; u++) {
+        const int c0 = cbase + u * Q2R_CB;
+        if (c0 >= NC) break;
+        fetch((u + Q2R_PF) % (Q2R_PF + 1), c0 + Q2R_PF * Q2R_CB); // (past the tile's end: the last column again, unused)
+        hb_v4i x[Q2R_CB];
+#pragma unroll
+        for (int c = 0; c < Q2R_CB; c++) x[c] = xr[u][c];
+        int a[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) a[i] = 0;
+#pragma unroll
+        for (int c = 0; c < Q2R_CB; c++) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                unsigned xw = (unsigned)(w == 0 ? x[c].x : w == 1 ? x[c].y : w == 2 ? x[c].z : x[c].w);
+                xw = valid ? xw : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int m = (int)((xw >> (2 * k)) & 0x03030303u);
+#pragma unroll
+                    for (int p = 0; p < HB_ND; p++) {
+                        if (Q2_DIAG == 2) { if (p == 0 && k == 0) a[c * 8 + p] += m ^ dig[p][4 * w + k]; }
+                        else a[c * 8 + p] = __builtin_amdgcn_sdot4(m, dig[p][4 * w + k], a[c * 8 + p], false);
+                    }
+                }
+            }
+        }
+        // halving butterfly: after the step with lane bit s the lanes with that bit clear hold the lower half of the sums,
+        // the others the upper half, each added up over the pair
+        int n = 16;
+#pragma unroll
+        for (int s = 32; s >= 2; s >>= 1) {
+            const bool up = (lane & s) != 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (i < n) {
+                    const int lo = a[i], hi = a[i + n];
+                    const int send = up ? lo : hi, keep = up ? hi : lo;
+                    a[i] = keep + __shfl_xor(send, s, 64);
+                }
+            }
+            n >>= 1;
+        }
+        const int tot = a[0] + __shfl_xor(a[0], 1, 64);
+        // which sum this lane holds: bit 32 of the lane picked the upper 16, bit 16 the upper 8, ... bit 2 the upper 1
+        const int vi = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        const int cc = vi >> 3, pp = vi & 7;
+        if (Q2_DIAG == 1) { if (tot == 0x12345678) v.accq[0] = tot; } else
+        if (!(lane & 1) && pp < HB_ND)
+            __hip_atomic_fetch_add(v.accq + (int64_t)pp * v.accstride + cgi * NC + c0 + cc, (long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dotq2r(dq_view v, upd_view uq)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2048 + 4096 + 16]; // the update rows' move lists
+    unsigned long long t0 = 0;
+    if (v.stamp) t0 = wall_clock64();
+    int b = blockIdx.x;
+    if (b < v.nupd) {
+        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096));
+    } else if (b < v.nupd + v.nfin) {
+        const int col = (b - v.nupd) * 64 + threadIdx.x;
+        if (col < v.fin_ncols) hbq_finalize(v.fin_acc, v.accstride, col, *v.fin_exp, v.fin_out);
+    } else {
+        dotq2r_tile(v, b - v.nupd - v.nfin);
     }
     if (v.stamp && threadIdx.x == 0) {
         v.stamp[2 * (size_t)blockIdx.x] = t0;

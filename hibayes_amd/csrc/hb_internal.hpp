@@ -19,7 +19,7 @@ int hb_fail(int status, const std::string &msg);
 
 // layout of the per-sweep scalar block the kernels accumulate into / the host reads back
 #define HB_ND 7 /* int8 digits of the fixed-point residual: 55 bits + sign */
-#define HB_LSTAMP_BLOCKS 2048
+#define HB_LSTAMP_BLOCKS 4608
 
 enum {
     HB_ACC_SUMG2 = 0,
@@ -64,7 +64,8 @@ struct hb_ctx {
     uint32_t *X2 = nullptr;
     int64_t ld2 = 0;     // bytes per column of X2 = 128 * ceil(ld / 512)
     int layout = 8;      // 8: int8 columns, 2: 2-bit columns
-    int dotq2_cpl = 2, dotq2_tiles = 512; // k_dotq2 launch shape (HB_DOTQ2_CPL, HB_DOTQ2_TILES)
+    int dotq2_cpl = 1, dotq2_tiles = 3072, dotq2_rs = 256;
+    int dotq2_kind = 0, dotq2_nc = 16;    // (measured: 23.3 us per 3584-column launch for kind 0 at these defaults, 26.1 for kind 1) 1: individuals across the lanes, no LDS (k_dotq2r), NC columns per tile; 0: lane = column through LDS (k_dotq2) // k_dotq2 launch shape (HB_DOTQ2_CPL, HB_DOTQ2_TILES)
     double *xpx = nullptr, *vx = nullptr, *g = nullptr, *vargL = nullptr;
     double *alpha_sum = nullptr, *alpha_sq = nullptr;
     uint8_t *tracker = nullptr;

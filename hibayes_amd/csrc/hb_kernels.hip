@@ -556,12 +556,12 @@ __global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
 // Sweep start of the fixed-point path: max |yadj| -> mb[0] and the exponent of slot 0, then slot 0's digit planes.
 // One workgroup (n is a few hundred KB).
 __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, unsigned *__restrict__ flags, int32_t *__restrict__ ev_count,
-                                                    int np, unsigned long long *__restrict__ dsum, int m_pad)
+                                                    int np, unsigned long long *__restrict__ dsum, int m_pad, int p_lo)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (acc && i < HB_ACC_N) acc[i] = 0.0; // (null: a later range of the same sweep keeps the sums)
     if (i < HB_NFLAGS && (acc || i != HB_FLAG_ABORT)) flags[i] = 0u; // (a later range keeps an abort raised by an earlier one)
-    for (int k = i; k < np; k += stride) ev_count[k] = 0;
+    for (int k = p_lo + i; k < np; k += stride) ev_count[k] = 0; // (panels of this range on: an earlier range's move lists stay readable)
     for (int k = i; k < m_pad; k += stride) dsum[k] = ~0ull;
 }
 
@@ -2533,8 +2533,45 @@ static void dotq_geometry(const hb_ctx *c, int ncols, int *ncg, int *NS, int *ns
 static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st, int gidx, const upd_view *upd, int fin_col0,
                          int fin_ncols, int fin_gidx)
 {
+    if (c->dotq2_kind == 1) { // rows across the lanes, no LDS (k_dotq2r): tiles = row blocks x groups of NC columns
+        int NC = c->dotq2_nc;
+        while (NC > Q2R_CB && ncols % NC) NC -= Q2R_CB;
+        if (ncols % NC == 0 && NC % Q2R_CB == 0 && c->ld >= 64) {
+            upd_view uq{};
+            if (upd) uq = *upd;
+            dq_view v{};
+            v.X = nullptr;
+            v.X2 = reinterpret_cast<const uint8_t *>(c->X2) + (int64_t)col0 * c->ld2;
+            v.ld2 = c->ld2;
+            v.ld = c->ld;
+            v.rq = c->rq + (size_t)slot * HB_ND * c->ld;
+            v.vexp_in = c->vexp + slot;
+            v.gexp_out = c->gexp + gidx;
+            v.accq = c->accq + col0;
+            v.accstride = c->m_pad;
+            v.NS = NC;
+            v.ncg = ncols / NC;
+            v.nstages = (int)((c->ld2 * 4 + Q2R_RB - 1) / Q2R_RB);
+            v.nupd = (uq.p1 > uq.p0) ? (int)(c->ld / 256) : 0;
+            v.nfin = fin_ncols > 0 ? (fin_ncols + 63) / 64 : 0;
+            v.fin_acc = c->accq + fin_col0;
+            v.fin_out = c->dsum + fin_col0;
+            v.fin_exp = c->gexp + fin_gidx;
+            v.fin_ncols = fin_ncols;
+            const int nblk = v.nupd + v.nfin + v.ncg * v.nstages;
+            v.stamp = nullptr;
+            if (c->lstamp && gidx >= 0 && gidx <= c->npanels && nblk <= HB_LSTAMP_BLOCKS) {
+                v.stamp = c->lstamp + (size_t)gidx * HB_LSTAMP_BLOCKS * 2;
+                c->lstamp_nblk[gidx] = nblk;
+                c->lstamp_cols[gidx] = ncols;
+            }
+            hipLaunchKernelGGL(k_dotq2r, dim3(nblk), dim3(64), 0, st, v, uq);
+            return;
+        }
+    }
     int cpl = (ncols % 128 == 0) ? c->dotq2_cpl : 1;
-    const int nst = (int)((c->ld + Q2_RS - 1) / Q2_RS);
+    const int RS = c->dotq2_rs;
+    const int nst = (int)((c->ld + RS - 1) / RS);
     const int ncg = ncols / (64 * cpl);
     const int ns = std::max(1, std::min(nst, (int)((double)c->dotq2_tiles / ncg + 0.5)));
     const int NS = (nst + ns - 1) / ns, nsplit = (nst + NS - 1) / NS;
@@ -2566,8 +2603,11 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
         c->lstamp_nblk[gidx] = nblk;
         c->lstamp_cols[gidx] = ncols;
     }
-    if (cpl == 2) hipLaunchKernelGGL((k_dotq2<2>), dim3(nblk), dim3(64), 2 * (16 * HBQ_SLOT + Q2_DP * 1024), st, v, uq);
-    else hipLaunchKernelGGL((k_dotq2<1>), dim3(nblk), dim3(64), 2 * (8 * HBQ_SLOT + Q2_DP * 1024), st, v, uq);
+    // (the update rows stage their lists in the tile buffers: 6152 bytes, below the smallest shape's 12416)
+    if (cpl == 2 && RS == 512) hipLaunchKernelGGL((k_dotq2<2, 512>), dim3(nblk), dim3(64), q2_lds(2, 512), st, v, uq);
+    else if (cpl == 2) hipLaunchKernelGGL((k_dotq2<2, 256>), dim3(nblk), dim3(64), q2_lds(2, 256), st, v, uq);
+    else if (RS == 512) hipLaunchKernelGGL((k_dotq2<1, 512>), dim3(nblk), dim3(64), q2_lds(1, 512), st, v, uq);
+    else hipLaunchKernelGGL((k_dotq2<1, 256>), dim3(nblk), dim3(64), q2_lds(1, 256), st, v, uq);
 }
 
 static void launch_dotq(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st, int gidx, const upd_view *upd, int fin_col0,
@@ -2846,7 +2886,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // first mat-vec launch (it needs a compute unit with all of its LDS free, and back-to-back mat-vec launches never leave
     // one), so both branches start together after the join.
     hipLaunchKernelGGL(k_sweep_init, dim3(256), dim3(256), 0, sA, first ? c->acc : nullptr, c->flags, c->ev_count, c->npanels,
-                       reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad);
+                       reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad, pb);
     const bool fx = c->precise == 2;
     if (fx) {
         HB_HIP(hipEventRecord(c->ev_dot[0], sA));

@@ -78,6 +78,7 @@ struct hb_run {
     int nvar0 = 0, nw = 0, n_levels = 0;
     std::vector<double> beta, cpc, beta_sum, vr, vrtmp, vr_sum, zz, estR, estR_sum, vara_fold, fold_snp_num, pi_sum;
     std::vector<int32_t> zid, nlev, lev_first;
+    std::vector<int> cls_of; // device class index -> the caller's (BayesR with an unsorted `fold`)
     double dfr = -1, s2r = 0, dfvara_ = 4, vara_ = 0, vare_ = 0, dfvare_ = -2, s2vara_ = 0, varg = 0, s2varg_ = 0,
            s2vare_ = 0, lambda2 = 0, lambda = 0, shape0 = 1.1, rate0 = 0, mu = 0;
     double sum_r = 0, sum_r2 = 0;
@@ -273,10 +274,18 @@ int hb_run::setup(const hb_bayes_args *args)
     dfvara_ = a.has_dfvg ? a.dfvg : 4; // :319-326
     if (dfvara_ <= 2) return hb_fail(HB_ERR_INVALID, "dfvg should not be less than 2.");
     if (niter < nburn) return hb_fail(HB_ERR_INVALID, "Number of total iteration ('niter') shold be larger than burn-in ('nburn').");
-    if (model_index == 6)
+    // BayesR: the device evaluates the class boundaries as nested thresholds on q = rhs^2, which needs the non-null classes in
+    // order of increasing variance. The reference takes `fold` in any order (src/Bayes.cpp:743-815): the classes are sorted here
+    // and every per-class quantity that crosses the device boundary goes through cls_of[] (internal -> caller's index); draws,
+    // Pi, counts and the returned pi stay in the caller's order. Class 0 is the null class whatever fold[0] says (:759).
+    cls_of.resize(n_fold);
+    for (int k = 0; k < n_fold; k++) cls_of[k] = k;
+    if (model_index == 6) {
+        std::stable_sort(cls_of.begin() + 1, cls_of.end(), [&](int x, int z) { return fold_[x] < fold_[z]; });
         for (int k = 2; k < n_fold; k++)
-            if (!(fold_[k] > fold_[k - 1]))
-                return hb_fail(HB_ERR_UNSUPPORTED, "BayesR on the GPU path needs 'fold' in strictly increasing order");
+            if (!(fold_[cls_of[k]] > fold_[cls_of[k - 1]]))
+                return hb_fail(HB_ERR_UNSUPPORTED, "BayesR on the GPU path needs distinct 'fold' values for the non-null classes");
+    }
     if (a.windindx) wind.assign(a.windindx, a.windindx + m);
     if (a.g_init) {
         g_init.assign(a.g_init, a.g_init + m);
@@ -454,6 +463,10 @@ int hb_run::setup(const hb_bayes_args *args)
             if (rc) return rc;
             rc = hb_ctx_matvec(c, g_init.data(), zero.data()); // u = X g
             if (rc) return rc;
+            if (sharded) { // every rank starts from the residual of ALL shards' effects (u and yadj are replicated)
+                rc = allreduce_host(zero.data(), n);
+                if (rc) return rc;
+            }
             for (int i = 0; i < n; i++) yadj[i] -= zero[i];
         }
         rc = hb_ctx_set_residual(c, yadj.data(), zero.data());
@@ -520,9 +533,9 @@ int hb_run::step()
     in.s2varg_df = s2varg_ * dfvara_;
     in.dfvara = dfvara_;
     for (int j = 0; j < n_fold; j++) {
-        in.logpi[j] = std::log(Pi[j]);
-        in.fold[j] = fold_[j];
-        in.vara_fold[j] = vara_fold[j];
+        in.logpi[j] = std::log(Pi[cls_of[j]]);
+        in.fold[j] = fold_[cls_of[j]];
+        in.vara_fold[j] = vara_fold[cls_of[j]];
     }
     in.lambda = lambda;
     in.lambda2 = lambda2;
@@ -621,7 +634,7 @@ int hb_run::step()
     }
     case 6: { // :803-814
         double nz = 0;
-        for (int j = 0; j < n_fold; j++) fold_snp_num[j] = so.class_count[j];
+        for (int j = 0; j < n_fold; j++) fold_snp_num[cls_of[j]] = so.class_count[j];
         for (int j = 1; j < n_fold; j++) nz += fold_snp_num[j];
         NnzSnp = (long long)nz;
         varg = (so.sum_g2 + s2varg_ * dfvara_) / hs.chisq(dfvara_ + (double)NnzSnp);

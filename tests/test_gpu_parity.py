@@ -114,7 +114,7 @@ def test_error_texts_through_the_c_abi(demo):
         (dict(Pi=[0.95, 0.05], dfvg=2.0), "dfvg should not be less than 2.", 1),
         (dict(Pi=[0.95, 0.05], niter=5, nburn=10), "Number of total iteration ('niter') shold be larger than burn-in ('nburn').", 1),
         (dict(model="BSLMM", Pi=[0.95, 0.05]), "BSLMM (Ki/Kival) is not part of the GPU path", 4),
-        (dict(model="BayesR", Pi=[0.9, 0.05, 0.05], fold=[0, 1e-2, 1e-3]), "BayesR on the GPU path needs 'fold' in strictly increasing order", 4),
+        (dict(model="BayesR", Pi=[0.9, 0.05, 0.05], fold=[0, 1e-2, 1e-2]), "BayesR on the GPU path needs distinct 'fold' values for the non-null classes", 4),
     ]
     for kw, msg, status in cases:
         a = dict(model="BayesCpi", niter=4, nburn=2, thin=1, verbose=False)
@@ -245,6 +245,25 @@ def test_bayesr_class_counts_draw_for_draw_against_the_oracle(K):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(r["pi"], ref["pi"], rtol=1e-9, atol=1e-14)
         np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"], r["mu"]], [ref["Vg"], ref["Ve"], ref["h2"], ref["mu"]], rtol=1e-9)
+
+
+def test_bayesr_fold_in_any_order_draw_for_draw_against_the_oracle():
+    """The reference takes `fold` in any order (src/Bayes.cpp:748-781: the class is picked by a cumulative walk over the classes as
+    given). The device needs the non-null classes by increasing variance for its nested thresholds: hb_run sorts them and maps
+    every per-class quantity back, so Pi, the class counts behind the Dirichlet draw and the returned pi stay in the caller's order."""
+    g = np.load(os.path.join(G, "small_all_models_philox.npz"))
+    for Pi, fold in (([0.9375, 0.015625, 0.03125, 0.015625], [0, 1e-2, 1e-3, 1e-4]), ([0.875, 0.0625, 0.03125, 0.03125], [0, 1e-3, 1e-2, 1e-4])):
+        kw = dict(fold=fold, niter=16, nburn=6, thin=2, seed=424242)
+        ref = O.bayes(g["y"], g["X"], "BayesR", Pi, rng=O.RNG_PHILOX, store_alpha=True, **kw)
+        for panel in (64, 512):
+            r = H.Bayes(g["y"], g["X"], "BayesR", Pi, verbose=False, panel=panel, **kw)
+            a, b = r["MCMCsamples"]["alpha"], ref["s_alpha"]
+            assert np.array_equal(a != 0, b != 0)
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(r["pi"], ref["pi"], rtol=1e-9, atol=1e-14)
+            np.testing.assert_allclose(r["MCMCsamples"]["pi"], ref["s_pi"], rtol=1e-9, atol=1e-14)
+            np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"], r["mu"]], [ref["Vg"], ref["Ve"], ref["h2"], ref["mu"]], rtol=1e-9)
+            np.testing.assert_allclose(r["pip"], ref["pip"], rtol=0, atol=1e-12)
 
 
 @pytest.mark.parametrize("n,m", [(37, 5), (257, 65), (64, 513)])

@@ -14,6 +14,10 @@ with H.Context(n, m, precise=precise, seed=1) as c:
     c.generate(20240901, 1000)
     c.marker_stats()
     c.set_pipeline(1, 2, 7)
+    bits = int(os.environ.get("HB_MV_BITS", "8"))
+    if bits == 2:
+        c.set_layout(2, keep_int8=False)
     c.set_residual(np.random.default_rng(0).normal(size=n), np.zeros(n))
     ms, nl, nc = c.time_matvec(reps=reps)
-    print("precise=%d: %d launches of %d columns, %.2f us per launch, %.3f TB/s" % (precise, nl, nc, ms * 1e3, n * nc / (ms * 1e-3) / 1e12))
+    print("precise=%d bits=%d: %d launches of %d columns, %.2f us per launch, %.3f TB/s of resident bytes (%.3f at one byte per genotype)" % (
+        precise, bits, nl, nc, ms * 1e3, n * nc * bits / 8 / (ms * 1e-3) / 1e12, n * nc / (ms * 1e-3) / 1e12))
