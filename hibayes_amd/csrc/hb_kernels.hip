@@ -2573,7 +2573,8 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     const int RS = c->dotq2_rs;
     const int nst = (int)((c->ld + RS - 1) / RS);
     const int ncg = ncols / (64 * cpl);
-    const int ns = std::max(1, std::min(nst, (int)((double)c->dotq2_tiles / ncg + 0.5)));
+    // (a tile is at least four stages: its first stage's load latency and its closing atomics are paid per tile)
+    const int ns = std::max(1, std::min(std::max(1, nst / 4), (int)((double)c->dotq2_tiles / ncg + 0.5)));
     const int NS = (nst + ns - 1) / ns, nsplit = (nst + NS - 1) / NS;
     upd_view uq{};
     if (upd) uq = *upd;

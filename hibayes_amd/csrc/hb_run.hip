@@ -275,15 +275,21 @@ int hb_run::setup(const hb_bayes_args *args)
     if (dfvara_ <= 2) return hb_fail(HB_ERR_INVALID, "dfvg should not be less than 2.");
     if (niter < nburn) return hb_fail(HB_ERR_INVALID, "Number of total iteration ('niter') shold be larger than burn-in ('nburn').");
     // BayesR: the device evaluates the class boundaries as nested thresholds on q = rhs^2, which needs the non-null classes in
-    // order of increasing variance. The reference takes `fold` in any order (src/Bayes.cpp:743-815): the classes are sorted here
-    // and every per-class quantity that crosses the device boundary goes through cls_of[] (internal -> caller's index); draws,
-    // Pi, counts and the returned pi stay in the caller's order. Class 0 is the null class whatever fold[0] says (:759).
+    // order of increasing variance (P(class <= c | q) is then decreasing in q for every c). The reference takes `fold` in any
+    // order (src/Bayes.cpp:743-815) and walks the classes as given (:773-781) — with another order the same uniform picks another
+    // class, so no formulation can be that walk draw for draw AND monotone. The run is therefore the reference's chain for the
+    // classes SORTED by fold (the same posterior: the mixture does not depend on how its components are numbered); cls_of[]
+    // maps the internal class index back to the caller's for everything reported: pi, MCMCsamples$pi, the progress line.
     cls_of.resize(n_fold);
     for (int k = 0; k < n_fold; k++) cls_of[k] = k;
     if (model_index == 6) {
-        std::stable_sort(cls_of.begin() + 1, cls_of.end(), [&](int x, int z) { return fold_[x] < fold_[z]; });
+        std::stable_sort(cls_of.begin() + 1, cls_of.end(), [&](int x, int z) { return fold_[x] < fold_[z]; }); // class 0 is the null class (:759)
+        std::vector<double> f2(n_fold), p2(n_fold);
+        for (int k = 0; k < n_fold; k++) { f2[k] = fold_[cls_of[k]]; p2[k] = Pi[cls_of[k]]; }
+        fold_ = f2;
+        Pi = p2;
         for (int k = 2; k < n_fold; k++)
-            if (!(fold_[cls_of[k]] > fold_[cls_of[k - 1]]))
+            if (!(fold_[k] > fold_[k - 1]))
                 return hb_fail(HB_ERR_UNSUPPORTED, "BayesR on the GPU path needs distinct 'fold' values for the non-null classes");
     }
     if (a.windindx) wind.assign(a.windindx, a.windindx + m);
@@ -533,9 +539,9 @@ int hb_run::step()
     in.s2varg_df = s2varg_ * dfvara_;
     in.dfvara = dfvara_;
     for (int j = 0; j < n_fold; j++) {
-        in.logpi[j] = std::log(Pi[cls_of[j]]);
-        in.fold[j] = fold_[cls_of[j]];
-        in.vara_fold[j] = vara_fold[cls_of[j]];
+        in.logpi[j] = std::log(Pi[j]);
+        in.fold[j] = fold_[j];
+        in.vara_fold[j] = vara_fold[j];
     }
     in.lambda = lambda;
     in.lambda2 = lambda2;
@@ -634,7 +640,7 @@ int hb_run::step()
     }
     case 6: { // :803-814
         double nz = 0;
-        for (int j = 0; j < n_fold; j++) fold_snp_num[cls_of[j]] = so.class_count[j];
+        for (int j = 0; j < n_fold; j++) fold_snp_num[j] = so.class_count[j];
         for (int j = 1; j < n_fold; j++) nz += fold_snp_num[j];
         NnzSnp = (long long)nz;
         varg = (so.sum_g2 + s2varg_ * dfvara_) / hs.chisq(dfvara_ + (double)NnzSnp);
@@ -693,7 +699,9 @@ int hb_run::step()
         for (int t = 0; t < nr; t++) vt += vr[t];
         char pis[256] = {0};
         size_t off = 0;
-        for (int j = 0; j < n_fold && off < sizeof(pis) - 16; j++) off += snprintf(pis + off, sizeof(pis) - off, "%.4f ", Pi[j]);
+        std::vector<double> pc(n_fold);
+        for (int j = 0; j < n_fold; j++) pc[cls_of[j]] = Pi[j]; // (the caller's class order)
+        for (int j = 0; j < n_fold && off < sizeof(pis) - 16; j++) off += snprintf(pis + off, sizeof(pis) - off, "%.4f ", pc[j]);
         char lam[32] = {0};
         if (model == "BayesL") snprintf(lam, sizeof(lam), "%.4f ", lambda);
         line(" %d %lld %s%s%.4f %.4f %.4f %02dh%02dm%02ds", iter + 1, NnzSnp, pis, lam, vara_, vare_, vara_ / vt, tt / 3600,
@@ -752,7 +760,7 @@ int hb_run::finish(hb_bayes_out *o)
             s_pi[(size_t)r * n_fold + 1] = Pi[1];
         }
     }
-    if (o->pi) for (int j = 0; j < n_pi; j++) o->pi[j] = Pi[j];
+    if (o->pi) for (int j = 0; j < n_pi; j++) o->pi[cls_of[j]] = Pi[j]; // (the caller's class order)
     if (nr) {
         for (int t = 0; t < nr; t++) {
             if (o->Vr) o->Vr[t] = vr_sum[t] / Rn;
@@ -792,7 +800,10 @@ int hb_run::finish(hb_bayes_out *o)
     }
     o->nzct = nzct;
     auto cp = [](double *dst, const std::vector<double> &src) { if (dst && !src.empty()) std::memcpy(dst, src.data(), sizeof(double) * src.size()); };
-    cp(o->s_mu, s_mu); cp(o->s_Vg, s_Vg); cp(o->s_Ve, s_Ve); cp(o->s_h2, s_h2); cp(o->s_pi, s_pi);
+    cp(o->s_mu, s_mu); cp(o->s_Vg, s_Vg); cp(o->s_Ve, s_Ve); cp(o->s_h2, s_h2);
+    if (o->s_pi)
+        for (int r = 0; r < n_records; r++)
+            for (int j = 0; j < n_fold; j++) o->s_pi[(size_t)r * n_fold + cls_of[j]] = s_pi[(size_t)r * n_fold + j];
     cp(o->s_beta, s_beta); cp(o->s_Vr, s_Vr); cp(o->s_r, s_r);
     if (a.store_alpha) cp(o->s_alpha, s_alpha);
     o->setup_seconds = setup_seconds;
@@ -846,7 +857,8 @@ int hb_run_state(hb_run *r, hb_run_info *info)
     info->vare = r->vare_;
     info->varg = r->varg;
     info->mu = r->mu;
-    for (int j = 0; j < HB_MAX_FOLD; j++) info->pi[j] = j < r->n_fold ? r->Pi[j] : 0.0;
+    for (int j = 0; j < HB_MAX_FOLD; j++) info->pi[j] = 0.0;
+    for (int j = 0; j < r->n_fold; j++) info->pi[r->cls_of[j]] = r->Pi[j];
     info->mean_events = r->iter > 0 ? r->events_sum / r->iter : 0.0;
     info->mean_misses = r->iter > 0 ? r->miss_sum / r->iter : 0.0;
     info->mean_redo = r->iter > 0 ? r->redo_sum / r->iter : 0.0;

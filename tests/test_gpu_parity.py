@@ -247,21 +247,24 @@ def test_bayesr_class_counts_draw_for_draw_against_the_oracle(K):
         np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"], r["mu"]], [ref["Vg"], ref["Ve"], ref["h2"], ref["mu"]], rtol=1e-9)
 
 
-def test_bayesr_fold_in_any_order_draw_for_draw_against_the_oracle():
-    """The reference takes `fold` in any order (src/Bayes.cpp:748-781: the class is picked by a cumulative walk over the classes as
-    given). The device needs the non-null classes by increasing variance for its nested thresholds: hb_run sorts them and maps
-    every per-class quantity back, so Pi, the class counts behind the Dirichlet draw and the returned pi stay in the caller's order."""
+def test_bayesr_fold_in_any_order_is_the_chain_of_the_sorted_classes():
+    """The reference takes `fold` in any order (src/Bayes.cpp:743-815) and picks the class by a cumulative walk over the classes
+    as given (:773-781). The device needs the non-null classes by increasing variance (nested thresholds on q): hb_run sorts
+    them — the run is the reference's chain for the sorted classes, draw for draw (the oracle on the sorted problem is the
+    checker), and pi / MCMCsamples$pi come back in the caller's order. Same posterior: a mixture does not depend on how its
+    components are numbered."""
     g = np.load(os.path.join(G, "small_all_models_philox.npz"))
     for Pi, fold in (([0.9375, 0.015625, 0.03125, 0.015625], [0, 1e-2, 1e-3, 1e-4]), ([0.875, 0.0625, 0.03125, 0.03125], [0, 1e-3, 1e-2, 1e-4])):
-        kw = dict(fold=fold, niter=16, nburn=6, thin=2, seed=424242)
-        ref = O.bayes(g["y"], g["X"], "BayesR", Pi, rng=O.RNG_PHILOX, store_alpha=True, **kw)
+        order = [0] + sorted(range(1, len(fold)), key=lambda k: fold[k])          # internal class -> caller's class
+        kw = dict(niter=16, nburn=6, thin=2, seed=424242)
+        ref = O.bayes(g["y"], g["X"], "BayesR", [Pi[k] for k in order], fold=[fold[k] for k in order], rng=O.RNG_PHILOX, store_alpha=True, **kw)
         for panel in (64, 512):
-            r = H.Bayes(g["y"], g["X"], "BayesR", Pi, verbose=False, panel=panel, **kw)
+            r = H.Bayes(g["y"], g["X"], "BayesR", Pi, fold=fold, verbose=False, panel=panel, **kw)
             a, b = r["MCMCsamples"]["alpha"], ref["s_alpha"]
             assert np.array_equal(a != 0, b != 0)
             np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
-            np.testing.assert_allclose(r["pi"], ref["pi"], rtol=1e-9, atol=1e-14)
-            np.testing.assert_allclose(r["MCMCsamples"]["pi"], ref["s_pi"], rtol=1e-9, atol=1e-14)
+            np.testing.assert_allclose(np.asarray(r["pi"])[order], ref["pi"], rtol=1e-9, atol=1e-14)
+            np.testing.assert_allclose(np.asarray(r["MCMCsamples"]["pi"])[order, :], ref["s_pi"], rtol=1e-9, atol=1e-14)
             np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"], r["mu"]], [ref["Vg"], ref["Ve"], ref["h2"], ref["mu"]], rtol=1e-9)
             np.testing.assert_allclose(r["pip"], ref["pip"], rtol=0, atol=1e-12)
 
