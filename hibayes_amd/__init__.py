@@ -7,10 +7,11 @@ All compute runs in libhibayes_gpu.so (hand-written gfx950 HIP kernels behind in
 """
 from ._lib import HibayesError, lib, LIB_PATH
 from .bayes import Bayes, ibrm
+from .sbayes import SBayesD, sbrm
 from .engine import Context
 from .plink import read_plink, read_table, decode_bed, attach_bigmatrix, read_bigmatrix, write_bigmatrix
 from .windows import cutwind_by_bp, cutwind_by_num
 
 __all__ = ["Bayes", "ibrm", "read_plink", "read_table", "decode_bed", "attach_bigmatrix", "read_bigmatrix", "write_bigmatrix", "Context", "cutwind_by_bp",
-           "cutwind_by_num", "HibayesError", "lib", "LIB_PATH"]
+           "cutwind_by_num", "SBayesD", "sbrm", "HibayesError", "lib", "LIB_PATH"]
 __version__ = "0.1.0"

@@ -79,6 +79,31 @@ class BayesOut(C.Structure):
     ]
 
 
+class SBayesArgs(C.Structure):
+    _fields_ = [
+        ("m", C.c_int32), ("sumstat", C.c_void_p), ("ld_sumstat", C.c_int64), ("ldm", C.c_void_p), ("ld_ldm", C.c_int64),
+        ("model", C.c_char_p), ("Pi", C.c_void_p), ("n_pi", C.c_int32),
+        ("niter", C.c_int32), ("nburn", C.c_int32), ("thin", C.c_int32),
+        ("fold", C.c_void_p), ("n_fold", C.c_int32), ("windindx", C.c_void_p),
+        ("has_vg", C.c_int32), ("has_dfvg", C.c_int32), ("has_s2vg", C.c_int32), ("has_ve", C.c_int32), ("has_dfve", C.c_int32), ("has_s2ve", C.c_int32),
+        ("vg", C.c_double), ("dfvg", C.c_double), ("s2vg", C.c_double), ("ve", C.c_double), ("dfve", C.c_double), ("s2ve", C.c_double),
+        ("outfreq", C.c_int32), ("threads", C.c_int32), ("verbose", C.c_int32),
+        ("seed", C.c_uint64), ("device", C.c_int32), ("store_alpha", C.c_int32),
+        ("interrupt", INTERRUPT_FN), ("interrupt_user", C.c_void_p), ("log", LOG_FN), ("log_user", C.c_void_p),
+    ]
+
+
+class SBayesOut(C.Structure):
+    _fields_ = [
+        ("Vg", C.c_double), ("Ve", C.c_double), ("h2", C.c_double),
+        ("n_records", C.c_int32), ("nzct", C.c_int32), ("nw", C.c_int32), ("n", C.c_int32), ("count_y", C.c_int32),
+        ("alpha", C.c_void_p), ("pi", C.c_void_p), ("pip", C.c_void_p), ("gwas", C.c_void_p),
+        ("s_Vg", C.c_void_p), ("s_Ve", C.c_void_p), ("s_h2", C.c_void_p), ("s_alpha", C.c_void_p), ("s_pi", C.c_void_p),
+        ("r_hat", C.c_void_p), ("g_last", C.c_void_p),
+        ("setup_seconds", C.c_double), ("loop_seconds", C.c_double), ("iters_done", C.c_int32), ("mean_events", C.c_double),
+    ]
+
+
 class RunInfo(C.Structure):
     _fields_ = [
         ("iter", C.c_int32), ("records", C.c_int32), ("nnz", C.c_double),
@@ -130,7 +155,7 @@ class LaunchStats(C.Structure):
 
 # every symbol include/hibayes_gpu.h declares
 SYMBOLS = [
-    "hb_abi_version", "hb_version", "hb_last_error", "hb_device_count", "hb_exchange_count", "hb_bayes_run",
+    "hb_abi_version", "hb_version", "hb_last_error", "hb_device_count", "hb_exchange_count", "hb_bayes_run", "hb_sbayes_run",
     "hb_ctx_create", "hb_ctx_destroy", "hb_ctx_panel", "hb_ctx_ld", "hb_ctx_upload_genotype_i8",
     "hb_ctx_upload_genotype_f64", "hb_ctx_upload_bed", "hb_ctx_generate_genotype", "hb_ctx_download_genotype",
     "hb_ctx_marker_stats", "hb_ctx_build_gram", "hb_ctx_download_gram", "hb_ctx_set_residual",
@@ -172,6 +197,7 @@ def lib():
     L.hb_exchange_count.restype = C.c_size_t
     L.hb_exchange_count.argtypes = [C.c_int32]
     L.hb_bayes_run.argtypes = [C.POINTER(BayesArgs), C.POINTER(BayesOut)]
+    L.hb_sbayes_run.argtypes = [C.POINTER(SBayesArgs), C.POINTER(SBayesOut)]
     L.hb_ctx_create.argtypes = [C.POINTER(CtxParams), C.POINTER(C.c_void_p)]
     L.hb_ctx_destroy.argtypes = [C.c_void_p]
     L.hb_ctx_destroy.restype = None

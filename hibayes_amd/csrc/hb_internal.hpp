@@ -151,3 +151,19 @@ extern "C" int hb_ctx_sweep_begin(hb_ctx *c, const hb_sweep_in *in);
 extern "C" int hb_ctx_sweep_end(hb_ctx *c, hb_sweep_out *out);
 int hb_comm_allreduce_f64(hb_comm *c, double *buf, size_t count, hipStream_t st);
 int hb_build_gram_impl(hb_ctx *c);
+
+// device buffers of one summary-level run (hb_sbayes.hip owns them; the kernels are in hb_sbayes.hpp)
+struct hb_sb_dev {
+    int m = 0, m_pad = 0, n = 0;
+    uint64_t seed = 0;
+    hipStream_t stream = nullptr;
+    double *ldm = nullptr, *r_hat = nullptr, *xy = nullptr, *g = nullptr, *xpx = nullptr, *vx = nullptr, *vargL = nullptr;
+    double *thr = nullptr, *invv = nullptr, *sdz = nullptr, *acc = nullptr, *ev_gi = nullptr, *wppa = nullptr;
+    uint8_t *tracker = nullptr, *wflag = nullptr;
+    uint32_t *nzrate = nullptr, *wind = nullptr;
+    int *ev_n = nullptr, *ev_col = nullptr;
+    hb_sweep_in *d_in = nullptr;
+    int nw = 0;
+};
+int hbk_sb_enqueue_sweep(hb_sb_dev *d, int model, int n_fold);
+int hbk_sb_windows(hb_sb_dev *d);

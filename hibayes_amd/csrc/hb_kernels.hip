@@ -3226,6 +3226,8 @@ int hbk_unpack2(hb_ctx *c, int col0, int ncols, int8_t *dst)
     return HB_OK;
 }
 
+#include "hb_sbayes.hpp"
+
 // hb_ctx_time_matvec: the panel mat-vec launches of one sweep, as the pipeline issues them (same grouping, same
 // partial-sum rows; no update row), back to back on the context's stream between two HIP events
 int hbk_time_matvec(hb_ctx *c, int D, int reps, int as_pipeline, double *avg_us, int *launches)

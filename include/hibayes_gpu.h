@@ -220,6 +220,62 @@ hb_ctx *hb_run_ctx(hb_run *r);
 int hb_run_finish(hb_run *r, hb_bayes_out *out);
 void hb_run_destroy(hb_run *r);
 
+/* ------------------------------------------------------------------------------------
+ * Summary-level sampler on a dense LD matrix: replaces SBayesD(), reference src/SBayesD.cpp:5-609, reached
+ * through _hibayes_SBayesD (src/RcppExports.cpp:53, arity 18) from sbrm() (R/sbayes.r:213). Arguments in the reference's
+ * order (:5-26); errors carry its exception texts (:30-63, :123-125, :154-156). The same six conditionals as Bayes() with the
+ * right-hand sides kept in Gram space, r_hat += n (g_old - g_new) ldm[:, i] (:262-266): blocks of 64 markers, the chain kernel
+ * with the LD sub-block as its Gram matrix, a whole-chip column-slab update per block (hb_sbayes.hpp).
+ * ------------------------------------------------------------------------------------ */
+typedef struct hb_sbayes_args {
+    int32_t m;               /* ldm.n_rows == sumstat.n_rows                                              */
+    const double *sumstat;   /* arma::mat sumstat (:6): m x 4 column-major — the columns sbrm() keeps,
+                                R/sbayes.r:207: MAF, BETA, SE, NMISS; NaN = NA (the marker is then skipped, :102-104) */
+    int64_t ld_sumstat;      /* leading dimension (>= m)                                                  */
+    const double *ldm;       /* arma::mat ldm (:7): m x m column-major dense LD variance-covariance matrix */
+    int64_t ld_ldm;
+    const char *model;       /* (:8)  */
+    const double *Pi;        /* (:9)  */
+    int32_t n_pi;
+    int32_t niter, nburn, thin; /* (:10-12) defaults 50000 / 20000 / 5 */
+    const double *fold;      /* Nullable (:13) */
+    int32_t n_fold;
+    const uint32_t *windindx; /* Nullable (:14), m, 1-based */
+    int32_t has_vg, has_dfvg, has_s2vg, has_ve, has_dfve, has_s2ve; /* Nullable<double> (:15-20) */
+    double vg, dfvg, s2vg, ve, dfve, s2ve;
+    int32_t outfreq, threads, verbose; /* (:21-23); threads is accepted and ignored */
+    /* ---- additions without a reference counterpart ---- */
+    uint64_t seed;           /* replaces R's global RNG state (set.seed(), R/sbayes.r:132) */
+    int32_t device;
+    int32_t store_alpha;     /* keep MCMCsamples$alpha (m x n_records) */
+    hb_interrupt_fn interrupt;
+    void *interrupt_user;
+    hb_log_fn log;
+    void *log_user;
+} hb_sbayes_args;
+
+/* Result list of SBayesD(), src/SBayesD.cpp:541-580. Caller-allocated arrays, NULL = not wanted; R = (niter - nburn) / thin. */
+typedef struct hb_sbayes_out {
+    double Vg, Ve, h2;
+    int32_t n_records, nzct, nw;
+    int32_t n;               /* population size the sampler used: mean of the finite NMISS, truncated (:33-34) */
+    int32_t count_y;         /* markers with summary statistics (:111) */
+    double *alpha;           /* m  (:553) */
+    double *pi;              /* n_pi (:566) */
+    double *pip;             /* m  (:575) */
+    double *gwas;            /* nw (:580) */
+    double *s_Vg, *s_Ve, *s_h2; /* 1 x R (:547-549) */
+    double *s_alpha;         /* m x R column-major, only with store_alpha (:554) */
+    double *s_pi;            /* n_pi x R (:567) */
+    double *r_hat;           /* extras: the Gram-space right-hand side and the effects after the last sweep (m each) */
+    double *g_last;
+    double setup_seconds, loop_seconds;
+    int32_t iters_done;
+    double mean_events;
+} hb_sbayes_out;
+
+int hb_sbayes_run(const hb_sbayes_args *args, hb_sbayes_out *out);
+
 /* ====================================================================================
  * Fine-grained engine API.  hb_bayes_run() is built on it; the parity tests and bench.py
  * drive the device pieces through it one at a time.  A context owns all device state of

@@ -56,6 +56,28 @@ class _Out(C.Structure):
     ]
 
 
+class _SbArgs(C.Structure):
+    _fields_ = [
+        ("m", C.c_int32), ("sumstat", C.c_void_p), ("ldm", C.c_void_p), ("model", C.c_char_p),
+        ("Pi", C.c_void_p), ("n_pi", C.c_int32), ("fold", C.c_void_p), ("n_fold", C.c_int32),
+        ("niter", C.c_int32), ("nburn", C.c_int32), ("thin", C.c_int32),
+        ("vg", C.c_double), ("dfvg", C.c_double), ("s2vg", C.c_double), ("ve", C.c_double), ("dfve", C.c_double), ("s2ve", C.c_double),
+        ("windindx", C.c_void_p), ("rng_kind", C.c_int32), ("seed", C.c_uint64),
+    ]
+
+
+class _SbOut(C.Structure):
+    _fields_ = [
+        ("Vg", C.c_double), ("Ve", C.c_double), ("h2", C.c_double),
+        ("n_records", C.c_int32), ("nzct", C.c_int32), ("nw", C.c_int32), ("n", C.c_int32), ("count_y", C.c_int32),
+        ("vary", C.c_double),
+        ("alpha", C.c_void_p), ("pi", C.c_void_p), ("pip", C.c_void_p), ("gwas", C.c_void_p),
+        ("s_Vg", C.c_void_p), ("s_Ve", C.c_void_p), ("s_h2", C.c_void_p), ("s_alpha", C.c_void_p), ("s_pi", C.c_void_p),
+        ("r_hat", C.c_void_p), ("g_last", C.c_void_p),
+        ("loop_seconds", C.c_double), ("iters_done", C.c_int32), ("error", C.c_char * 256),
+    ]
+
+
 def build(force=False):
     so = os.path.join(_HERE, "libhb_oracle.so")
     if force or not os.path.exists(so):
@@ -74,6 +96,8 @@ def lib():
         L = _LIB
         L.hbo_bayes.argtypes = [C.POINTER(_Args), C.POINTER(_Out)]
         L.hbo_bayes.restype = C.c_int
+        L.hbo_sbayes.argtypes = [C.POINTER(_SbArgs), C.POINTER(_SbOut)]
+        L.hbo_sbayes.restype = C.c_int
         L.hbo_decode_bed.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, C.c_void_p]
         L.hbo_decode_bed.restype = C.c_int
         L.hbo_mt_set_seed.argtypes = [C.c_void_p, C.c_uint32]
@@ -279,5 +303,53 @@ def bayes(y, X, model, Pi, fold=None, Cmat=None, R=None, niter=50000, nburn=2000
         res[k] = getattr(o, k)
     if nr:
         res["r"] = res["r"][: o.n_levels]
+    del keep
+    return res
+
+
+def sbayes(sumstat, ldm, model, Pi, fold=None, niter=50000, nburn=20000, thin=5, vg=None, dfvg=None, s2vg=None, ve=None,
+           dfve=None, s2ve=None, windindx=None, rng=RNG_PHILOX, seed=666666, store_alpha=False):
+    """Mirror of reference SBayesD() (src/SBayesD.cpp:5-26). sumstat: m x 4 (MAF, BETA, SE, NMISS; NaN = NA), ldm: m x m dense."""
+    L = lib()
+    ss = np.asfortranarray(sumstat, dtype=np.float64)
+    ld = np.asfortranarray(ldm, dtype=np.float64)
+    m = ss.shape[0]
+    if ld.shape[0] != m:
+        raise RuntimeError("Number of SNPs not equals.")
+    Pi = np.ascontiguousarray(Pi, dtype=np.float64)
+    a = _SbArgs()
+    a.m, a.sumstat, a.ldm, a.model = m, ss.ctypes.data, ld.ctypes.data, model.encode()
+    a.Pi, a.n_pi = Pi.ctypes.data, Pi.size
+    keep = [ss, ld, Pi]
+    if fold is not None:
+        fo = np.ascontiguousarray(fold, dtype=np.float64)
+        a.fold, a.n_fold = fo.ctypes.data, fo.size
+        keep.append(fo)
+    a.niter, a.nburn, a.thin = niter, nburn, thin
+    a.vg, a.dfvg, a.s2vg, a.ve, a.dfve, a.s2ve = _nan(vg), _nan(dfvg), _nan(s2vg), _nan(ve), _nan(dfve), _nan(s2ve)
+    nw = 0
+    if windindx is not None:
+        w = np.ascontiguousarray(windindx, dtype=np.uint32)
+        a.windindx, nw = w.ctypes.data, int(w.max())
+        keep.append(w)
+    a.rng_kind, a.seed = rng, seed
+    nrec = max((niter - nburn) // thin, 0)
+    o, res = _SbOut(), {}
+
+    def buf(name, shape):
+        arr = np.zeros(shape, order="F")
+        res[name] = arr
+        return arr.ctypes.data
+
+    o.alpha, o.pi, o.pip = buf("alpha", m), buf("pi", Pi.size), buf("pip", m)
+    o.gwas = buf("gwas", nw) if nw else None
+    o.s_Vg, o.s_Ve, o.s_h2 = buf("s_Vg", nrec), buf("s_Ve", nrec), buf("s_h2", nrec)
+    o.s_alpha = buf("s_alpha", (m, nrec)) if store_alpha else None
+    o.s_pi = buf("s_pi", (Pi.size, nrec))
+    o.r_hat, o.g_last = buf("r_hat", m), buf("g_last", m)
+    if L.hbo_sbayes(C.byref(a), C.byref(o)):
+        raise RuntimeError(o.error.decode())
+    for k in ("Vg", "Ve", "h2", "n_records", "nzct", "nw", "n", "count_y", "vary", "loop_seconds", "iters_done"):
+        res[k] = getattr(o, k)
     del keep
     return res

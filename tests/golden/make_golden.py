@@ -47,6 +47,17 @@ def small_case(seed=11, n=400, m=700):
     return np.asfortranarray(X), y
 
 
+def sbayes_demo():
+    """sumstat = the MAF, BETA, SE, NMISS columns of inst/extdata/demo.ma (R/sbayes.r:207); ldm = the variance-covariance matrix
+    of the 600 demo genotypes with the 1 / n normalisation of ldmat() (src/tXXmat.cpp:165-180)."""
+    d = os.path.join(HERE, "demo", "demo")
+    G = H.read_plink(d)["geno"].astype(np.float64)
+    ld = np.cov(G, rowvar=False, ddof=0)
+    rows = [l.split() for l in open(d + ".ma")][1:]
+    f = lambda x: float(x) if x != "NA" else np.nan
+    return np.array([[f(r[3]), f(r[4]), f(r[5]), f(r[7])] for r in rows]), ld
+
+
 def main():
     # 1. demo data, the roxygen example of ibrm (R/bayes.r:93-94): BayesCpi, 2000/1200/5
     y, M, rows, phe, ids, pos = demo_slice()
@@ -80,6 +91,16 @@ def main():
         out[model + "_pi"] = rr["pi"]
         out[model + "_pip"] = rr["pip"]
     np.savez_compressed(os.path.join(HERE, "small_all_models_philox.npz"), **out)
+    # 4. summary-level sampler (SBayesD) on the demo COJO file + the LD matrix of the demo genotypes, every model, few sweeps
+    ss, ld = sbayes_demo()
+    out = {}
+    for model, Pi, fold in MODELS:
+        rr = O.sbayes(ss, ld, model, Pi, fold=fold, niter=12, nburn=4, thin=2, rng=O.RNG_PHILOX, seed=2468, store_alpha=True)
+        out[model + "_alpha"] = rr["s_alpha"]
+        out[model + "_scal"] = np.array([rr["Vg"], rr["Ve"], rr["h2"]])
+        out[model + "_pi"] = rr["pi"]
+        out[model + "_pip"] = rr["pip"]
+    np.savez_compressed(os.path.join(HERE, "sbayes_demo_philox.npz"), **out)
     print("golden vectors written to", HERE)
 
 

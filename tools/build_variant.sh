@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../hibayes_amd/csrc"
 mkdir -p ../variants /tmp/hbv_$1
-for f in hb_ctx hb_kernels hb_gram hb_run hb_comm; do
+for f in hb_ctx hb_kernels hb_gram hb_run hb_comm hb_sbayes; do
   if [ $f = hb_kernels ] || [ ! -f $f.o ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-result $2 -c $f.hip -o /tmp/hbv_$1/$f.o
   else cp $f.o /tmp/hbv_$1/$f.o; fi
