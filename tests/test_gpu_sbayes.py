@@ -16,7 +16,7 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def _compare(r, ref, tol=1e-9):
     a, b = r["MCMCsamples"]["alpha"], ref["s_alpha"]
     assert np.array_equal(a != 0, b != 0), "inclusion pattern differs in %d entries" % int(((a != 0) != (b != 0)).sum())
-    np.testing.assert_allclose(a, b, rtol=tol, atol=1e-13)
+    np.testing.assert_allclose(a, b, rtol=tol, atol=1e-13 if tol < 1e-7 else 1e-8)   # (effects here are of order 1)
     np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"]], [ref["Vg"], ref["Ve"], ref["h2"]], rtol=tol)
     np.testing.assert_allclose(r["pi"], ref["pi"], rtol=tol, atol=1e-14)
     np.testing.assert_allclose(r["MCMCsamples"]["pi"], ref["s_pi"], rtol=tol, atol=1e-14)
@@ -31,7 +31,7 @@ def test_demo_draw_for_draw_against_golden_and_live_oracle(sdemo, model, Pi, fol
     g = np.load(os.path.join(G, "sbayes_demo_philox.npz"))
     tol = 1e-6 if model == "BayesL" else 1e-9  # (1 / inverse-Gaussian(|g|) amplifies last-bit differences, as in the individual-level path)
     r = H.SBayesD(ss, ld, model, Pi, fold=fold, niter=12, nburn=4, thin=2, seed=2468, verbose=False)
-    np.testing.assert_allclose(r["MCMCsamples"]["alpha"], g[model + "_alpha"], rtol=tol, atol=1e-13)
+    np.testing.assert_allclose(r["MCMCsamples"]["alpha"], g[model + "_alpha"], rtol=tol, atol=1e-13 if tol < 1e-7 else 1e-8)
     np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"]], g[model + "_scal"], rtol=tol)
     np.testing.assert_allclose(r["pip"], g[model + "_pip"], rtol=0, atol=1e-12)
     kw = dict(fold=fold, niter=60, nburn=20, thin=4, seed=97)
