@@ -59,6 +59,7 @@ class BayesArgs(C.Structure):
         ("comm", C.c_void_p),
         ("sync_blocks", C.c_int32),
         ("genotype_bits", C.c_int32),
+        ("shard_rows", C.c_int32), ("n_global", C.c_int64), ("row_offset", C.c_int64),
     ]
 
 

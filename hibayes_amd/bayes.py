@@ -28,7 +28,8 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
           thin=5, epsl_y_J=None, epsl_Gi=None, epsl_index=None, dfvr=None, s2vr=None, vg=None,
           dfvg=None, s2vg=None, ve=None, dfve=None, s2ve=None, windindx=None, outfreq=100, threads=0,
           verbose=True, *, seed=666666, device=0, panel=0, precise=2, store_alpha=True,
-          comm=None, m_global=None, m_offset=0, log=None, C=None, g_init=None, ctx=None, sync_every_blocks=1, genotype_bits=8):
+          comm=None, m_global=None, m_offset=0, log=None, C=None, g_init=None, ctx=None, sync_every_blocks=1, genotype_bits=8,
+          shard_rows=False, n_global=None, row_offset=0):
     """Individual-level Gibbs sampler on one MI355X (or one marker shard of it when `comm` is given).
 
     X is n x m: int8 (fast path, no double blow-up) or any integer-valued float array in the
@@ -117,7 +118,7 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
     nrec = max((int(niter) - int(nburn)) // max(int(thin), 1), 0)
     a.store_alpha = int(bool(store_alpha))
     if comm is not None and (comm.world > 1 or hasattr(comm, "handle")):
-        if comm.world > 1 and m_global is None:
+        if comm.world > 1 and m_global is None and not shard_rows:
             raise HibayesError(1, "a sharded run needs m_global (markers over all ranks) and m_offset (first global marker of this shard)")
         a.rank, a.world = comm.rank, comm.world
         a.m_global = int(m_global if m_global is not None else m)
@@ -137,6 +138,8 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
             raise HibayesError(1, "g_init must have one entry per marker")
         a.g_init = gi.ctypes.data
         keep.append(gi)
+    if shard_rows:  # exact cross-check mode: this process holds rows [row_offset, row_offset + n) of every marker (include/hibayes_gpu.h)
+        a.shard_rows, a.n_global, a.row_offset = 1, int(n if n_global is None else n_global), int(row_offset)
     a.genotype_bits = int(genotype_bits)  # 8: int8 columns resident; 2: 2 bits per genotype resident (codes 0..3), same chain
     a.sync_blocks = int(sync_every_blocks)  # exchanges per sweep of a sharded run; the chain itself does not depend on it
     if log is not None:

@@ -172,6 +172,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->X, (size_t)c->ld * mp));
     TRY(dev_alloc(&c->xpx, mp));
     TRY(dev_alloc(&c->vx, mp));
+    TRY(dev_alloc(&c->s1, mp));
     TRY(dev_alloc(&c->g, mp));
     TRY(dev_alloc(&c->vargL, mp));
     TRY(dev_alloc(&c->alpha_sum, mp));
@@ -261,7 +262,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
-    void *ptrs[] = {c->X, c->X2, c->xpx, c->vx, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
+    void *ptrs[] = {c->X, c->X2, c->xpx, c->vx, c->s1, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->dots, c->ev_count, c->ev_idx,
                     c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
     for (void *p : ptrs)

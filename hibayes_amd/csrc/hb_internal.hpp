@@ -67,6 +67,7 @@ struct hb_ctx {
     int dotq2_cpl = 1, dotq2_tiles = 3072, dotq2_rs = 256;
     int dotq2_kind = 0, dotq2_nc = 16;    // (measured: 23.3 us per 3584-column launch for kind 0 at these defaults, 26.1 for kind 1) 1: individuals across the lanes, no LDS (k_dotq2r), NC columns per tile; 0: lane = column through LDS (k_dotq2) // k_dotq2 launch shape (HB_DOTQ2_CPL, HB_DOTQ2_TILES)
     double *xpx = nullptr, *vx = nullptr, *g = nullptr, *vargL = nullptr;
+    double *s1 = nullptr; // column sums of the resident rows (k_stats), for the row-sharded mode's global statistics
     double *alpha_sum = nullptr, *alpha_sq = nullptr;
     uint8_t *tracker = nullptr;
     uint32_t *nzrate = nullptr;
@@ -139,6 +140,13 @@ struct hb_ctx {
     int graph_model = -1, graph_fold = -1;
     bool use_graph = true;
 
+    // Row-sharded exact cross-check mode (hb_bayes_args.shard_rows): this context holds a block of INDIVIDUALS of every marker; the
+    // digit-plane sums of each panel mat-vec (and the few other n-long reductions) are summed over the shards by this hook, on
+    // host arrays, in place. Integer sums are order-independent, so every shard runs the single-GPU chain.
+    int (*row_reduce)(void *user, double *vals, size_t count) = nullptr;
+    void *row_user = nullptr;
+    int row_rank = 0, row_world = 1;
+    bool row_failed = false;
     bool profiling = false;
     bool chain_alone = false; // hb_ctx_set_profiling bit 2: the pipeline's kernels, mat-vec launches first, the chain alone afterwards
     hb_sweep_timing timing{};

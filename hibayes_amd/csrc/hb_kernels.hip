@@ -94,7 +94,7 @@ __device__ __forceinline__ T block_sum(T v, T *red)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_stats(const int8_t *__restrict__ X, int64_t ld, int n, int m,
                                                double *__restrict__ xpx, double *__restrict__ vx,
-                                               int *__restrict__ xinfo)
+                                               int *__restrict__ xinfo, double *__restrict__ s1out)
 {
     __shared__ long long red[4];
     const int j = blockIdx.x;
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void k_stats(const int8_t *__restrict__ X, int
         atomicMax(&xinfo[1], mx);
     }
     if (threadIdx.x == 0) {
+        if (s1out) s1out[j] = j < m ? (double)s1 : 0.0; // (row-sharded cross-check mode: the shards' integer sums are added up by the host)
         if (j < m) {
             xpx[j] = (double)s2;
             const long long num = (long long)n * s2 - s1 * s1; // n*S2 - S1^2, exact
@@ -566,12 +567,12 @@ __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, un
 }
 
 __global__ __launch_bounds__(1024) void k_quant0(const double *__restrict__ r, int64_t ld, int8_t *__restrict__ rq,
-                                                 double *__restrict__ mb, int *__restrict__ vexp)
+                                                 double *__restrict__ mb, int *__restrict__ vexp, const double *__restrict__ force_max)
 {
     __shared__ double red[16];
     __shared__ double s_max;
-    double mx = 0.0;
-    for (int64_t i = threadIdx.x; i < ld; i += blockDim.x) mx = fmax(mx, fabs(r[i]));
+    double mx = force_max ? *force_max : 0.0; // (row-sharded mode: max |yadj| over ALL shards, so that every shard's digits share one exponent)
+    for (int64_t i = threadIdx.x; i < ld && !force_max; i += blockDim.x) mx = fmax(mx, fabs(r[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
@@ -2686,7 +2687,33 @@ static void launch_dotq_fin(hb_ctx *c, int col0, int ncols, int gidx, double *ou
 static void launch_quant0(hb_ctx *c, hipStream_t st)
 {
     (void)hipMemsetAsync(c->accq, 0, sizeof(long long) * (size_t)HB_ND * c->m_pad, st);
-    hipLaunchKernelGGL(k_quant0, dim3(1), dim3(1024), 0, st, c->r, c->ld, c->rq, c->mb, c->vexp);
+    hipLaunchKernelGGL(k_quant0, dim3(1), dim3(1024), 0, st, c->r, c->ld, c->rq, c->mb, c->vexp, (const double *)nullptr);
+    if (c->row_reduce) { // the shards' maxima -> one exponent for all (host round trip: this is the cross-check mode)
+        (void)hipStreamSynchronize(st);
+        std::vector<double> slot((size_t)std::max(1, c->row_world), 0.0);
+        double mxl = 0.0;
+        (void)hipMemcpy(&mxl, c->mb, sizeof(double), hipMemcpyDeviceToHost);
+        slot[c->row_rank] = mxl;
+        if (c->row_reduce(c->row_user, slot.data(), slot.size())) { c->row_failed = true; return; }
+        for (double v : slot) mxl = std::max(mxl, v);
+        (void)hipMemcpy(c->scratch, &mxl, sizeof(double), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_quant0, dim3(1), dim3(1024), 0, st, c->r, c->ld, c->rq, c->mb, c->vexp, (const double *)c->scratch);
+    }
+}
+
+// row-sharded cross-check mode: the digit-plane sums of columns [col0, col0 + ncols) summed over the shards (exact: integers
+// below 2^53 travel as doubles), before they are finalized
+static int row_reduce_accq(hb_ctx *c, int col0, int ncols, hipStream_t st)
+{
+    HB_HIP(hipStreamSynchronize(st));
+    std::vector<long long> hq((size_t)HB_ND * ncols);
+    HB_HIP(hipMemcpy2D(hq.data(), sizeof(long long) * ncols, c->accq + col0, sizeof(long long) * c->m_pad, sizeof(long long) * ncols, HB_ND, hipMemcpyDeviceToHost));
+    std::vector<double> hd(hq.size());
+    for (size_t i = 0; i < hq.size(); i++) hd[i] = (double)hq[i];
+    if (c->row_reduce(c->row_user, hd.data(), hd.size())) return hb_fail(HB_ERR_COMM, "row-sharded mode: the all-reduce of the digit sums failed");
+    for (size_t i = 0; i < hq.size(); i++) hq[i] = (long long)hd[i];
+    HB_HIP(hipMemcpy2D(c->accq + col0, sizeof(long long) * c->m_pad, hq.data(), sizeof(long long) * ncols, sizeof(long long) * ncols, HB_ND, hipMemcpyHostToDevice));
+    return HB_OK;
 }
 
 // the reduction of the last launch's partials (there is no next launch to carry it)
@@ -2786,6 +2813,8 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
             const int vread = pd - L - 1;
             if (!timed && vread >= 0) HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[vread], 0));
             launch_dot(c, pd * c->P, c->P, ver_slot(c, vread < -1 ? -1 : vread), sA, false, nullptr, 0, 0, pd);
+            if (fx && c->row_reduce)
+                if (int rcr = row_reduce_accq(c, pd * c->P, c->P, sA)) return rcr;
             if (fx) launch_dotq_fin(c, pd * c->P, c->P, pd, c->partial + (size_t)pd * c->P, sA); // the chain sums one "split"
             if (!timed) HB_HIP(hipEventRecord(c->ev_dot[pd], sA));
             tm.end(0, b);
@@ -2991,7 +3020,7 @@ int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
 {
     *c->h_in = *in;
     HB_HIP(hipMemcpyAsync(c->d_in, c->h_in, sizeof(hb_sweep_in), hipMemcpyHostToDevice, c->stream));
-    if (timed) return enqueue_sweep_kernels(c, in->model_index, in->n_fold, true);
+    if (timed || c->row_reduce) return enqueue_sweep_kernels(c, in->model_index, in->n_fold, true); // (row-sharded mode: host round trips inside the sweep)
     const int pb = c->rng_pe ? c->rng_pb : 0, pe = c->rng_pe ? c->rng_pe : c->npanels;
     const bool first = c->rng_pe ? c->rng_first : true, last = c->rng_pe ? c->rng_last : true;
     auto enqueue = [&]() {
@@ -3071,7 +3100,7 @@ int hbk_stats(hb_ctx *c)
 {
     int init[2] = {127, -128};
     HB_HIP(hipMemcpyAsync(c->xinfo, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_stats, dim3(c->m_pad), dim3(256), 0, c->stream, c->X, c->ld, c->n, c->m, c->xpx, c->vx, c->xinfo);
+    hipLaunchKernelGGL(k_stats, dim3(c->m_pad), dim3(256), 0, c->stream, c->X, c->ld, c->n, c->m, c->xpx, c->vx, c->xinfo, c->s1);
     HB_HIP(hipGetLastError());
     int info[2];
     HB_HIP(hipMemcpyAsync(info, c->xinfo, sizeof(info), hipMemcpyDeviceToHost, c->stream));

@@ -66,6 +66,8 @@ struct hb_run {
     std::vector<uint32_t> wind;
     int n = 0, m = 0, model_index = 0, n_pi = 0, n_fold = 0, nc = 0, nr = 0, world = 1;
     bool fixpi = false, always_in = false, sharded = false;
+    bool rowmode = false;      // hb_bayes_args.shard_rows: individuals sharded, exact digit-sum all-reduce per panel
+    int64_t n_glob = 0, row_off = 0;
     int64_t m_global = 0;
     int niter = 0, nburn = 0, thin = 1, n_records = 0;
     // ---- device ----
@@ -74,7 +76,7 @@ struct hb_run {
     double *r0 = nullptr, *u0 = nullptr, *xbuf_own = nullptr, *xbuf = nullptr;
     size_t xcount = 0;
     // ---- state of the chain ----
-    double vary = 0, sumvx = 0;
+    double vary = 0, sumvx = 0, ymean_glob = 0;
     int nvar0 = 0, nw = 0, n_levels = 0;
     std::vector<double> beta, cpc, beta_sum, vr, vrtmp, vr_sum, zz, estR, estR_sum, vara_fold, fold_snp_num, pi_sum;
     std::vector<int32_t> zid, nlev, lev_first;
@@ -127,7 +129,8 @@ struct hb_run {
 
     int allreduce_host(double *vals, int cnt)
     { // a few host scalars through the device exchange buffer
-        if (!sharded) return HB_OK;
+        if (!sharded && !rowmode) return HB_OK;
+        if (rowmode && world == 1 && !a.comm && !a.allreduce) return HB_OK; // (one shard: the sum over the ranks is the value itself)
         if ((size_t)cnt > xcount) return hb_fail(HB_ERR_INVALID, "allreduce_host: too many values");
         HB_HIP(hipMemsetAsync(xbuf, 0, sizeof(double) * xcount, c->stream));
         HB_HIP(hipMemcpyAsync(xbuf, vals, sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
@@ -138,10 +141,115 @@ struct hb_run {
         return HB_OK;
     }
 
+    // any number of host values summed over the ranks, in place (chunks of the exchange buffer)
+    int allreduce_chunks(double *vals, size_t cnt)
+    {
+        for (size_t k0 = 0; k0 < cnt; k0 += xcount) {
+            const int rc = allreduce_host(vals + k0, (int)std::min(xcount, cnt - k0));
+            if (rc) return rc;
+        }
+        return HB_OK;
+    }
+    static int row_hook(void *user, double *vals, size_t cnt) { return static_cast<hb_run *>(user)->allreduce_chunks(vals, cnt); }
+    // maximum over the ranks of one non-negative value each (a sum over one-hot slots)
+    int allreduce_max(double *v)
+    {
+        std::vector<double> slot(world, 0.0);
+        slot[a.rank] = *v;
+        const int rc = allreduce_chunks(slot.data(), slot.size());
+        for (double s : slot) *v = std::max(*v, s);
+        return rc;
+    }
+    int row_stats_and_gram();
+    int row_sums(double *sr, double *sr2, double *varu);
     int setup(const hb_bayes_args *args);
     int step();
     int finish(hb_bayes_out *o);
 };
+
+// ---- row-sharded exact mode (hb_bayes_args.shard_rows) ----
+// Marker statistics and Gram blocks are sums over individuals: the shards' integer sums are added up (exact in doubles), so
+// xpx, vx and every Gram entry are the single-GPU numbers on every rank.
+int hb_run::row_stats_and_gram()
+{
+    int rc = hb_ctx_marker_stats(c, nullptr, nullptr, nullptr, nullptr); // local S1 (c->s1), S2 (c->xpx), min / max
+    if (rc) return rc;
+    std::vector<double> s12((size_t)2 * m);
+    HB_HIP(hipMemcpy(s12.data(), c->s1, sizeof(double) * m, hipMemcpyDeviceToHost));
+    HB_HIP(hipMemcpy(s12.data() + m, c->xpx, sizeof(double) * m, hipMemcpyDeviceToHost));
+    rc = allreduce_chunks(s12.data(), s12.size());
+    if (rc) return rc;
+    std::vector<double> vxh(m);
+    const double N = (double)n_glob;
+    for (int j = 0; j < m; j++) { // src/Bayes.cpp:310-317 from the exact integer sums: vx = (N S2 - S1^2) / (N (N - 1))
+        const double num = N * s12[m + j] - s12[j] * s12[j];
+        vxh[j] = (num == 0 || n_glob < 2) ? 0.0 : num / (N * (N - 1));
+    }
+    HB_HIP(hipMemcpy(c->xpx, s12.data() + m, sizeof(double) * m, hipMemcpyHostToDevice));
+    HB_HIP(hipMemcpy(c->vx, vxh.data(), sizeof(double) * m, hipMemcpyHostToDevice));
+    sumvx = arma_sum(vxh.data(), vxh.size());
+    nvar0 = 0;
+    for (double v : vxh) nvar0 += (v == 0.0);
+    double lo = std::abs((double)c->xmin), hi = std::abs((double)c->xmax), neg = c->xmin < 0 ? 1.0 : 0.0;
+    rc = allreduce_max(&lo);
+    if (!rc) rc = allreduce_max(&hi);
+    if (!rc) rc = allreduce_max(&neg);
+    if (rc) return rc;
+    c->xmax = (int)std::max(lo, hi); // (only max |x| matters from here on: the bound on max |yadj|, the Gram range check)
+    c->xmin = neg != 0.0 ? -c->xmax : 0;
+    rc = hb_ctx_build_gram(c, &gram_seconds);
+    if (rc) return rc;
+    const size_t cnt = (size_t)c->m_pad * c->P * (c->Lg + 1);
+    std::vector<int32_t> gi(cnt);
+    HB_HIP(hipMemcpy(gi.data(), c->gram, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+    std::vector<double> gd(cnt);
+    for (size_t i = 0; i < cnt; i++) gd[i] = (double)gi[i];
+    rc = allreduce_chunks(gd.data(), cnt);
+    if (rc) return rc;
+    for (size_t i = 0; i < cnt; i++) {
+        if (std::fabs(gd[i]) >= 2147483647.0) return hb_fail(HB_ERR_UNSUPPORTED, "genotype codes too large for the exact int32 Gram matrix at this n");
+        gi[i] = (int32_t)gd[i];
+    }
+    HB_HIP(hipMemcpy(c->gram, gi.data(), sizeof(int32_t) * cnt, hipMemcpyHostToDevice));
+    return HB_OK;
+}
+
+// sum(yadj), yadj.yadj, var(u) over ALL individuals, the same numbers on every rank AND for every number of shards: partial
+// sums of fixed 256-row chunks (sequential inside a chunk), gathered over the ranks, added in chunk order.
+int hb_run::row_sums(double *sr, double *sr2, double *varu)
+{
+    std::vector<double> r(n), u(n);
+    int rc = hb_ctx_get_residual(c, r.data(), u.data());
+    if (rc) return rc;
+    const size_t nch = (size_t)((n_glob + 255) / 256), c0 = (size_t)(row_off / 256);
+    std::vector<double> part(3 * nch, 0.0);
+    for (int i = 0; i < n; i++) {
+        const size_t ch = c0 + (size_t)i / 256;
+        part[ch] += r[i];
+        part[nch + ch] = std::fma(r[i], r[i], part[nch + ch]);
+        part[2 * nch + ch] += u[i];
+    }
+    rc = allreduce_chunks(part.data(), part.size());
+    if (rc) return rc;
+    double a = 0, b = 0, su = 0;
+    for (size_t k = 0; k < nch; k++) { a += part[k]; b += part[nch + k]; su += part[2 * nch + k]; }
+    *sr = a;
+    *sr2 = b;
+    const double mean = su / (double)n_glob;
+    std::vector<double> p2(2 * nch, 0.0);
+    for (int i = 0; i < n; i++) {
+        const size_t ch = c0 + (size_t)i / 256;
+        const double d = mean - u[i];
+        p2[ch] = std::fma(d, d, p2[ch]);
+        p2[nch + ch] += d;
+    }
+    rc = allreduce_chunks(p2.data(), p2.size());
+    if (rc) return rc;
+    double a2 = 0, a3 = 0;
+    for (size_t k = 0; k < nch; k++) { a2 += p2[k]; a3 += p2[nch + k]; }
+    *varu = n_glob > 1 ? (a2 - a3 * a3 / (double)n_glob) / (double)(n_glob - 1) : 0.0; // arma::var, two-pass, N - 1
+    return HB_OK;
+}
 
 int hb_run::setup(const hb_bayes_args *args)
 {
@@ -191,15 +299,26 @@ int hb_run::setup(const hb_bayes_args *args)
         world = hb_comm_world(a.comm);
         a.rank = hb_comm_rank(a.comm);
     }
-    sharded = world > 1 || a.comm != nullptr; // (a one-rank communicator still runs the exchange path)
+    rowmode = a.shard_rows != 0;
+    sharded = !rowmode && (world > 1 || a.comm != nullptr); // (a one-rank communicator still runs the exchange path)
+    n_glob = rowmode ? a.n_global : n;
+    row_off = rowmode ? a.row_offset : 0;
+    if (rowmode) {
+        if (!a.allreduce && !a.comm && world > 1) return hb_fail(HB_ERR_INVALID, "hb_bayes_run: shard_rows needs a communicator (comm or allreduce)");
+        if (n_glob < n || row_off < 0 || row_off + n > n_glob || row_off % 256 || (row_off + n < n_glob && n % 256))
+            return hb_fail(HB_ERR_INVALID, "hb_bayes_run: shard_rows needs row_offset and every shard but the last in multiples of 256 individuals");
+        if (a.precise != 2) return hb_fail(HB_ERR_UNSUPPORTED, "shard_rows needs the exact fixed-point mat-vec (precise = 2): only integer sums are order-independent");
+        if ((a.C && a.nc) || (a.R && a.nr)) return hb_fail(HB_ERR_UNSUPPORTED, "shard_rows: covariates and random effects are not part of the cross-check mode");
+        if (a.genotype_bits == 2) return hb_fail(HB_ERR_UNSUPPORTED, "shard_rows runs on the int8 layout");
+    }
     sync_blocks = std::max(1, std::min(64, (int)a.sync_blocks));
-    m_global = (world > 1 || a.m_global > 0) ? a.m_global : m;
-    if (world > 1 && ((!a.allreduce && !a.comm) || m_global < m))
+    m_global = (!rowmode && (world > 1 || a.m_global > 0)) ? a.m_global : m;
+    if (!rowmode && world > 1 && ((!a.allreduce && !a.comm) || m_global < m))
         return hb_fail(HB_ERR_INVALID, "hb_bayes_run: sharded run needs a communicator (comm or allreduce) and m_global");
     if (m_global < m) m_global = m;
 
     // ---- sizes, :119-124 ----
-    vary = var_n1(y.data(), n);
+    vary = var_n1(y.data(), n); // (row-sharded mode: replaced by the variance over all shards once the exchange is up)
     const double h2 = 0.5;
     niter = a.niter;
     nburn = a.nburn;
@@ -325,7 +444,8 @@ int hb_run::setup(const hb_bayes_args *args)
         // few markers move per sweep in the point-mass models: long look-ahead, big mat-vec launches; where many or
         // all markers move the forward corrections dominate: one panel per launch, two groups of look-ahead (with one, the
         // chain idles for an update + launch boundary per panel)
-        if (model_index == 3 || model_index == 4) rc = hb_ctx_set_pipeline(c, 1, 2, 7);
+        if (rowmode) rc = hb_ctx_set_pipeline(c, 0, 0, 1); // per-panel kernels: an exchange sits between each mat-vec and its chain
+        else if (model_index == 3 || model_index == 4) rc = hb_ctx_set_pipeline(c, 1, 2, 7);
         else rc = hb_ctx_set_pipeline(c, 1, 2, 1); // (BayesR; RR / A / L: 6.3 instead of 4.9 sweeps/s at n=50k, m=500k with the second group of look-ahead)
         if (rc) return rc;
         if (a.X_i8) rc = hb_ctx_upload_genotype_i8(c, a.X_i8, a.ld_i8, 0, m);
@@ -337,7 +457,7 @@ int hb_run::setup(const hb_bayes_args *args)
     HB_HIP(hipSetDevice(c->device));
 
     xcount = hb_exchange_count(n);
-    if (sharded) {
+    if (sharded || rowmode) {
         if (a.exchange_buf) xbuf = static_cast<double *>(a.exchange_buf);
         else {
             HB_HIP(hipMalloc(reinterpret_cast<void **>(&xbuf_own), sizeof(double) * xcount));
@@ -346,9 +466,44 @@ int hb_run::setup(const hb_bayes_args *args)
         HB_HIP(hipMalloc(reinterpret_cast<void **>(&r0), sizeof(double) * n));
         HB_HIP(hipMalloc(reinterpret_cast<void **>(&u0), sizeof(double) * n));
     }
+    if (rowmode) {
+        c->row_reduce = &hb_run::row_hook;
+        c->row_user = this;
+        c->row_rank = a.rank;
+        c->row_world = world;
+        c->graph_model = -1;
+        if (c->pipeline) { // (a pre-loaded context: the exchange needs the per-panel kernels)
+            rc = hb_ctx_set_pipeline(c, 0, 0, 1);
+            if (rc) return rc;
+        }
+        // var(y) over all shards, two-pass (arma::var): sums gathered per rank and added in rank order
+        std::vector<double> sl(world, 0.0);
+        sl[a.rank] = arma_sum(y.data(), n);
+        rc = allreduce_chunks(sl.data(), sl.size());
+        if (rc) return rc;
+        double tot = 0;
+        for (double v : sl) tot += v;
+        ymean_glob = tot / (double)n_glob;
+        std::vector<double> s2(2 * (size_t)world, 0.0);
+        for (int i = 0; i < n; i++) {
+            const double t = ymean_glob - y[i];
+            s2[a.rank] += t * t;
+            s2[world + a.rank] += t;
+        }
+        rc = allreduce_chunks(s2.data(), s2.size());
+        if (rc) return rc;
+        double a2 = 0, a3 = 0;
+        for (int r = 0; r < world; r++) { a2 += s2[r]; a3 += s2[world + r]; }
+        vary = n_glob > 1 ? (a2 - a3 * a3 / (double)n_glob) / (double)(n_glob - 1) : 0.0;
+    }
 
     // ---- marker statistics, :310-317 ----
     std::vector<double> vx_host(g_init.empty() ? 0 : m);
+    if (rowmode) {
+        rc = row_stats_and_gram();
+        if (rc) return rc;
+        if (!g_init.empty()) HB_HIP(hipMemcpy(vx_host.data(), c->vx, sizeof(double) * m, hipMemcpyDeviceToHost));
+    } else
     rc = hb_ctx_marker_stats(c, nullptr, g_init.empty() ? nullptr : vx_host.data(), &sumvx, &nvar0);
     if (rc) return rc;
     {
@@ -454,7 +609,7 @@ int hb_run::setup(const hb_bayes_args *args)
     line(" Iter  NumNZSnp  pi  %sVg  Ve  h2  Timeleft", model == "BayesL" ? "Lambda  " : "");
 
     // ---- :469-472 ----
-    mu = arma_sum(y.data(), n) / n;
+    mu = rowmode ? ymean_glob : arma_sum(y.data(), n) / n;
     {
         std::vector<double> yadj(n), zero(n, 0.0);
         for (int i = 0; i < n; i++) yadj[i] = y[i] - mu;
@@ -478,6 +633,10 @@ int hb_run::setup(const hb_bayes_args *args)
         rc = hb_ctx_set_residual(c, yadj.data(), zero.data());
         if (rc) return rc;
     }
+    if (rowmode) {
+        double vu = 0;
+        rc = row_sums(&sum_r, &sum_r2, &vu);
+    } else
     rc = hb_ctx_residual_sums(c, &sum_r, &sum_r2);
     if (rc) return rc;
     NnzSnp = always_in ? m_global : 0;
@@ -508,7 +667,8 @@ int hb_run::step()
     hb_stream hs(a.seed, hb_sub(HB_PURPOSE_HOST, (uint64_t)iter), 0);
 
     // sample intercept, :479-482
-    const double mu_ = -(sum_r / n + std::sqrt(vare_ / n) * hs.norm());
+    const double ng = (double)n_glob; // (= n unless the individuals are sharded)
+    const double mu_ = -(sum_r / ng + std::sqrt(vare_ / ng) * hs.norm());
     mu -= mu_;
     rc = hb_ctx_residual_shift(c, mu_);
     if (rc) return rc;
@@ -598,6 +758,11 @@ int hb_run::step()
     redo_sum += so.n_redo;
     sum_r = so.sum_r;
     sum_r2 = so.sum_r2;
+    if (rowmode) { // the three n-long reductions over all shards (the sweep's own ones saw this shard's rows only)
+        if (c->row_failed) return hb_fail(HB_ERR_COMM, "row-sharded mode: an all-reduce inside the sweep failed");
+        rc = row_sums(&sum_r, &sum_r2, &so.var_u);
+        if (rc) return rc;
+    }
     if (nc + nr) { // the block state arrived with the sweep's fetch
         const double *h = c->h_blk;
         std::copy(h, h + nc, beta.begin());
@@ -650,7 +815,7 @@ int hb_run::step()
     }
     }
     vara_ = so.var_u;                                                       // :819
-    vare_ = (sum_r2 + s2vare_ * dfvare_) / hs.chisq((double)n + dfvare_);  // :823
+    vare_ = (sum_r2 + s2vare_ * dfvare_) / hs.chisq(ng + dfvare_);  // :823
 
     if (iter >= nburn) { // :826-845 (the per-marker counters themselves live on the device)
         nzct++;

@@ -153,6 +153,15 @@ typedef struct hb_bayes_args {
      * (the dot products are exact integers either way). A context the run creates drops its int8 copy once the Gram blocks
      * are built; with a pre-loaded ctx the layout is the context's (hb_ctx_set_layout). */
     int32_t genotype_bits;
+    /* Exact multi-GPU cross-check mode (ABI 4; SURVEY §8e "alternative rejected ... keep only as a correctness cross-check mode"):
+     * shard the INDIVIDUALS instead of the markers. This process holds rows [row_offset, row_offset + n) of all m markers and of y
+     * (n_global individuals in total; row_offset and every n but the last rank's multiples of 256). The digit-plane sums of every
+     * panel mat-vec are integers, so their all-reduce is exact and order-independent: every rank runs THE single-GPU chain
+     * (same decisions, same effects), whatever the model — the dense models (RR / A / L) that a marker-sharded sweep biases
+     * included. Price: one all-reduce per panel (through `allreduce` / `comm`, with a host round trip: the per-panel kernels, no
+     * pipeline), so it scales capacity, not throughput. Needs precise = 2; covariates / random effects are refused here. */
+    int32_t shard_rows;
+    int64_t n_global, row_offset;
 } hb_bayes_args;
 
 /* number of doubles exchanged per sweep for n individuals: the residual delta (u moves by its negative) + 16 scalar sums */
@@ -322,7 +331,8 @@ int hb_ctx_get_layout(const hb_ctx *c, int32_t *bits, int32_t *int8_resident);
 int hb_ctx_marker_stats(hb_ctx *c, double *xpx, double *vx, double *sumvx, int32_t *nvar0);
 /* Pipeline geometry of the sweep: pipeline 0 = one kernel per step and panel, 1 = persistent
  * chain workgroup overlapped with the mat-vec stream; `lookahead` mat-vec groups of `dotgroup` panels each run
- * ahead of the chain. Results do not depend on it (same chain, bit for bit). Invalidates the Gram blocks. */
+ * ahead of the chain. Results do not depend on it: the same chain — identical decisions and move lists, effects to 1e-9 (two
+ * geometries add the band corrections to a right-hand side in different orders). A band wider than the stored one rebuilds the Gram blocks. */
 int hb_ctx_set_pipeline(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t dotgroup);
 /* per-panel Gram blocks G = X_p' X_p (int32, exact) plus the look-ahead band; also reports seconds spent */
 int hb_ctx_build_gram(hb_ctx *c, double *seconds);

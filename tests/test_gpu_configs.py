@@ -85,7 +85,7 @@ def test_config2_bayescpi_n10k_m100k_pipeline_vs_serial():
         c.generate(20240901, mono_every=1000)
         y = synth_y(c, n, m, 11)
         a, b = run_both_geometries(c, y, "BayesCpi", [0.95, 0.05], None, (1, 2, 7), niter=50, precise=2, nburn=10, thin=2)
-        same_chain(a, b, 1e-9, "config 2: pipeline (1,2,6) vs serial kernels")
+        same_chain(a, b, 1e-9, "config 2: pipeline (1,2,7) vs serial kernels")
         assert a["timing"]["mean_events"] > 100
 
 

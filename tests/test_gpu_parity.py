@@ -1,6 +1,7 @@
 """Parity of the GPU sampler with the CPU oracle, through the C ABI (hb_bayes_run):
 Level 1  draw-for-draw: same Philox counters => identical inclusion flags and effects;
-Level 2  statistical: blocked fp32-mat-vec GPU chain vs sequential R-stream oracle, several seeds;
+Level 2  statistical: blocked GPU chain (Philox; every mat-vec arithmetic: exact fixed point, fp64 FMA, fp32 image) vs the
+         sequential R-stream oracle, several seeds;
 plus size-independent invariants at the BASELINE sizes."""
 import os
 
@@ -128,14 +129,16 @@ def test_error_texts_through_the_c_abi(demo):
         H.Bayes(yy, M, "BayesCpi", [0.95, 0.05], niter=4, nburn=2, thin=1, verbose=False)
 
 
-@pytest.mark.parametrize("model,Pi,fold", [("BayesCpi", [0.95, 0.05], None),
-                                            ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2])])
-def test_statistical_parity_fast_path_vs_r_stream_oracle(demo, model, Pi, fold):
-    """Level 2 (SURVEY.md §8 c): GPU = blocked chain, fp32 panel mat-vec, Philox; oracle = sequential
+@pytest.mark.parametrize("model,Pi,fold,precise", [("BayesCpi", [0.95, 0.05], None, 2), ("BayesCpi", [0.95, 0.05], None, 0),
+                                                    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], 2),
+                                                    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], 0)])
+def test_statistical_parity_vs_r_stream_oracle(demo, model, Pi, fold, precise):
+    """Level 2 (SURVEY.md §8 c): GPU = blocked chain, Philox, panel mat-vec in the default exact fixed point (precise = 2) and
+    in the fp32 image of the residual (precise = 0: the mode keeps a multi-seed statistical test of its own); oracle = sequential
     chain, fp64, R's Mersenne-Twister stream. Tolerance: |difference of means over 4 seeds| <
     max(1 % relative, 3 x Monte-Carlo standard error from the across-seed spread)."""
     kw = dict(niter=3000, nburn=1000, thin=5)
-    gpu = [H.Bayes(demo["y"], demo["M"], model, Pi, fold=fold, seed=s, verbose=False, store_alpha=False, **kw) for s in (11, 12, 13, 14)]
+    gpu = [H.Bayes(demo["y"], demo["M"], model, Pi, fold=fold, seed=s, verbose=False, store_alpha=False, precise=precise, **kw) for s in (11, 12, 13, 14)]
     ora = [O.bayes(demo["y"], demo["M"], model, Pi, fold=fold, rng=O.RNG_R, seed=s, **kw) for s in (21, 22, 23, 24)]
 
     def close(a, b, what):

@@ -297,3 +297,76 @@ def test_eight_rank_dry_run_at_the_shape_of_config_4():
         assert o[8] > 1000 and o[11] > 1000
     print("8 ranks x 250k markers: mu %.6f Vg %.5f Ve %.5f h2 %.4f pi0 %.5f; markers in the model per rank %s; max |u - Xg| %.2e, max |yadj + u - (y - mu)| %.2e"
           % (ref[1], ref[2], ref[3], ref[4], ref[5], [o[8] for o in out], max(o[9] for o in out), max(o[10] for o in out)))
+
+
+def _rows_data():
+    rng = np.random.default_rng(31)
+    n, m = 900, 1300                                       # shards of 512 + 388 individuals (a 256-multiple and a ragged tail)
+    p = rng.uniform(0.05, 0.5, m)
+    X = np.asfortranarray((rng.random((n, m)) < p).astype(np.int8) + (rng.random((n, m)) < p).astype(np.int8))
+    X[:, 9] = 1
+    idx = rng.choice(m, 20, replace=False)
+    y = X[:, idx].astype(np.float64) @ rng.normal(0, 0.5, 20) + rng.normal(0, 1.0, n)
+    return y, X
+
+
+ROW_MODELS = (("BayesCpi", [0.95, 0.05], None), ("BayesRR", [0.95, 0.05], None), ("BayesR", [0.9375, 0.03125, 0.015625, 0.015625], [0, 1e-4, 1e-3, 1e-2]),
+              ("BayesA", [0.95, 0.05], None))
+ROW_KW = dict(niter=30, nburn=10, thin=2, seed=77, verbose=False)
+
+
+def _worker_rows(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hibayes_amd as H
+    from hibayes_amd.dist import TorchComm
+    comm = TorchComm(device=torch.device("cuda", 0))
+    y, X = _rows_data()
+    n = y.size
+    lo, hi = (0, 512) if rank == 0 else (512, n)
+    out = {}
+    for model, Pi, fold in ROW_MODELS:
+        f = H.Bayes(y[lo:hi], np.asfortranarray(X[lo:hi, :]), model, Pi, fold=fold, comm=comm, shard_rows=True, n_global=n, row_offset=lo, **ROW_KW)
+        out[model] = (f["MCMCsamples"]["alpha"], f["Vg"], f["Ve"], f["h2"], f["mu"], f["pi"], f["pip"], f["g"], f["e"])
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_row_sharded_exact_mode_is_the_single_gpu_chain_bit_for_bit():
+    """SURVEY §8e's exact alternative, kept as the correctness cross-check mode (hb_bayes_args.shard_rows): the INDIVIDUALS are
+    sharded, every panel mat-vec's digit-plane sums — integers — are all-reduced, and every rank runs the whole chain. Two shards
+    (512 + 388 individuals, gloo ranks on one MI355X) against one process holding all 900, same mode: BIT FOR BIT — every stored
+    effect sample, Vg, Ve, h2, mu, pi, pip; the returned u and e are the shard's rows of the single-process vectors. This holds for the
+    models a marker-sharded sweep biases (BayesRR, BayesA: every marker moves) as for the sparse ones. Against the default
+    single-GPU path (pipeline, one-workgroup reductions) the same chain to 1e-9: only the order of three n-long sums differs."""
+    import torch.multiprocessing as mp
+    import hibayes_amd as H
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker_rows, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=560) for _ in ps)
+    for p in ps:
+        p.join(timeout=30)
+    y, X = _rows_data()
+    n = y.size
+    for model, Pi, fold in ROW_MODELS:
+        one = H.Bayes(y, X, model, Pi, fold=fold, shard_rows=True, n_global=n, row_offset=0, **ROW_KW)     # one shard, same code path
+        plain = H.Bayes(y, X, model, Pi, fold=fold, **ROW_KW)                                                # the default pipeline
+        for rank, (lo, hi) in ((0, (0, 512)), (1, (512, n))):
+            a, vg, ve, h2, mu, pi, pip, u, e = res[rank][model]
+            assert np.array_equal(a, one["MCMCsamples"]["alpha"]), model
+            assert (vg, ve, h2, mu) == (one["Vg"], one["Ve"], one["h2"], one["mu"]), model
+            assert np.array_equal(pi, one["pi"]) and np.array_equal(pip, one["pip"])
+            assert np.array_equal(u, one["g"][lo:hi])
+            np.testing.assert_allclose(e, one["e"][lo:hi], rtol=0, atol=1e-10)       # (X * alpha sums its column blocks with atomics)
+        a1, a0 = one["MCMCsamples"]["alpha"], plain["MCMCsamples"]["alpha"]
+        assert np.array_equal(a1 != 0, a0 != 0), model
+        np.testing.assert_allclose(a1, a0, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose([one["Vg"], one["Ve"], one["h2"], one["mu"]], [plain["Vg"], plain["Ve"], plain["h2"], plain["mu"]], rtol=1e-9)
