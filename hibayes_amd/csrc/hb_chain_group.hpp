@@ -30,13 +30,10 @@
 #define HBG_STAMP_ONCE(i) do { } while (0)
 #define HBG_STAMP_VAL(i, x) do { } while (0)
 #endif
-#define HBG_FW 14 /* panels ahead a move is folded into: Lv * D <= (Lv + 1) * D - 1 - (D - 1) <= 20 - ... (hb_pipeline_geometry); checked at launch */
-#ifndef HBG_CH
-#define HBG_CH 3  /* moves whose rows are requested together */
-#endif
-#define HBG_DM 8 /* panels per group the register arrays are sized for (hb_pipeline_geometry caps D at 8) */
-
-template <int K1>
+// Template shape: HBG_DM = panels per group the register arrays are sized for (>= D), HBG_FW = panels ahead a move is folded into
+// (>= Lv * D), HBG_CH = moves whose rows are requested together — HBG_CH * (HBG_DM + HBG_FW) loads per lane and trip, ~60: a narrow
+// geometry (few rows per move) takes many moves per trip, the wide one of the stationary point-mass sweep three.
+template <int K1, int HBG_DM, int HBG_FW, int HBG_CH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
                                                                                                  persist_view pv)
 {
@@ -73,6 +70,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     double mbr = v.mb ? v.mb[0] : 0.0;
     int gcount = pv.p0 / D;
     bool ok = true;
+    if (t == 0) { // where this workgroup runs: k_warm's workgroups on the same XCD (= the same L2) fetch the Gram rows ahead of it
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        st_flag(pv.flags + HB_FLAG_XCC, (xcc & 15u) + 1u);
+    }
     __syncthreads();
 
     int gslot = 0; // ring slot of the group's first panel

@@ -42,7 +42,8 @@ struct hb_ctx {
     int D = 1;     // panels per mat-vec launch
     int NB = 1;    // residual versions kept = Lv + D
     int pipeline = 0;              // 0: serial kernels per panel; 1: persistent chain workgroup + flags
-    int chain_kind = 1;            // persistent chain of BayesB/C: 1 = one step per mat-vec group (k_chain_group), 0 = one per panel (k_chain_persist); HB_CHAIN=panel
+    int chain_kind = 1;            // group-granular chain (k_chain_group): bit 0 BayesB/C, bit 1 the dense models at one panel per group; 0 = k_chain_persist everywhere (HB_CHAIN=panel / all / <bits>)
+    bool warm_group = false;       // k_warm beside the group chain (HB_WARM_GROUP=1)
     bool concurrent = true;        // kernels on two streams were seen running at the same time (probe at create)
     std::string pipeline_note;     // why the persistent pipeline is off, when it is
     unsigned int *flags = nullptr; // [0] chain_done (panels whose moves are published), [1] abort

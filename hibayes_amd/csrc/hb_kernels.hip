@@ -2499,7 +2499,9 @@ int hbk_init_attrs()
     HB_PERSIST_ATTR(1, 0); HB_PERSIST_ATTR(1, 1); HB_PERSIST_ATTR(1, 17); HB_PERSIST_ATTR(1, 20);
     HB_PERSIST_ATTR(3, 0); HB_PERSIST_ATTR(3, 2);
     HB_PERSIST_ATTR(7, 0); HB_PERSIST_ATTR(7, 2);
-    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define HB_GROUP_ATTR(K1, DM, FW, CH) HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<K1, DM, FW, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    HB_GROUP_ATTR(1, 8, 14, 3); HB_GROUP_ATTR(1, 2, 4, 10); HB_GROUP_ATTR(1, 1, 2, 20);
+    HB_GROUP_ATTR(3, 1, 2, 20); HB_GROUP_ATTR(7, 1, 2, 20);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2948,10 +2950,18 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // (tools/chain_timeline.py with CT_ALONE=1) is then what the chain costs without the mat-vec's memory traffic beside it.
     const bool alone = c->chain_alone || getenv("HB_CHAIN_ALONE") != nullptr;
     // the point-mass models run the group-granular chain (hb_chain_group.hpp); HB_CHAIN=panel keeps the per-panel one
-    const bool group_chain = kp == 1 && (model == 3 || model == 4) && c->chain_kind == 1 && !c->chain_alone && Lv * D <= HBG_FW && D <= HBG_DM;
+    // (chain_kind bit 0: BayesB / BayesC; bit 1: the dense models too — BayesR and RR / A / L at one panel per group)
+    const int shape = (D <= 1 && Lv * D <= 2) ? 2 : (D <= 2 && Lv * D <= 4) ? 1 : (D <= 8 && Lv * D <= 14) ? 0 : -1;
+    const bool sparse_model = kp == 1 && (model == 3 || model == 4);
+    const bool group_chain = shape >= 0 && !c->chain_alone && (sparse_model ? (c->chain_kind & 1) != 0 : ((c->chain_kind & 2) != 0 && shape == 2));
     auto launch_the_chain = [&](hipStream_t st) -> int {
         if (group_chain) {
-            hipLaunchKernelGGL((k_chain_group<1>), dim3(1), dim3(c->P), persist_smem(c->P), st, c->d_in, cv, pv);
+            const size_t sm = persist_smem(c->P);
+            if (kp == 1 && shape == 0) hipLaunchKernelGGL((k_chain_group<1, 8, 14, 3>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            else if (kp == 1 && shape == 1) hipLaunchKernelGGL((k_chain_group<1, 2, 4, 10>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            else if (kp == 1) hipLaunchKernelGGL((k_chain_group<1, 1, 2, 20>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            else if (kp == 3) hipLaunchKernelGGL((k_chain_group<3, 1, 2, 20>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            else hipLaunchKernelGGL((k_chain_group<7, 1, 2, 20>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_group launch: ") + hipGetErrorString(e));
             return HB_OK;
@@ -2966,7 +2976,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // the L2 warmers (k_warm): a third branch of the graph, 4 workgroups per XCD of which only the chain's XCD's stay
     int warm = 4;
     if (const char *e = getenv("HB_WARM")) warm = std::max(0, std::min(16, atoi(e)));
-    if (alone || group_chain) warm = 0;
+    if (alone || (group_chain && !c->warm_group)) warm = 0;
     if (warm) {
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         int ahead = D + 4;

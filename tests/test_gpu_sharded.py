@@ -81,7 +81,7 @@ def _stat_data(kind):
     return xb + rng.normal(0, np.sqrt(0.5), n), X
 
 
-STAT_KW = dict(niter=2500, nburn=1000, thin=5, verbose=False, store_alpha=False)
+STAT_KW = dict(niter=1600, nburn=600, thin=5, verbose=False, store_alpha=False)
 CASES_SPARSE = (("wide", "BayesCpi", [0.95, 0.05]),)
 CASES_BIASED = (("wide", "BayesRR", [0.95, 0.05]), ("ld", "BayesCpi", [0.95, 0.05]), ("ld", "BayesRR", [0.95, 0.05]))
 
