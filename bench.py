@@ -451,6 +451,12 @@ def main():
         # the other model family of BASELINE.json's configs on the same genotypes, shorter run
         geo2 = PIPELINE.get(args.secondary, (1, 1, 1))
         ctx.set_pipeline(*geo2)
+        bits2 = bits
+        if bits == 2 and geo2[2] == 1:
+            # one panel per mat-vec launch (the dense models): the launch is 512 columns, the sweep is bound by the chain workgroup,
+            # and the ALU-heavier 2-bit kernel only lengthens the launches beside it (measured: 31.5 vs 26.4 ms per BayesR sweep)
+            ctx.set_layout(8)
+            bits2 = 8
         ctx.build_gram()
         K2, W2 = max(10, K // 4), max(5, min(W, 30))
         y2 = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, args.secondary)
@@ -462,7 +468,7 @@ def main():
         curve2 = list(getattr(measure, "curve", []))
         curve2.append({"sweeps": "timed region", "moves_per_sweep": round(ev2, 1), "sweeps_per_s": round(K2 / el2, 2)})
         res["secondary"] = {"model": args.secondary, "value": K2 / el2, "unit": "sweeps/s", "steps": K2, "warmup": W2,
-                            "roofline": roofline_block(args, n, cols2, launches2, ins2, iso2, None, bits),
+                            "roofline": roofline_block(args, n, cols2, launches2, ins2, iso2, None, bits2), "resident_genotype_bits": bits2,
                             "ms_per_step": el2 / K2 * 1e3, "achieved_frac_of_hbm_peak": K2 / el2 * n * m / 1e9 / HBM_PEAK_GBPS,
                             "mcmc_burn_in_sweeps_before_warmup": args.burnin_secondary,
                           "mean_changed_markers_per_sweep": ev2, "row_cache_misses_per_sweep": miss2, "NumNZSnp_last": nnz2,

@@ -126,7 +126,7 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
         if hasattr(comm, "handle"):      # RcclComm: the collective runs inside the library
             a.comm = comm.handle
         else:                            # TorchComm: the library calls back for every exchange
-            cb, xbuf_ptr = comm.make_callback(L.hb_exchange_count(n))
+            cb, xbuf_ptr = comm.make_callback(L.hb_exchange_count(4096 if shard_rows else n))   # (row shards differ in n: a fixed message)
             a.allreduce = cb
             a.exchange_buf = xbuf_ptr
             keep.append(cb)

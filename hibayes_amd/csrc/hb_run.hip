@@ -456,7 +456,8 @@ int hb_run::setup(const hb_bayes_args *args)
     a.X_f64 = nullptr;
     HB_HIP(hipSetDevice(c->device));
 
-    xcount = hb_exchange_count(n);
+    // (row-sharded mode: the shards hold different numbers of individuals, the message must not depend on n)
+    xcount = rowmode ? hb_exchange_count(4096) : hb_exchange_count(n);
     if (sharded || rowmode) {
         if (a.exchange_buf) xbuf = static_cast<double *>(a.exchange_buf);
         else {
@@ -476,24 +477,27 @@ int hb_run::setup(const hb_bayes_args *args)
             rc = hb_ctx_set_pipeline(c, 0, 0, 1);
             if (rc) return rc;
         }
-        // var(y) over all shards, two-pass (arma::var): sums gathered per rank and added in rank order
-        std::vector<double> sl(world, 0.0);
-        sl[a.rank] = arma_sum(y.data(), n);
-        rc = allreduce_chunks(sl.data(), sl.size());
+        // var(y) over all shards, two-pass (arma::var), in the shard-count-independent order of row_sums(): partial sums of
+        // fixed 256-row chunks, gathered, added in chunk order
+        const size_t nch = (size_t)((n_glob + 255) / 256), c0 = (size_t)(row_off / 256);
+        std::vector<double> p1(nch, 0.0);
+        for (int i = 0; i < n; i++) p1[c0 + (size_t)i / 256] += y[i];
+        rc = allreduce_chunks(p1.data(), p1.size());
         if (rc) return rc;
         double tot = 0;
-        for (double v : sl) tot += v;
+        for (double v : p1) tot += v;
         ymean_glob = tot / (double)n_glob;
-        std::vector<double> s2(2 * (size_t)world, 0.0);
+        std::vector<double> p2(2 * nch, 0.0);
         for (int i = 0; i < n; i++) {
+            const size_t ch = c0 + (size_t)i / 256;
             const double t = ymean_glob - y[i];
-            s2[a.rank] += t * t;
-            s2[world + a.rank] += t;
+            p2[ch] += t * t;
+            p2[nch + ch] += t;
         }
-        rc = allreduce_chunks(s2.data(), s2.size());
+        rc = allreduce_chunks(p2.data(), p2.size());
         if (rc) return rc;
         double a2 = 0, a3 = 0;
-        for (int r = 0; r < world; r++) { a2 += s2[r]; a3 += s2[world + r]; }
+        for (size_t k = 0; k < nch; k++) { a2 += p2[k]; a3 += p2[nch + k]; }
         vary = n_glob > 1 ? (a2 - a3 * a3 / (double)n_glob) / (double)(n_glob - 1) : 0.0;
     }
 
@@ -506,7 +510,7 @@ int hb_run::setup(const hb_bayes_args *args)
     } else
     rc = hb_ctx_marker_stats(c, nullptr, g_init.empty() ? nullptr : vx_host.data(), &sumvx, &nvar0);
     if (rc) return rc;
-    {
+    if (sharded) { // marker shards: the statistics of all markers (row-sharded mode already holds the global ones)
         double sv[2] = {sumvx, (double)nvar0};
         rc = allreduce_host(sv, 2);
         if (rc) return rc;
@@ -636,6 +640,7 @@ int hb_run::setup(const hb_bayes_args *args)
     if (rowmode) {
         double vu = 0;
         rc = row_sums(&sum_r, &sum_r2, &vu);
+        if (getenv("HB_ROWDBG")) fprintf(stderr, "[rowdbg rank %d] vary %.17g sumvx %.17g nvar0 %d sum_r %.17g sum_r2 %.17g xmax %d Lg %d P %d\n", a.rank, vary, sumvx, nvar0, sum_r, sum_r2, c->xmax, c->Lg, c->P);
     } else
     rc = hb_ctx_residual_sums(c, &sum_r, &sum_r2);
     if (rc) return rc;

@@ -351,7 +351,7 @@ def test_row_sharded_exact_mode_is_the_single_gpu_chain_bit_for_bit():
     ps = [ctx.Process(target=_worker_rows, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = dict(q.get(timeout=560) for _ in ps)
+    res = dict(q.get(timeout=240) for _ in ps)
     for p in ps:
         p.join(timeout=30)
     y, X = _rows_data()
@@ -361,7 +361,7 @@ def test_row_sharded_exact_mode_is_the_single_gpu_chain_bit_for_bit():
         plain = H.Bayes(y, X, model, Pi, fold=fold, **ROW_KW)                                                # the default pipeline
         for rank, (lo, hi) in ((0, (0, 512)), (1, (512, n))):
             a, vg, ve, h2, mu, pi, pip, u, e = res[rank][model]
-            assert np.array_equal(a, one["MCMCsamples"]["alpha"]), model
+            assert np.array_equal(a, one["MCMCsamples"]["alpha"]), (model, float(np.abs(a - one["MCMCsamples"]["alpha"]).max()), vg - one["Vg"], mu - one["mu"])
             assert (vg, ve, h2, mu) == (one["Vg"], one["Ve"], one["h2"], one["mu"]), model
             assert np.array_equal(pi, one["pi"]) and np.array_equal(pip, one["pip"])
             assert np.array_equal(u, one["g"][lo:hi])
