@@ -170,8 +170,7 @@ def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8):
     int8 genotypes, SURVEY.md §8 d) / the average duration of the sweep's full-width mat-vec launches AS THE SWEEP RUNS THEM
     (device-clock stamps of every block, chain and update rows beside them); `isolated` is the same launch shape replayed without
     update rows and chain between two HIP events (round 2's figure)."""
-    alg8 = float(n) * cols               # SURVEY §8 d: one byte per genotype (the int8 contract)
-    alg = alg8 * bits / 8.0              # what the resident layout holds: the bytes this kernel has to move
+    alg = float(n) * cols                # SURVEY §8 d: ALGORITHMIC bytes of a launch = one byte per genotype it covers (n x m per sweep)
     avg_ms = insitu["avg_ms"] if insitu else iso_ms
     ach = alg / (avg_ms * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": ("k_dotq2" if bits == 2 else "k_dotq") if args.precise == 2 else "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -182,10 +181,13 @@ def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8):
          "isolated": {"avg_launch_ms": iso_ms, "achieved": alg / (iso_ms * 1e-3) / 1e9, "frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                       "what": "the same launches without update rows and chain, graph replay between two HIP events"}}
     r["resident_bits_per_genotype"] = bits
-    if bits != 8:  # both denominators: the resident bytes above (the kernel's real HBM roofline), and SURVEY §8 d's n x m bytes
-        r["at_one_byte_per_genotype"] = {"bytes_per_launch": alg8, "achieved": alg8 / (avg_ms * 1e-3) / 1e9,
-                                         "frac": alg8 / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                         "what": "the same launch priced at SURVEY §8 d's n x m bytes (int8 contract): genotypes per second, not bytes moved"}
+    if bits != 8:
+        # both denominators: above, SURVEY §8 d's n x m bytes — genotypes per second priced at one byte each;
+        # here the bytes the resident layout really holds, i.e. what this kernel has to pull from HBM
+        res_b = alg * bits / 8.0
+        r["resident_bytes"] = {"bytes_per_launch": res_b, "achieved": res_b / (avg_ms * 1e-3) / 1e9, "frac": res_b / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               "what": "HBM roofline of the bytes actually moved: the 2-bit kernel is VALU-issue-bound (v_dot4_i32_i8 issues once per "
+                                       "4 cycles per SIMD, 28 per 16 genotypes: DESIGN.md 2c), not HBM-bound"}
     if insitu:
         r["in_situ"] = {k: insitu[k] for k in ("min_ms", "max_ms", "sum_ms", "span_ms", "blocks_per_launch", "full_width_launches",
                                                "ms_per_step_of_the_stamped_sweeps")}
@@ -415,12 +417,12 @@ def main():
     # from inside this process); reported only when this run has the same n, panel and launch width as that pass
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_k_dotq.json" if args.precise == 2 else "r01_pmc_k_dot.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", ("r03_pmc_k_dotq2.json" if bits == 2 else "r02_pmc_k_dotq.json") if args.precise == 2 else "r01_pmc_k_dot.json")))
         if pm["n"] == n and pm["panel"] * pm["panels_per_launch"] == cols:
             traffic = pm["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
-    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, traffic if bits == 8 else None, bits)
+    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, traffic, bits)
     note("mat-vec timing pass done")
 
     # one unit = one pass over m_ref markers (the metric's m = 500k); all ranks together pass over m_global markers per step
