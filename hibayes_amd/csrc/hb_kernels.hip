@@ -2714,7 +2714,6 @@ static int row_reduce_accq(hb_ctx *c, int col0, int ncols, hipStream_t st)
     for (size_t i = 0; i < hq.size(); i++) hd[i] = (double)hq[i];
     if (c->row_reduce(c->row_user, hd.data(), hd.size())) return hb_fail(HB_ERR_COMM, "row-sharded mode: the all-reduce of the digit sums failed");
     for (size_t i = 0; i < hq.size(); i++) hq[i] = (long long)hd[i];
-    if (getenv("HB_ROWDBG") && col0 == 0) fprintf(stderr, "[rowdbg rank %d] accq after reduce: %lld %lld %lld | plane1 %lld\n", c->row_rank, hq[0], hq[1], hq[2], hq[ncols]);
     HB_HIP(hipMemcpy2D(c->accq + col0, sizeof(long long) * c->m_pad, hq.data(), sizeof(long long) * ncols, sizeof(long long) * ncols, HB_ND, hipMemcpyHostToDevice));
     return HB_OK;
 }

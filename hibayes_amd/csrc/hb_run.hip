@@ -640,9 +640,9 @@ int hb_run::setup(const hb_bayes_args *args)
     if (rowmode) {
         double vu = 0;
         rc = row_sums(&sum_r, &sum_r2, &vu);
-        if (getenv("HB_ROWDBG")) fprintf(stderr, "[rowdbg rank %d] vary %.17g sumvx %.17g nvar0 %d sum_r %.17g sum_r2 %.17g xmax %d Lg %d P %d\n", a.rank, vary, sumvx, nvar0, sum_r, sum_r2, c->xmax, c->Lg, c->P);
-    } else
-    rc = hb_ctx_residual_sums(c, &sum_r, &sum_r2);
+    } else {
+        rc = hb_ctx_residual_sums(c, &sum_r, &sum_r2);
+    }
     if (rc) return rc;
     NnzSnp = always_in ? m_global : 0;
     s_mu.assign(n_records, 0.0);

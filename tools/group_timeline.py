@@ -22,6 +22,8 @@ geo = B.PIPELINE[model]
 ctx.set_pipeline(*geo)
 ctx.build_gram()
 ctx.set_adaptive(True)
+if os.environ.get("GT_BITS") == "2":
+    ctx.set_layout(2, keep_int8=False)
 Pi, fold = B.prior(model)
 a = BayesArgs()
 a.n, a.m = n, m
