@@ -131,6 +131,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         HBG_STAMP(1);
+        const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP; // block l = 0 of the group's first panel
+        const size_t pstep = (size_t)(pv.Lg + 2) * PP;                   // block l of panel p -> block l + 1 of panel p + 1
+        const int nfw = max(0, min(pv.Lv * D, np - (gp0 + D)));        // panels ahead that are owed the corrections
+        const bool have_fw = nfw > 0;
         int nround = 0, nmv_grp = 0;
         (void)nround; (void)nmv_grp;
         int pos_lo = 0;      // markers of the group before this position are decided
@@ -280,10 +284,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int x = 0; x < HBG_FW; x++) fw[x] = 0.0;
             // (row addresses are "wave-uniform pointer"[t]: scalar base + one vector offset, no 64-bit vector arithmetic)
-            const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP; // block l = 0 of the group's first panel
-            const size_t pstep = (size_t)(pv.Lg + 2) * PP;                   // block l of panel p -> block l + 1 of panel p + 1
-            const int nfw = max(0, min(pv.Lv * D, np - (gp0 + D)));        // panels ahead that are owed the corrections
-            const bool have_fw = nfw > 0;
 #pragma unroll 1
             for (int e0 = 0; e0 < nmoves; e0 += HBG_CH) {
                 int gv[HBG_CH][HBG_DM], gf[HBG_CH][HBG_FW];

@@ -198,8 +198,8 @@ extern "C" int hb_sbayes_run(const hb_sbayes_args *args, hb_sbayes_out *o)
     TRYA(R.alloc(&d.invv, (size_t)d.m_pad * (HB_MAX_FOLD - 1)));
     TRYA(R.alloc(&d.sdz, (size_t)d.m_pad * (HB_MAX_FOLD - 1)));
     TRYA(R.alloc(&d.acc, HB_ACC_N));
-    TRYA(R.alloc(&d.ev_gi, 64));
-    TRYA(R.alloc(&d.ev_col, 64));
+    TRYA(R.alloc(&d.ev_gi, 512)); // SB_GS (hb_sbayes.hpp): the moves of one group
+    TRYA(R.alloc(&d.ev_col, 512));
     TRYA(R.alloc(&d.ev_n, 1));
     TRYA(R.alloc(&d.tracker, d.m_pad));
     TRYA(R.alloc(&d.nzrate, d.m_pad));

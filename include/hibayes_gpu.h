@@ -233,8 +233,8 @@ void hb_run_destroy(hb_run *r);
  * Summary-level sampler on a dense LD matrix: replaces SBayesD(), reference src/SBayesD.cpp:5-609, reached
  * through _hibayes_SBayesD (src/RcppExports.cpp:53, arity 18) from sbrm() (R/sbayes.r:213). Arguments in the reference's
  * order (:5-26); errors carry its exception texts (:30-63, :123-125, :154-156). The same six conditionals as Bayes() with the
- * right-hand sides kept in Gram space, r_hat += n (g_old - g_new) ldm[:, i] (:262-266): blocks of 64 markers, the chain kernel
- * with the LD sub-block as its Gram matrix, a whole-chip column-slab update per block (hb_sbayes.hpp).
+ * right-hand sides kept in Gram space, r_hat += n (g_old - g_new) ldm[:, i] (:262-266): groups of 512 markers, the candidate-
+ * round chain kernel with the LD matrix as its Gram matrix, a whole-chip column update per group (hb_sbayes.hpp).
  * ------------------------------------------------------------------------------------ */
 typedef struct hb_sbayes_args {
     int32_t m;               /* ldm.n_rows == sumstat.n_rows                                              */

@@ -63,3 +63,10 @@ for name, sel in (("quiet", cand == 0), ("candidates, no move", (cand > 0) & (nm
     print("      dots %6.0f | rank %6.0f | exact data %6.0f | gram gather %6.0f | serial %6.0f | fold+verify %6.0f | commit+publish %6.0f | forward %6.0f | later rounds+end %6.0f" % (
         seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4), seg(4, 5), seg(5, 6), seg(6, 7), seg(7, 8), seg(8, 9)))
 print("moves/sweep %.0f" % info.mean_events)
+busy = st[:, 9] - st[:, 1]   # the group's work once its dots are in hand
+opening = st[:, 1] - st[:, 0]
+q = lambda a: "mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (a.mean(), *np.percentile(a, [50, 90, 99]), a.max())
+print("busy cycles per group:   ", q(busy))
+print("opening (dots, waiting): ", q(opening))
+print("period:                  ", q(per))
+print("busy / span %.3f" % (busy.sum() / cyc))
