@@ -274,7 +274,7 @@ extern "C" int hb_sbayes_run(const hb_sbayes_args *args, hb_sbayes_out *o)
         in.store = 0;
         *R.h_in = in;
         HB_HIP(hipMemcpyAsync(d.d_in, R.h_in, sizeof(hb_sweep_in), hipMemcpyHostToDevice, d.stream));
-        if (!R.gexec) { // one sweep = 2 ceil(m / 64) + 3 launches: captured once, replayed every iteration
+        if (!R.gexec) { // one sweep = 2 ceil(m / 512) + 3 launches: captured once, replayed every iteration
             HB_HIP(hipStreamSynchronize(d.stream));
             HB_HIP(hipStreamBeginCapture(d.stream, hipStreamCaptureModeRelaxed));
             rc = hbk_sb_enqueue_sweep(&d, model_index, n_fold);

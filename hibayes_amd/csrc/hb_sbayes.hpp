@@ -14,12 +14,15 @@
 //   k_sb_update  all compute units: r_hat[j] += sum over the group's moves of n (g_old - g_new)_k ldm[j][k] for EVERY j (the
 //                group's own markers included: k_sb_group leaves r_hat alone), the columns read coalesced down the rows.
 // The kernel boundary is the grid barrier; a sweep is 2 ceil(m / 512) + 3 launches replayed from one captured graph (one wave and
-// 64 markers per launch, the first version, was launch- and latency-bound: 35 us per 64 markers, slower than the CPU oracle).
+// 64 markers per launch, the first version, was latency-bound: 35 us per 64 markers, slower than the CPU oracle. Measured and
+// dropped: the update of the next group's rows first and the other rows on a second stream beside the next chain launch — the
+// cross-stream edges of the graph cost more than the overlap gives, 2.44 against 2.10 ms per BayesCpi sweep at m = 20000).
 // Same chain as the reference in exact arithmetic; in floating point the corrections inside a group are summed in another order
 // than the reference's daxpy sequence (last bits), like every blocked path of this library.
 #pragma once
 
 #define SB_GS 512 // markers per k_sb_group launch (= its workgroup size)
+#define SB_CH 32  // moves whose column segments a thread requests together when a round is folded onto the later markers
 
 struct sb_view {
     int m, m_pad, n;
@@ -51,16 +54,20 @@ __global__ __launch_bounds__(SB_GS) void k_sb_group(const hb_sweep_in *__restric
     const bool in = i < v.m;
     const int ic = min(i, v.m - 1); // (loads of a thread past the end go to an address that exists)
     const int model = pin->model_index;
-    const bool active = in && v.vx[ic] != 0.0;
-    const double gold = in ? v.g[ic] : 0.0, xx = v.xpx[ic];
+    // (every load of the opening is unconditional, on a clamped index: one round trip, the selects afterwards)
+    const double vxi = v.vx[ic], gi0 = v.g[ic], xx = v.xpx[ic];
     double thr[K1], invv[K1], sdz[K1];
 #pragma unroll
     for (int c = 0; c < K1; c++) {
-        thr[c] = active ? v.thr[(size_t)c * v.m_pad + ic] : HB_INF;
+        thr[c] = v.thr[(size_t)c * v.m_pad + ic];
         invv[c] = v.invv[(size_t)c * v.m_pad + ic];
         sdz[c] = v.sdz[(size_t)c * v.m_pad + ic];
     }
     double r0 = v.r_hat[ic]; // the marker's right-hand side with every move BEFORE the current round applied (without xx g_old)
+    const bool active = in && vxi != 0.0;
+    const double gold = in ? gi0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < K1; c++) thr[c] = active ? thr[c] : HB_INF;
     const int gend = min(SB_GS, v.m - g0);
     const double nn = (double)v.n;
     const double *blk = v.ldm + (size_t)g0 * v.m + g0; // the group's diagonal block: blk[k m + c] = ldm[g0 + c][g0 + k]
@@ -98,12 +105,19 @@ __global__ __launch_bounds__(SB_GS) void k_sb_group(const hb_sweep_in *__restric
         }
         __syncthreads(); // B2
         const int pos_hi = misc[1];
-        // ---- LD entries among the round's candidates ----
-        for (int idx = t; idx < ncr * 64; idx += SB_GS) {
-            const int k = idx >> 6, c = idx & 63;
-            double x = 0.0;
-            if (k < c && c < ncr) x = blk[(size_t)cs_pos[k] * v.m + cs_pos[c]];
-            cg[idx] = x;
+        // ---- LD entries among the round's candidates (all of a thread's entries requested before the first is stored) ----
+        {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = u * SB_GS + t, k = idx >> 6, c = idx & 63;
+                const bool need = k < c && c < ncr;
+                const int pk = cs_pos[min(k, ncr - 1)], pc = cs_pos[min(c, ncr - 1)];
+                x[u] = blk[(size_t)pk * v.m + pc]; // (an entry that is not needed re-reads one that is: no branch around the load)
+                x[u] = need ? x[u] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) cg[u * SB_GS + t] = x[u];
         }
         __syncthreads(); // B3
         // ---- the exact serial chain over the round's candidates: wave 0, one candidate per lane, in marker order ----
@@ -158,18 +172,18 @@ __global__ __launch_bounds__(SB_GS) void k_sb_group(const hb_sweep_in *__restric
         }
         __syncthreads(); // B4
         const int nmoves = misc[0];
-        // ---- the round's moves onto the later markers of the group: one coalesced column segment per move, 8 in flight ----
+        // ---- the round's moves onto the later markers of the group: one coalesced column segment per move, SB_CH in flight ----
         double rnew = r0;
-        for (int e0 = 0; e0 < nmoves; e0 += 8) {
-            double x[8];
-            int pe[8];
+        for (int e0 = 0; e0 < nmoves; e0 += SB_CH) {
+            double x[SB_CH];
+            int pe[SB_CH];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < SB_CH; q++) {
                 pe[q] = __builtin_amdgcn_readfirstlane(ev_pos[min(e0 + q, nmoves - 1)]);
                 x[q] = blk[(size_t)pe[q] * v.m + min(t, gend - 1)];
             }
 #pragma unroll
-            for (int q = 0; q < 8; q++)
+            for (int q = 0; q < SB_CH; q++)
                 if (e0 + q < nmoves && t > pe[q]) rnew = fma(ev_del[min(e0 + q, 63)], x[q], rnew); // in move order, as the reference's daxpy sequence
         }
         // ---- did every marker the round passed over really stay below its threshold? ----

@@ -66,6 +66,11 @@ for model, Pi, fold in (("BayesCpi", [0.95, 0.05], None), ("BayesR", [0.95, 0.02
     t1 = time.time()
     o = O.sbayes(sumstat, ldm, model, Pi, fold=fold, niter=ko, nburn=0, thin=1, seed=7)
     cpu_ms = 1e3 * o["loop_seconds"] / max(o["iters_done"], 1)
+    # the same few sweeps on the device: draw for draw the oracle's chain (one Philox stream per marker and iteration)
+    rp = H.SBayesD(sumstat, ldm, model, Pi, niter=ko, nburn=0, thin=1, fold=fold, verbose=False, seed=7, store_alpha=False)
+    scale = np.abs(o["g_last"]).max() + 1e-300
+    gdiff = float(np.abs(rp["g_last"] - o["g_last"]).max() / scale)
+    same_set = bool(((rp["g_last"] != 0) == (o["g_last"] != 0)).all())
     moved = tg["mean_events"]
     # bytes a sweep must move: one LD column (m doubles) per marker whose effect changed, read by k_sb_update
     alg = moved * m * 8.0
@@ -73,4 +78,4 @@ for model, Pi, fold in (("BayesCpi", [0.95, 0.05], None), ("BayesR", [0.95, 0.02
                       "setup_seconds": round(tg["setup_seconds"], 2), "moves_per_sweep": round(moved, 1),
                       "ld_bytes_per_sweep": alg, "achieved_GBps": round(alg / (gpu_ms * 1e-3) / 1e9, 1),
                       "cpu_oracle_ms_per_sweep": round(cpu_ms, 1), "cpu_sweeps": ko, "gpu_over_cpu": round(cpu_ms / gpu_ms, 1),
-                      "h2": round(r["h2"], 4)}))
+                      "h2": round(r["h2"], 4), "parity_sweeps": ko, "same_markers_in_model": same_set, "max_abs_diff_g_over_max_g": gdiff}))
