@@ -70,3 +70,32 @@ def test_ragged_size_windows_unsorted_fold_and_sbrm_defaults():
     full = np.column_stack([np.zeros((m, 3)), ss[:, 0], ss[:, 1], ss[:, 2], np.zeros(m), ss[:, 3]])
     f = H.sbrm(full, ld, method="BayesCpi", niter=40, nburn=10, verbose=False)
     assert f["n_records"] == 6 and f["model"] == "Summary level Bayesian model fit by [BayesCpi]" and np.isfinite(f["h2"])
+
+
+@pytest.mark.parametrize("model,Pi,fold", [("BayesCpi", [0.7, 0.3], None), ("BayesB", [0.5, 0.5], None),
+                                           ("BayesR", [0.6, 0.2, 0.15, 0.05], [0, 1e-3, 1e-2, 1e-1]), ("BayesRR", [0.95, 0.05], None)])
+def test_groups_of_512_with_many_candidates_under_strong_ld(model, Pi, fold):
+    """Several k_sb_group launches with more than 64 candidates each (several rounds per group, markers pushed over their threshold
+    by an earlier move of the same round) and a ragged last group: blocks of 32 markers in strong LD, a third of them in the model."""
+    rng = np.random.default_rng(31)
+    n, m = 600, 1700                                       # 3 groups of 512 and a tail of 164
+    p = np.repeat(rng.uniform(0.1, 0.5, (m + 31) // 32), 32)[:m]
+    X = np.empty((n, m))
+    for j in range(m):
+        fresh = (rng.random(n) < p[j]).astype(float) + (rng.random(n) < p[j])
+        X[:, j] = fresh if j % 32 == 0 else np.where(rng.random(n) < 0.92, X[:, j - 1], fresh)
+    ld = np.cov(X, rowvar=False, ddof=0)
+    beta = np.zeros(m)
+    causal = rng.choice(m, 120, replace=False)
+    beta[causal] = rng.normal(0, 0.5, causal.size)
+    y = X @ beta + rng.normal(0, 1.0, n)
+    Xc = X - X.mean(0)
+    xx = (Xc ** 2).sum(0)
+    b = (Xc * (y - y.mean())[:, None]).sum(0) / xx
+    se = np.sqrt(((y - y.mean()) ** 2).sum() / (n - 2) / xx)
+    ss = np.column_stack([X.mean(0) / 2, b, se, np.full(m, float(n))])
+    kw = dict(fold=fold, niter=12, nburn=4, thin=2, seed=77)
+    ref = O.sbayes(ss, ld, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, **kw)
+    r = H.SBayesD(ss, ld, model, Pi, verbose=False, **kw)
+    assert (ref["s_alpha"][:, -1] != 0).sum() > 200       # (the regime the test is about)
+    _compare(r, ref, 1e-8)
