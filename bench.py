@@ -195,7 +195,7 @@ def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8):
 
 
 PIPELINE = {  # (pipeline, look-ahead groups, panels per mat-vec launch): see DESIGN.md §2
-    "BayesCpi": (1, 2, 7), "BayesC": (1, 2, 7), "BayesB": (1, 2, 7), "BayesBpi": (1, 2, 7),
+    "BayesCpi": (1, 3, 7), "BayesC": (1, 3, 7), "BayesB": (1, 3, 7), "BayesBpi": (1, 3, 7),
     "BayesR": (1, 2, 1), "BayesRR": (1, 2, 1), "BayesA": (1, 2, 1), "BayesL": (1, 2, 1),
 }
 
@@ -386,7 +386,7 @@ def main():
     note("phenotype built")
     geo = PIPELINE.get(args.model, (1, 1, 1))
     ctx.set_pipeline(*geo)
-    adaptive = geo == (1, 2, 7) and not os.environ.get("HB_NO_ADAPTIVE")
+    adaptive = geo in ((1, 2, 7), (1, 3, 7)) and not os.environ.get("HB_NO_ADAPTIVE")
     if adaptive:
         ctx.set_adaptive(True)  # narrow band while many markers move (burn-in), this geometry once few do (the timed region)
     gram_s = ctx.build_gram()

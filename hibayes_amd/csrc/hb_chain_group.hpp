@@ -42,7 +42,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int lgP = 31 - __clz(P);
     const int D = pv.D, np = pv.npanels;
-    const int R = (pv.Lv + 1) * D; // correction ring: this group's panels and those of the next Lv groups
+    const int R = (pv.fcorr ? 2 : pv.Lv + 1) * D; // correction ring: this group's panels and those of the next Lv groups (with k_fwd: the next one)
     const size_t PP = (size_t)P * P;
     const unsigned long long lt = (1ull << lane) - 1ull;
 
@@ -85,7 +85,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         double r0[HBG_DM];
         float fl[HBG_DM];
         {
-            double dj[HBG_DM];
+            double dj[HBG_DM], fc[HBG_DM];
+            // (k_fwd writes the corrections the moves of the group before the last owe this one: sentinel-prefilled like the dots)
+            const bool far_in = pv.fcorr != nullptr && gp0 - pv.p0 >= 2 * D;
             bool bad = false;
             // (branch-free: a panel past the group's end re-reads the last one — a load behind a branch is waited for on the spot,
             // and eight dependent round trips is what this opening would then cost)
@@ -94,11 +96,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const size_t j = (size_t)(gp0 + min(i, Dg - 1)) * P + t;
                 dj[i] = ld_sc1(&v.dsum[j]);
                 fl[i] = pv.thr0f[j];
+                fc[i] = far_in ? ld_sc1(&pv.fcorr[j]) : 0.0;
             }
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) fl[i] = i < Dg ? fl[i] : __int_as_float(0x7fc00000);
 #pragma unroll
-            for (int i = 0; i < HBG_DM; i++) bad |= (i < Dg) && __double_as_longlong(dj[i]) == -1ll;
+            for (int i = 0; i < HBG_DM; i++) bad |= (i < Dg) && (__double_as_longlong(dj[i]) == -1ll || __double_as_longlong(fc[i]) == -1ll);
             HBG_STAMP_VAL(11, bad ? 1 : 0);
             if (__any(bad)) { // the mat-vec has not delivered (all of) this group yet: re-read what is missing
                 const unsigned long long t0 = wall_clock64();
@@ -109,6 +112,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         if (i < Dg && __double_as_longlong(dj[i]) == -1ll) {
                             dj[i] = ld_sc1(&v.dsum[(size_t)(gp0 + i) * P + t]);
                             bad |= __double_as_longlong(dj[i]) == -1ll;
+                        }
+                        if (i < Dg && __double_as_longlong(fc[i]) == -1ll) {
+                            fc[i] = ld_sc1(&pv.fcorr[(size_t)(gp0 + i) * P + t]);
+                            bad |= __double_as_longlong(fc[i]) == -1ll;
                         }
                     }
                     if (!__any(bad)) break;
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 r0[i] = 0.0;
                 if (i < Dg) {
                     double *cp = corr + (size_t)(gslot + i) * P + t;
-                    r0[i] = dj[i] - *cp;
+                    r0[i] = dj[i] - *cp - fc[i];
                     *cp = 0.0; // the slot belongs to a panel Lv + 1 groups ahead from now on
                     nact += (fl[i] == fl[i]) ? 1 : 0;
                 }
@@ -133,7 +140,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         HBG_STAMP(1);
         const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP; // block l = 0 of the group's first panel
         const size_t pstep = (size_t)(pv.Lg + 2) * PP;                   // block l of panel p -> block l + 1 of panel p + 1
-        const int nfw = max(0, min(pv.Lv * D, np - (gp0 + D)));        // panels ahead that are owed the corrections
+        // panels ahead that are owed the corrections by THIS workgroup (with k_fwd beside it: the next group's only)
+        const int nfw = max(0, min(pv.fcorr ? D : pv.Lv * D, np - (gp0 + D)));
         const bool have_fw = nfw > 0;
         int nround = 0, nmv_grp = 0;
         (void)nround; (void)nmv_grp;
@@ -464,5 +472,92 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (t == 0 && !ok) { // aborted: the host must see it (fetch_acc checks the flag), then release every waiter
         st_flag(pv.flags + HB_FLAG_ABORT, 1u);
         st_flag(pv.flags + HB_FLAG_CHAIN_DONE, 0x7fffffffu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fwd: the forward fold of the groups AFTER the next one, on a second compute unit.
+// A move of group g owes corrections to the dots of every panel whose mat-vec ran without it: the D panels of each of the groups
+// g + 1 .. g + Lv. k_chain_group needs those of g + 1 at once — it opens group g + 1 as soon as it has closed g — and keeps
+// them; the others have at least a whole group of slack, and what a fold trip costs is one compute unit's memory pipeline
+// (DESIGN §6), so they go to another one: this workgroup waits for chain_done(g), reads the group's published move lists, sums
+// G[move][q] delta over the moves for every marker q of the groups g + 2 .. g + Lv (thread = marker of each of those panels,
+// HBF_CH moves per trip, the chain's row walk continued) and writes to fcorr[] what group g + 2 is owed in all — its own sums
+// plus what the groups before g left for it, carried in registers — sentinel-prefilled like the dots, so the chain polls both in
+// the same trip. Every entry of group g + 2 is written, moves or not. One fma per move, in move order, like the chain's own
+// forward sums: the same chain in exact arithmetic (tests: draw for draw).
+// HBF_D = D panels per group (slot y of fs[] is panel y counted from the first panel of group g + 2), HBF_G = Lv - 1 groups.
+// ---------------------------------------------------------------------------------------------
+template <int HBF_D, int HBF_G, int HBF_CH>
+__global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
+{
+    constexpr int NF = HBF_D * HBF_G;
+    __shared__ int s_pos[HBF_D * 512];    // the group's moves: panel * P + marker
+    __shared__ double s_del[HBF_D * 512]; // ... and changes of effect
+    __shared__ int s_cnt[HBF_D + 1], s_ok;
+    const int P = v.P, t = threadIdx.x, lgP = 31 - __clz(P);
+    const int D = pv.D, np = pv.npanels, G = pv.Lv - 1;
+    const size_t PP = (size_t)P * P, pstep = (size_t)(pv.Lg + 2) * PP;
+    double fs[NF]; // [k * HBF_D + x]: owed to panel x of group g + 2 + k by the groups up to g
+    if (D != HBF_D || G != HBF_G) return; // (the host launches the matching shape)
+#pragma unroll
+    for (int x = 0; x < NF; x++) fs[x] = 0.0;
+    for (int gp0 = pv.p0; gp0 < np; gp0 += D) {
+        const int Dg = min(D, np - gp0);
+        const int nfar = max(0, min(G * D, np - (gp0 + 2 * D))); // panels of the groups g + 2 .. g + Lv
+        if (nfar == 0) break;
+        if (t == 0) s_ok = wait_ge(pv.flags, HB_FLAG_CHAIN_DONE, (unsigned)(gp0 + Dg)) ? 1 : 0;
+        __syncthreads();
+        if (!s_ok) return;
+        if (t <= HBF_D) { // exclusive scan of the panels' move counts
+            int a = 0;
+            for (int i = 0; i < t && i < Dg; i++) a += ld_sc1(&v.ev_count[gp0 + i]);
+            s_cnt[t] = a;
+        }
+        __syncthreads();
+        const int nev = s_cnt[min(Dg, HBF_D)];
+        for (int i = 0; i < Dg; i++) {
+            const int b = s_cnt[i], c = s_cnt[i + 1] - b;
+            for (int k = t; k < c; k += P) {
+                s_pos[b + k] = i * P + ld_sc1(&v.ev_idx[(size_t)(gp0 + i) * P + k]);
+                s_del[b + k] = ld_sc1(&v.ev_delta[(size_t)(gp0 + i) * P + k]);
+            }
+        }
+        __syncthreads();
+        const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP;
+#pragma unroll 1
+        for (int e0 = 0; e0 < nev; e0 += HBF_CH) {
+            int gf[HBF_CH][NF];
+            double dl[HBF_CH];
+#pragma unroll
+            for (int f = 0; f < HBF_CH; f++) {
+                const int e = min(e0 + f, nev - 1);
+                const int a = __builtin_amdgcn_readfirstlane(s_pos[e]);
+                const int pa = a >> lgP, ia = a & (P - 1);
+                dl[f] = (e0 + f < nev) ? s_del[e] : 0.0;
+                // panel y (counted from the first panel of group g + 2) meets the mover in block l = 2 D + y - pa: the chain's walk, 2 D panels on
+                const int32_t *row = gblk0 + (size_t)ia * P + (size_t)(2 * D) * pstep - (size_t)pa * PP;
+#pragma unroll
+                for (int y = 0; y < NF; y++) {
+                    gf[f][y] = row[t];
+                    row += (y + 1 < nfar) ? pstep : 0; // (past the last panel: the same row again, its value is not used)
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < HBF_CH; f++)
+#pragma unroll
+                for (int y = 0; y < NF; y++) fs[y] = (y < nfar) ? fma((double)gf[f][y], dl[f], fs[y]) : fs[y];
+        }
+        // group g + 2 has now heard from every group that owes it: publish, and shift what the later ones have so far
+#pragma unroll
+        for (int x = 0; x < HBF_D; x++)
+            if (x < nfar) st_sc1(&pv.fcorr[(size_t)(gp0 + 2 * D + x) * P + t], fs[x]);
+#pragma unroll
+        for (int k = 0; k + 1 < HBF_G; k++)
+#pragma unroll
+            for (int x = 0; x < HBF_D; x++) fs[k * HBF_D + x] = fs[(k + 1) * HBF_D + x];
+#pragma unroll
+        for (int x = 0; x < HBF_D; x++) fs[(HBF_G - 1) * HBF_D + x] = 0.0;
+        __syncthreads(); // (the lists are rewritten for the next group)
     }
 }

@@ -557,13 +557,16 @@ __global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
 // Sweep start of the fixed-point path: max |yadj| -> mb[0] and the exponent of slot 0, then slot 0's digit planes.
 // One workgroup (n is a few hundred KB).
 __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, unsigned *__restrict__ flags, int32_t *__restrict__ ev_count,
-                                                    int np, unsigned long long *__restrict__ dsum, int m_pad, int p_lo)
+                                                    int np, unsigned long long *__restrict__ dsum, int m_pad, int p_lo,
+                                                    unsigned long long *__restrict__ fcorr)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (acc && i < HB_ACC_N) acc[i] = 0.0; // (null: a later range of the same sweep keeps the sums)
     if (i < HB_NFLAGS && (acc || i != HB_FLAG_ABORT)) flags[i] = 0u; // (a later range keeps an abort raised by an earlier one)
     for (int k = p_lo + i; k < np; k += stride) ev_count[k] = 0; // (panels of this range on: an earlier range's move lists stay readable)
     for (int k = i; k < m_pad; k += stride) dsum[k] = ~0ull;
+    if (fcorr)
+        for (int k = i; k < m_pad; k += stride) fcorr[k] = ~0ull;
 }
 
 __global__ __launch_bounds__(1024) void k_quant0(const double *__restrict__ r, int64_t ld, int8_t *__restrict__ rq,
@@ -1050,6 +1053,7 @@ struct persist_view {
     const int *slot_of, *hotpack;        // per-sweep row-cache lists from k_hotlist
     const float *thr0f;                  // ... and the opening filter
     double candf;                        // a marker at zero is a chain candidate when q >= candf * thr0 (candf <= 1)
+    double *fcorr;                       // k_fwd's corrections (null: the chain folds all Lv D panels ahead itself)
 };
 
 #define HB_LBMAX 20
@@ -2500,7 +2504,7 @@ int hbk_init_attrs()
     HB_PERSIST_ATTR(3, 0); HB_PERSIST_ATTR(3, 2);
     HB_PERSIST_ATTR(7, 0); HB_PERSIST_ATTR(7, 2);
 #define HB_GROUP_ATTR(K1, DM, FW, CH) HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<K1, DM, FW, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-    HB_GROUP_ATTR(1, 8, 14, 3); HB_GROUP_ATTR(1, 2, 4, 10); HB_GROUP_ATTR(1, 1, 2, 20);
+    HB_GROUP_ATTR(1, 8, 14, 3); HB_GROUP_ATTR(1, 8, 7, 4); HB_GROUP_ATTR(1, 2, 4, 10); HB_GROUP_ATTR(1, 1, 2, 20);
     HB_GROUP_ATTR(3, 1, 2, 20); HB_GROUP_ATTR(7, 1, 2, 20);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2918,7 +2922,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // first mat-vec launch (it needs a compute unit with all of its LDS free, and back-to-back mat-vec launches never leave
     // one), so both branches start together after the join.
     hipLaunchKernelGGL(k_sweep_init, dim3(256), dim3(256), 0, sA, first ? c->acc : nullptr, c->flags, c->ev_count, c->npanels,
-                       reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad, pb);
+                       reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad, pb,
+                       c->fwd_group ? reinterpret_cast<unsigned long long *>(c->fcorr) : nullptr);
     const bool fx = c->precise == 2;
     if (fx) {
         HB_HIP(hipEventRecord(c->ev_dot[0], sA));
@@ -2930,7 +2935,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         pre_view pvw{c->m, c->m_pad, c->m_offset, c->seed, c->xpx, c->vx, c->g, c->vargL, c->thr, c->invv, c->sdz, kp};
         hipLaunchKernelGGL(k_pre, dim3((c->m_pad + 255) / 256), dim3(256), 0, sA, c->d_in, pvw);
     }
-    const int ns = persist_nslot(c->P, c->L, kp);
+    const int ns = std::max(0, persist_nslot(c->P, std::min(c->L, HB_LBMAX), kp));
     // (the hot lists are rebuilt for every range: they hold the effects as they are when the range starts)
     hipLaunchKernelGGL(k_hotlist, dim3(c->npanels), dim3(c->P), 0, sA, c->d_in, c->vx, c->g, c->thr, c->xpx, c->kappa, c->P, ns, c->hot_slot,
                        c->hot_list, c->thr0f, c->tracker);
@@ -2943,7 +2948,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
                   c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
     const int last_panels = np - (g0 + ngroups - 1) * D;
     persist_view pv{np, D, Lv, c->L, c->Lg, pb, c->flags,
-                    c->hot_slot, c->hot_list, c->thr0f, c->candf};
+                    c->hot_slot, c->hot_list, c->thr0f, c->candf, nullptr};
     // HB_CHAIN_ALONE=1 / hb_ctx_set_profiling(c, 4) — a TIMING AND COUNTER DIAGNOSTIC, results are meaningless (it needs no
     // co-resident kernels, so it is also how k_chain_persist runs under a counter-collecting profiler, tools/chain_counters.py): the mat-vec launches run first against a pre-set
     // chain_done (their update rows find empty event lists), the chain afterwards with the device to itself; the stamped span
@@ -2951,13 +2956,20 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     const bool alone = c->chain_alone || getenv("HB_CHAIN_ALONE") != nullptr;
     // the point-mass models run the group-granular chain (hb_chain_group.hpp); HB_CHAIN=panel keeps the per-panel one
     // (chain_kind bit 0: BayesB / BayesC; bit 1: the dense models too — BayesR and RR / A / L at one panel per group)
-    const int shape = (D <= 1 && Lv * D <= 2) ? 2 : (D <= 2 && Lv * D <= 4) ? 1 : (D <= 8 && Lv * D <= 14) ? 0 : -1;
+    const int shape = (D <= 1 && Lv * D <= 2) ? 2 : (D <= 2 && Lv * D <= 4) ? 1 : (D <= 8 && Lv * D <= 14) ? 0 : (c->fwd_group && Lv == 3 && D == 7 && c->P == 512) ? 0 : -1;
     const bool sparse_model = kp == 1 && (model == 3 || model == 4);
     const bool group_chain = shape >= 0 && !c->chain_alone && (sparse_model ? (c->chain_kind & 1) != 0 : ((c->chain_kind & 2) != 0 && shape == 2));
+    // k_fwd beside the wide group chain: the chain folds a move into its own group and the next (15 rows, four moves per trip),
+    // a second workgroup into the group after that (HB_FWD=0: the chain does all 22 rows itself, three moves per trip)
+    const bool fwd = group_chain && kp == 1 && (Lv == 2 || Lv == 3) && D == 7 && c->P == 512 && c->fwd_group && !alone;
+    if (fwd) pv.fcorr = c->fcorr;
+    if (c->L > HB_LBMAX && !fwd)
+        return hb_fail(HB_ERR_UNSUPPORTED, "three groups of seven panels of look-ahead need the group chain with k_fwd (BayesB / BayesC, panel 512)");
     auto launch_the_chain = [&](hipStream_t st) -> int {
         if (group_chain) {
             const size_t sm = persist_smem(c->P);
-            if (kp == 1 && shape == 0) hipLaunchKernelGGL((k_chain_group<1, 8, 14, 3>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            if (fwd) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            else if (kp == 1 && shape == 0) hipLaunchKernelGGL((k_chain_group<1, 8, 14, 3>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (kp == 1 && shape == 1) hipLaunchKernelGGL((k_chain_group<1, 2, 4, 10>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (kp == 1) hipLaunchKernelGGL((k_chain_group<1, 1, 2, 20>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (kp == 3) hipLaunchKernelGGL((k_chain_group<3, 1, 2, 20>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
@@ -2976,7 +2988,13 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // the L2 warmers (k_warm): a third branch of the graph, 4 workgroups per XCD of which only the chain's XCD's stay
     int warm = 4;
     if (const char *e = getenv("HB_WARM")) warm = std::max(0, std::min(16, atoi(e)));
-    if (alone || (group_chain && !c->warm_group)) warm = 0;
+    if (alone || (group_chain && !c->warm_group) || fwd) warm = 0;
+    if (fwd) {
+        HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
+        if (Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+        else hipLaunchKernelGGL((k_fwd<7, 2, 4>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+        HB_HIP(hipGetLastError());
+    }
     if (warm) {
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         int ahead = D + 4;
@@ -3007,7 +3025,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
                            make_upd(c, (g0 + h) * D, std::min(np, (g0 + h) * D + D), slot2(h - 1), slot2(h), c->flags, g0 + h));
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
-    if (warm) {
+    if (warm || fwd) {
         HB_HIP(hipEventRecord(c->ev_upd[0], c->s_upd));
         HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[0], 0));
     }

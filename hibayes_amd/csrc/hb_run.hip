@@ -89,6 +89,7 @@ struct hb_run {
     double mu_sum = 0, vara_sum = 0, vare_sum = 0, hsq_sum = 0, events_sum = 0, miss_sum = 0, redo_sum = 0;
     int sync_blocks = 1;       // runs of mat-vec groups per sweep, an exchange after each (hb_bayes_args.sync_blocks)
     bool adaptive_geo = false; // choose (Lv, D) per sweep from the previous sweep's moves (BayesB/C)
+    int geo_wide_lv = 2;       // look-ahead groups of the wide geometry (3 with k_fwd beside the chain, else 2)
     int geo_cur = 0;           // 0: (2, 7), 1: (2, 2)
     double last_events_pp = 0;
     bool done = false;
@@ -445,7 +446,7 @@ int hb_run::setup(const hb_bayes_args *args)
         // all markers move the forward corrections dominate: one panel per launch, two groups of look-ahead (with one, the
         // chain idles for an update + launch boundary per panel)
         if (rowmode) rc = hb_ctx_set_pipeline(c, 0, 0, 1); // per-panel kernels: an exchange sits between each mat-vec and its chain
-        else if (model_index == 3 || model_index == 4) rc = hb_ctx_set_pipeline(c, 1, 2, 7);
+        else if (model_index == 3 || model_index == 4) rc = hb_ctx_set_pipeline(c, 1, 3, 7); // ((2, 7) where k_fwd is not available: panels other than 512)
         else rc = hb_ctx_set_pipeline(c, 1, 2, 1); // (BayesR; RR / A / L: 6.3 instead of 4.9 sweeps/s at n=50k, m=500k with the second group of look-ahead)
         if (rc) return rc;
         if (a.X_i8) rc = hb_ctx_upload_genotype_i8(c, a.X_i8, a.ld_i8, 0, m);
@@ -530,7 +531,8 @@ int hb_run::setup(const hb_bayes_args *args)
     {   // geometry by regime: only from the wide-band geometry of the point-mass models, whose stored band serves the narrow one
         int32_t gp = 0, gl = 0, gd = 0, gb = 0;
         (void)hb_ctx_get_pipeline(c, &gp, &gl, &gd, &gb);
-        adaptive_geo = (model_index == 3 || model_index == 4) && (own_ctx || c->adaptive) && gp == 1 && gl == 2 && gd == 7 && c->Lg >= 20;
+        adaptive_geo = (model_index == 3 || model_index == 4) && (own_ctx || c->adaptive) && gp == 1 && (gl == 2 || gl == 3) && gd == 7 && c->Lg >= 20;
+        geo_wide_lv = gl;
         geo_cur = 0;
         if (adaptive_geo) { // the first sweep: as many moves as markers are expected in the model (a cold start) or are in it
             double nz = 0;
@@ -723,7 +725,7 @@ int hb_run::step()
         if (geo_cur == 1 && pp < 2.0) want = 0;       // -> (2, 7)
         else if (geo_cur == 0 && pp > 2.6) want = 1;  // -> (2, 2)
         if (want != geo_cur) {
-            rc = hb_ctx_set_pipeline(c, 1, 2, want == 0 ? 7 : 2);
+            rc = hb_ctx_set_pipeline(c, 1, want == 0 ? geo_wide_lv : 2, want == 0 ? 7 : 2);
             if (rc) return rc;
             geo_cur = want;
         }

@@ -131,8 +131,9 @@ def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=
     assert (g_ref != 0).sum() > 0
 
 
-def test_config3_bayescpi_n50k_m500k_draw_for_draw_against_live_oracle():
-    _full_size_vs_oracle(50000, 500000, "BayesCpi", [0.95, 0.05], None, (1, 2, 7), 0)
+@pytest.mark.parametrize("geo", [(1, 3, 7), (1, 2, 7)])   # the default (k_fwd beside the group chain, a 28-block band) and round 3's first
+def test_config3_bayescpi_n50k_m500k_draw_for_draw_against_live_oracle(geo):
+    _full_size_vs_oracle(50000, 500000, "BayesCpi", [0.95, 0.05], None, geo, 0)
 
 
 def test_config3_bayesr_n50k_m500k_draw_for_draw_against_live_oracle():
@@ -141,7 +142,7 @@ def test_config3_bayesr_n50k_m500k_draw_for_draw_against_live_oracle():
     _full_size_vs_oracle(50000, 500000, "BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 0)
 
 
-@pytest.mark.parametrize("model,Pi,fold,geo", [("BayesCpi", [0.95, 0.05], None, (1, 2, 7)),
+@pytest.mark.parametrize("model,Pi,fold,geo", [("BayesCpi", [0.95, 0.05], None, (1, 3, 7)),
                                                 ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1))])
 def test_config3_dense_installed_state_against_live_oracle(model, Pi, fold, geo):
     """The same size from an installed state with 5 % of the markers in the model (25 000 certain movers in the first sweep)."""
@@ -150,7 +151,7 @@ def test_config3_dense_installed_state_against_live_oracle(model, Pi, fold, geo)
 
 def test_config5_shard_shape_bayesb_n200k_m125k_draw_for_draw_against_live_oracle():
     # rank 5 of 8 of config 5 (BayesB, n = 200k, m_global = 1M)
-    _full_size_vs_oracle(200000, 125000, "BayesB", [0.95, 0.05], None, (1, 2, 7), 625000)
+    _full_size_vs_oracle(200000, 125000, "BayesB", [0.95, 0.05], None, (1, 3, 7), 625000)
 
 
 @pytest.mark.parametrize("model,Pi,fold,geo", [("BayesCpi", [0.95, 0.05], None, (1, 2, 7)),
