@@ -89,35 +89,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // (k_fwd writes the corrections the moves of the group before the last owe this one: sentinel-prefilled like the dots)
             const bool far_in = pv.fcorr != nullptr && gp0 - pv.p0 >= 2 * D;
             bool bad = false;
-            // (branch-free: a panel past the group's end re-reads the last one — a load behind a branch is waited for on the spot,
-            // and eight dependent round trips is what this opening would then cost)
+            // (every load of the opening AND of a poll is unconditional, on a clamped address: 2 HBG_DM loads in flight, one round
+            // trip per look. Re-reading only what is missing puts each load behind a branch — a dozen dependent trips per look,
+            // most of them after the values have arrived)
+            const double *fcp = far_in ? pv.fcorr : v.dsum; // (without k_fwd's share: any readable words, not looked at)
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) {
                 const size_t j = (size_t)(gp0 + min(i, Dg - 1)) * P + t;
                 dj[i] = ld_sc1(&v.dsum[j]);
                 fl[i] = pv.thr0f[j];
-                fc[i] = far_in ? ld_sc1(&pv.fcorr[j]) : 0.0;
+                fc[i] = ld_sc1(&fcp[j]);
             }
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) fl[i] = i < Dg ? fl[i] : __int_as_float(0x7fc00000);
 #pragma unroll
-            for (int i = 0; i < HBG_DM; i++) bad |= (i < Dg) && (__double_as_longlong(dj[i]) == -1ll || __double_as_longlong(fc[i]) == -1ll);
+            for (int i = 0; i < HBG_DM; i++)
+                bad |= (i < Dg) && (__double_as_longlong(dj[i]) == -1ll || (far_in && __double_as_longlong(fc[i]) == -1ll));
             HBG_STAMP_VAL(11, bad ? 1 : 0);
-            if (__any(bad)) { // the mat-vec has not delivered (all of) this group yet: re-read what is missing
+            if (__any(bad)) { // the mat-vec (or k_fwd) has not delivered (all of) this group yet: look again
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
                     bad = false;
 #pragma unroll
                     for (int i = 0; i < HBG_DM; i++) {
-                        if (i < Dg && __double_as_longlong(dj[i]) == -1ll) {
-                            dj[i] = ld_sc1(&v.dsum[(size_t)(gp0 + i) * P + t]);
-                            bad |= __double_as_longlong(dj[i]) == -1ll;
-                        }
-                        if (i < Dg && __double_as_longlong(fc[i]) == -1ll) {
-                            fc[i] = ld_sc1(&pv.fcorr[(size_t)(gp0 + i) * P + t]);
-                            bad |= __double_as_longlong(fc[i]) == -1ll;
-                        }
+                        const size_t j = (size_t)(gp0 + min(i, Dg - 1)) * P + t;
+                        dj[i] = ld_sc1(&v.dsum[j]);
+                        fc[i] = ld_sc1(&fcp[j]);
                     }
+#pragma unroll
+                    for (int i = 0; i < HBG_DM; i++)
+                        bad |= (i < Dg) && (__double_as_longlong(dj[i]) == -1ll || (far_in && __double_as_longlong(fc[i]) == -1ll));
                     if (!__any(bad)) break;
                     if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
                         if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); misc[2] = 1; }
@@ -126,6 +127,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
+#pragma unroll
+            for (int i = 0; i < HBG_DM; i++) fc[i] = far_in ? fc[i] : 0.0;
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) {
                 r0[i] = 0.0;

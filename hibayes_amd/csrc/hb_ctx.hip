@@ -1195,6 +1195,17 @@ int hb_ctx_debug_tune(hb_ctx *c, double kappa, double candf)
     return HB_OK;
 }
 
+// development aid (not in the header): the raw block stamps of mat-vec launch g of the last sweep (set_profiling(8)), 2 per block
+int hb_ctx_debug_launch_stamps(hb_ctx *c, int g, unsigned long long *out, int cap, int *nblocks)
+{
+    if (!c || !c->lstamp || g < 0 || g > c->npanels || !out || !nblocks) return hb_fail(HB_ERR_INVALID, "hb_ctx_debug_launch_stamps: bad argument");
+    HB_HIP(hipStreamSynchronize(c->stream));
+    const int nb = std::min(cap, c->lstamp_nblk[g]);
+    *nblocks = nb;
+    if (nb > 0) HB_HIP(hipMemcpy(out, c->lstamp + (size_t)g * HB_LSTAMP_BLOCKS * 2, sizeof(unsigned long long) * 2 * nb, hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
 int hb_ctx_debug_stamps(hb_ctx *c, long long *out)
 {
     if (!c || !c->dbg) return hb_fail(HB_ERR_INVALID, "hb_ctx_debug_stamps: stamps not enabled");

@@ -446,7 +446,8 @@ int hb_run::setup(const hb_bayes_args *args)
         // all markers move the forward corrections dominate: one panel per launch, two groups of look-ahead (with one, the
         // chain idles for an update + launch boundary per panel)
         if (rowmode) rc = hb_ctx_set_pipeline(c, 0, 0, 1); // per-panel kernels: an exchange sits between each mat-vec and its chain
-        else if (model_index == 3 || model_index == 4) rc = hb_ctx_set_pipeline(c, 1, 3, 7); // ((2, 7) where k_fwd is not available: panels other than 512)
+        else if (model_index == 3 || model_index == 4) // three groups of look-ahead pay where the chain, not HBM, sets the pace: 2-bit genotypes
+            rc = hb_ctx_set_pipeline(c, 1, a.genotype_bits == 2 ? 3 : 2, 7); // ((2, 7) where k_fwd is not available: panels other than 512)
         else rc = hb_ctx_set_pipeline(c, 1, 2, 1); // (BayesR; RR / A / L: 6.3 instead of 4.9 sweeps/s at n=50k, m=500k with the second group of look-ahead)
         if (rc) return rc;
         if (a.X_i8) rc = hb_ctx_upload_genotype_i8(c, a.X_i8, a.ld_i8, 0, m);

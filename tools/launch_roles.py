@@ -1,0 +1,66 @@
+"""Inside the pipeline's mat-vec launches: when do the update rows, the finalize blocks and the tiles of a launch end, and how long is
+the gap to the next launch? Block stamps (hb_ctx_set_profiling bit 3) of stationary BayesCpi sweeps at n = 50k, m = 500k.
+   python tools/launch_roles.py [bits] [Lv]"""
+import ctypes as ct, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import hibayes_amd as H
+import bench as B
+
+bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+Lv = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+n, m = 50000, 500000
+L = H.lib()
+L.hb_ctx_debug_launch_stamps.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]
+from hibayes_amd._lib import BayesArgs, check
+with H.Context(n, m, seed=20240901) as c:
+    c.generate(20240901, 1000)
+    y = B.synth_phenotype(c, n, m, 0, m, 20240901, None, "BayesCpi")
+    c.set_pipeline(1, Lv, 7)
+    c.build_gram()
+    c.set_adaptive(True)
+    if bits == 2:
+        c.set_layout(2, keep_int8=False)
+    a = BayesArgs()
+    a.n, a.m = n, m
+    yv = np.ascontiguousarray(y); a.y = yv.ctypes.data
+    a.model = b"BayesCpi"
+    pv = np.array([0.95, 0.05]); a.Pi, a.n_pi = pv.ctypes.data, pv.size
+    a.niter, a.nburn, a.thin = 340, 0, 5
+    a.seed, a.precise, a.ctx = 20240901, 2, c.h
+    run = ct.c_void_p(); check(L.hb_run_create(ct.byref(a), ct.byref(run)))
+    fin = ct.c_int32()
+    check(L.hb_run_step(run, 300, ct.byref(fin)))
+    c.set_profiling(8)
+    check(L.hb_run_step(run, 3, ct.byref(fin)))
+    s = {"n_events": -1}
+    st = c.matvec_stamps()
+    npan = (m + c.panel - 1) // c.panel
+    ng = (npan + 6) // 7
+    nupd = (n + 255) // 256
+    nfin = 7 * c.panel // 64
+    buf = np.zeros(2 * 4608, dtype=np.uint64)
+    nb = ct.c_int()
+    rows = []
+    for g in range(ng):
+        H._lib.check(L.hb_ctx_debug_launch_stamps(c.h, g, buf.ctypes.data, 4608, ct.byref(nb)))
+        k = nb.value
+        if k < nupd + nfin + 100:
+            continue
+        a = buf[:2 * k].reshape(k, 2).astype(np.int64)
+        ok = a[:, 0] > 0
+        s0 = a[ok, 0].min()
+        up, fi, ti = a[:nupd][ok[:nupd]], a[nupd:nupd + nfin][ok[nupd:nupd + nfin]], a[nupd + nfin:][ok[nupd + nfin:]]
+        rows.append((s0, up[:, 1].max() - s0 if len(up) else 0, (up[:, 1] - up[:, 0]).mean() if len(up) else 0, fi[:, 1].max() - s0 if len(fi) else 0,
+                     ti[:, 1].max() - s0, np.percentile(ti[:, 1] - s0, 50), (ti[:, 1] - ti[:, 0]).mean(), a[ok, 1].max(), ti[:, 0].max() - s0))
+    r = np.array(rows, dtype=np.float64)
+    gap = r[1:, 0] - r[:-1, 7]
+    us = 1e-2  # 100 MHz ticks -> us
+    print("bits %d, (Lv, D) = (%d, 7): %d full launches, %.2f us each in situ, moves per sweep %d" % (bits, Lv, len(r), st["avg_ms"] * 1e3, s["n_events"]))
+    print("  update rows: last one ends %.2f us after the launch's first block starts (a block lives %.2f us)" % (r[:, 1].mean() * us, r[:, 2].mean() * us))
+    print("  finalize blocks: last one ends at %.2f us" % (r[:, 3].mean() * us))
+    print("  tiles: last one STARTS at %.2f us, half of them have ended at %.2f us, last one ends at %.2f us (a tile lives %.2f us)" % (
+        r[:, 8].mean() * us, r[:, 5].mean() * us, r[:, 4].mean() * us, r[:, 6].mean() * us))
+    print("  launch ends at %.2f us; gap to the next launch's first block %.2f us (p90 %.2f)" % ((r[:, 7] - r[:, 0]).mean() * us, gap.mean() * us, np.percentile(gap, 90) * us))
+    late = r[:, 1] > r[:, 4]
+    print("  launches whose update rows end after their last tile: %d of %d (by %.2f us on average)" % (late.sum(), len(r), ((r[late, 1] - r[late, 4]).mean() * us) if late.any() else 0))
