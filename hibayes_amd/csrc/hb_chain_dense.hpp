@@ -1,0 +1,301 @@
+// hb_chain_dense.hpp — the chain of the models in which EVERY marker moves every sweep (BayesRR / BayesA / BayesL), and the
+// workgroups that fold its moves forward. Included by hb_kernels.hip (it uses that file's views and hand-off helpers).
+//
+// Why. For these models (reference src/Bayes.cpp:587-604 RR, :606-625 A, :719-741 L) there is nothing to decide: marker k's
+// new effect is an affine function of its right-hand side, gn_k = rhs_k / v_k + sd_k z_k, and the order of the moves is the
+// marker order. k_chain_persist's machinery — candidates, speculative rounds, violation checks, a row cache filled from a
+// hot-list — is all overhead here (round 2/3: 500 000 cycles per panel of 512, 6.3 sweeps/s at n = 50k, m = 500k), and what a
+// panel needs from memory, its own 1-MB Gram block and Lb more of the band, is three times what ONE compute unit can pull in the
+// time (~41 GB/s). So:
+//   * k_chain_dense — one persistent workgroup, thread = marker of the panel, wave w = sub-block w of 64 markers. A panel is
+//     eight steps: wave s runs the serial pass of its 64 markers with the 64 x 64 diagonal block of the panel's Gram block in
+//     REGISTERS (one column per lane, requested a panel ahead — the order is static, so everything is) and the loop fully
+//     unrolled: per marker  fma (new effect) - sub (change) - 2 v_readlane (broadcast) - fma (the later lanes' right-hand
+//     sides); then the later waves take the 64 changes with the strip G[64 s .. 64 s + 63][t] they requested two steps
+//     earlier (64 registers per thread, double-buffered). Nothing is ever decided, gathered or rolled back.
+//   * k_fold_dense — the band: panel q is owed  sum_l G_l[q]^T delta_{q-l}  by the panels whose moves its mat-vec has not
+//     seen, a dense 512 x 512 product per band block. 8 Lb small workgroups spread over the chip (one per 64 columns of a
+//     target panel, its four waves a quarter of the rows each) take the chain's changes sub-block by sub-block as they are
+//     published (dd[], sentinel-prefilled like the dots: no flag) and hand the finished sums to the chain through fcorr[],
+//     which the chain polls with its dots. The chain's compute unit never reads a band row.
+// Same chain as k_chain / k_chain_persist: the same fused multiply-adds per marker in the same order inside a panel; the band
+// sums are added in a different order (per row quarter), i.e. effects agree to the last bits' rounding (tests: draw for draw
+// against the oracle at 1e-9, tests/test_gpu_depth.py, test_gpu_parity.py).
+#pragma once
+
+#define HBD_P 512
+#define HBD_SENT(x) (__double_as_longlong(x) == -1ll)
+
+template <bool LASSO>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_dense(const hb_sweep_in *__restrict__ pin, chain_view v,
+                                                                                                 persist_view pv, double *__restrict__ dd)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *dl = reinterpret_cast<double *>(smem); // [512] the panel's changes of effect, by marker
+    double *red = dl + HBD_P;                      // [16]
+    double *sabs = red + 16;                       // [2] sum |change| of the panel so far
+    int *misc = reinterpret_cast<int *>(sabs + 2); // [0] moves of the panel so far, [2] abort
+    constexpr int P = HBD_P;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int np = pv.npanels, D = pv.D;
+    const size_t PP = (size_t)P * P, pblk = (size_t)(pv.Lg + 1) * PP;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int count_pip = pin->count_pip, store = pin->store;
+    if (t < 8) misc[t] = 0;
+    if (t < 2) sabs[t] = 0.0;
+
+    double wacc = 0.0, mbr = v.mb ? v.mb[0] : 0.0, absd_grp = 0.0;
+    int nact = 0, evacc = 0, gcount = pv.p0 / D;
+    bool ok = true;
+
+    // per-marker data of the panel this wave handles next, and the diagonal block of its sub-block (column `lane`, rows 0..63)
+    double c_invv, c_sdz, c_gold, c_xx, c_thr;
+    int dg[64], bufA[64], bufB[64];
+    auto load_coeffs = [&](int pp) {
+        const size_t j = (size_t)pp * P + t;
+        c_invv = v.invv[j];
+        c_sdz = v.sdz[j];
+        c_gold = v.g[j];
+        c_xx = v.xpx[j];
+        c_thr = v.thr[j];
+    };
+    auto load_dg = [&](int pp) {
+        const int32_t *gp = v.gram + (size_t)pp * pblk + (size_t)(64 * wave) * P + 64 * wave + lane;
+#pragma unroll
+        for (int k = 0; k < 64; k++) dg[k] = gp[(size_t)k * P];
+    };
+    // strip rs of panel pp: rows 64 rs .. 64 rs + 63 of its Gram block, this thread's column
+#define HBD_REQUEST(BUF, pp, rs)                                                                 \
+    do {                                                                                         \
+        const int32_t *gp_ = v.gram + (size_t)(pp) * pblk + (size_t)(64 * (rs)) * P + t;         \
+        _Pragma("unroll") for (int k = 0; k < 64; k++) BUF[k] = gp_[(size_t)k * P];              \
+    } while (0)
+    load_coeffs(pv.p0);
+    load_dg(pv.p0);
+    if (wave > 0) HBD_REQUEST(bufA, pv.p0, 0);
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) dg[k] = lane > k ? dg[k] : 0;
+    }
+    __syncthreads();
+
+    for (int p = pv.p0; ok && p < np; p++) {
+        const size_t j = (size_t)p * P + t;
+        const bool group_end = ((p - pv.p0) % D == D - 1) || p == np - 1;
+        if (wave == 7 && p > pv.p0) {
+            // the previous panel's moves: every wave has drained its stores before that panel's last barrier; this one now
+            // drains its own and raises chain_done (the update rows of the group wait for it), then fetches what the others
+            // requested a panel ahead
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const bool prev_end = ((p - 1 - pv.p0) % D == D - 1);
+            if (prev_end && lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)p);
+            load_coeffs(p);
+            load_dg(p);
+        }
+        // ---- opening: the panel's dots and what the band owes it ----
+        const bool use_fc = p > pv.p0 && pv.Lb > 0;
+        double rhs;
+        {
+            const double *fcp = use_fc ? pv.fcorr : v.dsum;
+            double dj = ld_sc1(&v.dsum[j]), fc = ld_sc1(&fcp[j]);
+            bool bad = HBD_SENT(dj) || (use_fc && HBD_SENT(fc));
+            if (__any(bad)) {
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    dj = ld_sc1(&v.dsum[j]);
+                    fc = ld_sc1(&fcp[j]);
+                    bad = HBD_SENT(dj) || (use_fc && HBD_SENT(fc));
+                    if (!__any(bad)) break;
+                    if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
+                        if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); misc[2] = 1; }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            rhs = dj - (use_fc ? fc : 0.0);
+        }
+        const bool act = c_thr < 0.0; // -inf: in the model (always, for these models); +inf: monomorphic or padding (src/Bayes.cpp:589)
+        const double gold = c_gold, invv = c_invv, sdz = c_sdz;
+        if (gold != 0.0) rhs = fma(c_xx, gold, rhs); // :594 / :616 / :725
+        nact += act ? 1 : 0;
+        HB_STAMP(0);
+
+#define HBD_STEP(s, BUF)                                                                                                          \
+    do {                                                                                                                          \
+        if ((s) > 0 && wave >= (s)) { /* the changes of sub-block s - 1 onto the later markers of the panel */                    \
+            const double2 *d2_ = reinterpret_cast<const double2 *>(dl + 64 * ((s) - 1));                                          \
+            _Pragma("unroll") for (int k = 0; k < 64; k += 2) {                                                                   \
+                const double2 dk_ = d2_[k >> 1];                                                                                  \
+                rhs = fma(-(double)BUF[k], dk_.x, rhs);                                                                           \
+                rhs = fma(-(double)BUF[k + 1], dk_.y, rhs);                                                                       \
+            }                                                                                                                     \
+        }                                                                                                                         \
+        if ((s) == 7 && wave < 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this panel's stores of waves 0..6 */        \
+        {                                                                                                                         \
+            const int rs_ = ((s) + 1) & 7, pp_ = p + ((s) == 7 ? 1 : 0);                                                          \
+            if (rs_ != 7 && wave > rs_ && pp_ < np) HBD_REQUEST(BUF, pp_, rs_);                                                   \
+        }                                                                                                                         \
+        if (wave == (((s) + 1) & 7)) { /* the next serial wave prepares its diagonal block: row k only reaches the lanes after k */ \
+            _Pragma("unroll") for (int k = 0; k < 64; k++) dg[k] = lane > k ? dg[k] : 0;                                          \
+        }                                                                                                                         \
+        double gn_f = 0.0, dmine = 0.0;                                                                                           \
+        if (wave == (s)) {                                                                                                        \
+            double r_ = rhs;                                                                                                      \
+            _Pragma("unroll") for (int k = 0; k < 64; k++) {                                                                      \
+                double gn_ = fma(r_, invv, sdz);                                                                                  \
+                if (LASSO) gn_ = (act && fabs(gn_) < 1e-6) ? 1e-6 : gn_; /* :728 */                                               \
+                const double dk_ = readlane_f64(gn_ - gold, k);                                                                   \
+                r_ = fma(-(double)dg[k], dk_, r_);                                                                                \
+            }                                                                                                                     \
+            gn_f = fma(r_, invv, sdz); /* a lane's right-hand side is not touched after its own step */                           \
+            if (LASSO) gn_f = (act && fabs(gn_f) < 1e-6) ? 1e-6 : gn_f;                                                           \
+            if (!act) gn_f = 0.0;                                                                                                 \
+            dmine = act ? gn_f - gold : 0.0;                                                                                      \
+            dl[t] = dmine;                                                                                                        \
+            st_sc1(&dd[j], dmine); /* k_fold_dense is waiting for exactly this */                                                 \
+        }                                                                                                                         \
+        __syncthreads();                                                                                                          \
+        if ((s) == 0 && misc[2]) { ok = false; break; }                                                                           \
+        if (wave == (s)) { /* off the critical path: the move list, the results, next panel's requests */                         \
+            const unsigned long long moved_ = __ballot(dmine != 0.0);                                                             \
+            const int evb_ = (s) == 0 ? 0 : misc[0];                                                                              \
+            if (dmine != 0.0) {                                                                                                   \
+                const int pos_ = evb_ + __popcll(moved_ & lt);                                                                    \
+                st_sc1(&v.ev_idx[(size_t)p * P + pos_], t);                                                                       \
+                st_sc1(&v.ev_delta[(size_t)p * P + pos_], dmine);                                                                 \
+            }                                                                                                                     \
+            const double ab_ = wave_sum(fabs(dmine)) + ((s) == 0 ? 0.0 : sabs[0]);                                                \
+            const int nev_ = evb_ + __popcll(moved_);                                                                             \
+            if (lane == 0) { misc[0] = nev_; sabs[0] = ab_; }                                                                     \
+            if (gn_f != gold) v.g[j] = gn_f;                                                                                      \
+            v.tracker[j] = act ? (uint8_t)1 : (uint8_t)0;                                                                         \
+            if (count_pip && act) {                                                                                               \
+                __hip_atomic_fetch_add(&v.nzrate[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                             \
+                if (v.wind) v.wflag[v.wind[j] - 1u] = 1;                                                                          \
+            }                                                                                                                     \
+            if (store && gn_f != 0.0) {                                                                                           \
+                unsafeAtomicAdd(&v.alpha_sum[j], gn_f);                                                                           \
+                unsafeAtomicAdd(&v.alpha_sq[j], gn_f * gn_f);                                                                     \
+            }                                                                                                                     \
+            if (act) wacc += gn_f * gn_f;                                                                                         \
+            if ((s) == 7) {                                                                                                       \
+                if (lane == 0) st_sc1(&v.ev_count[p], nev_);                                                                      \
+                evacc += nev_;                                                                                                    \
+                absd_grp += ab_;                                                                                                  \
+                if (group_end) {                                                                                                  \
+                    if (v.mb) {                                                                                                   \
+                        mbr = fma(v.xabs, absd_grp, mbr);                                                                         \
+                        if (lane == 0) st_sc1(&v.mb[1 + gcount], mbr);                                                            \
+                    }                                                                                                             \
+                    absd_grp = 0.0;                                                                                               \
+                }                                                                                                                 \
+            } else if (p + 1 < np) {                                                                                              \
+                load_coeffs(p + 1);                                                                                               \
+                load_dg(p + 1);                                                                                                   \
+            }                                                                                                                     \
+        }                                                                                                                         \
+    } while (0)
+
+        // (strip s lives in bufA for even s, bufB for odd s: step s consumes strip s - 1 and requests strip s + 1 into the same registers)
+        HBD_STEP(0, bufB); if (!ok) break;
+        HBD_STEP(1, bufA);
+        HBD_STEP(2, bufB);
+        HBD_STEP(3, bufA);
+        HBD_STEP(4, bufB);
+        HBD_STEP(5, bufA);
+        HBD_STEP(6, bufB);
+        HBD_STEP(7, bufA);
+        if (group_end) gcount++;
+        HB_STAMP(1);
+    }
+#undef HBD_STEP
+#undef HBD_REQUEST
+
+    // ---- the last panel's moves: drain and publish ----
+    if (wave == 7 && ok) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)np);
+    }
+    // ---- sweep totals for the hyper-parameter draws (:603 g.g; class counts exclude monomorphic markers) ----
+    __syncthreads();
+    const double wsum = block_sum(wacc, red);
+    const double ev = block_sum((double)(lane == 0 ? evacc : 0), red);
+    const double na = block_sum((double)nact, red);
+    if (t == 0) {
+        v.acc[HB_ACC_SUMG2] += wsum;
+        v.acc[HB_ACC_EVENTS] += ev;
+        v.acc[HB_ACC_COUNT0 + 1] += na;
+        if (!ok) { // aborted: the host must see it (fetch_acc checks the flag), then release every waiter
+            st_flag(pv.flags + HB_FLAG_ABORT, 1u);
+            st_flag(pv.flags + HB_FLAG_CHAIN_DONE, 0x7fffffffu);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fold_dense: what the band owes a panel, summed by workgroups spread over the chip.
+// Target panel q is owed  fcorr[q P + c] = sum over the source panels p = q - l (l = 1 .. Lv D + q mod D: the panels whose moves
+// the mat-vec of q's group has not seen) of  sum_k G_l[q][k][c] delta_p[k].  Workgroup (tq, ch): the targets q = p0 + 1 + tq,
+// + LBW, + 2 LBW, ... (LBW = Lb targets are open at any time), columns 64 ch .. 64 ch + 63; wave w = rows 16 w .. 16 w + 15 of
+// every source sub-block of 64. The 16 Gram entries of the next sub-block are requested BEFORE the chain's changes are polled
+// (dd[] is sentinel-prefilled: every 8-byte value lands whole), so that what follows the arrival of a sub-block's changes is
+// 16 fused multiply-adds; after the last sub-block of panel q - 1 the four row quarters are added in order and the sum is written
+// through to fcorr[] — the chain polls it with the panel's dots.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view pv, const double *__restrict__ dd)
+{
+    __shared__ double part[4][64];
+    __shared__ int s_abort;
+    constexpr int P = HBD_P;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int LBW = pv.Lb, np = pv.npanels, D = pv.D;
+    if (LBW <= 0) return;
+    const int tq = blockIdx.x >> 3, ch = blockIdx.x & 7;
+    const size_t PP = (size_t)P * P, pblk = (size_t)(pv.Lg + 1) * PP;
+    if (t == 0) s_abort = 0;
+    __syncthreads();
+    for (int q = pv.p0 + 1 + tq; q < np; q += LBW) {
+        const int nsrc = min(pv.Lv * D + (q - pv.p0) % D, q - pv.p0); // source panels q - nsrc .. q - 1
+        double acc = 0.0;
+        const int nsteps = nsrc * 8;
+        int gv[16], gn[16];
+        auto request = [&](int st, int (&g)[16]) {
+            const int l = nsrc - (st >> 3), s = st & 7; // source panel q - l, its sub-block s
+            const int32_t *gp = v.gram + (size_t)q * pblk + (size_t)l * PP + (size_t)(64 * s + 16 * wave) * P + 64 * ch + lane;
+#pragma unroll
+            for (int i = 0; i < 16; i++) g[i] = gp[(size_t)i * P];
+        };
+        request(0, gv);
+        bool dead = false;
+        for (int st = 0; st < nsteps; st++) {
+            if (st + 1 < nsteps) request(st + 1, gn);
+            const int l = nsrc - (st >> 3), s = st & 7;
+            const double *dp = dd + (size_t)(q - l) * P + 64 * s + 16 * wave + (lane & 15);
+            double d = ld_sc1(dp);
+            if (__any(HBD_SENT(d))) {
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    d = ld_sc1(dp);
+                    if (!__any(HBD_SENT(d))) break;
+                    if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
+                        if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); s_abort = 1; }
+                        dead = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (dead) break;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc = fma((double)gv[i], readlane_f64(d, i), acc);
+#pragma unroll
+            for (int i = 0; i < 16; i++) gv[i] = gn[i];
+        }
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (s_abort) return;
+        if (wave == 0) st_sc1(&pv.fcorr[(size_t)q * P + 64 * ch + lane], ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
+        __syncthreads();
+    }
+}

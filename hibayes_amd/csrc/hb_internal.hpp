@@ -44,6 +44,7 @@ struct hb_ctx {
     int pipeline = 0;              // 0: serial kernels per panel; 1: persistent chain workgroup + flags
     int chain_kind = 1;            // group-granular chain (k_chain_group): bit 0 BayesB/C, bit 1 the dense models at one panel per group; 0 = k_chain_persist everywhere (HB_CHAIN=panel / all / <bits>)
     bool warm_group = false;       // k_warm beside the group chain (HB_WARM_GROUP=1)
+    bool dense_chain = true;       // BayesRR / A / L at panel 512: k_chain_dense + k_fold_dense (hb_chain_dense.hpp; HB_DENSE=0: k_chain_persist)
     bool fwd_group = true;         // k_fwd beside the group chain: a second workgroup folds a move's rows for the group after next (HB_FWD=0: off)
     bool concurrent = true;        // kernels on two streams were seen running at the same time (probe at create)
     std::string pipeline_note;     // why the persistent pipeline is off, when it is
@@ -98,6 +99,7 @@ struct hb_ctx {
     double *partial = nullptr;                              // nsplit x m_pad
     double *dsum = nullptr;                                 // m_pad: the partials added up (by the next mat-vec launch)
     double *fcorr = nullptr;                                // m_pad: k_fwd's corrections for the group after next (sentinel-prefilled like dsum)
+    double *ddense = nullptr;                               // m_pad: the dense chain's changes of effect by marker (k_chain_dense -> k_fold_dense; sentinel-prefilled)
     double *dots = nullptr;                                 // m_pad (hb_ctx_dot)
     int nchunks = 0, nsplit = 0;
     int32_t *ev_count = nullptr, *ev_idx = nullptr;

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
 // One workgroup (n is a few hundred KB).
 __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, unsigned *__restrict__ flags, int32_t *__restrict__ ev_count,
                                                     int np, unsigned long long *__restrict__ dsum, int m_pad, int p_lo,
-                                                    unsigned long long *__restrict__ fcorr)
+                                                    unsigned long long *__restrict__ fcorr, unsigned long long *__restrict__ dd)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (acc && i < HB_ACC_N) acc[i] = 0.0; // (null: a later range of the same sweep keeps the sums)
@@ -567,6 +567,8 @@ __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, un
     for (int k = i; k < m_pad; k += stride) dsum[k] = ~0ull;
     if (fcorr)
         for (int k = i; k < m_pad; k += stride) fcorr[k] = ~0ull;
+    if (dd)
+        for (int k = i; k < m_pad; k += stride) dd[k] = ~0ull;
 }
 
 __global__ __launch_bounds__(1024) void k_quant0(const double *__restrict__ r, int64_t ld, int8_t *__restrict__ rq,
@@ -2009,6 +2011,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 #include "hb_chain_group.hpp"
+#include "hb_chain_dense.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // k_warm: the chain workgroup's memory traffic, pulled into ITS L2 ahead of time by other compute units.
@@ -2506,6 +2509,8 @@ int hbk_init_attrs()
 #define HB_GROUP_ATTR(K1, DM, FW, CH) HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<K1, DM, FW, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     HB_GROUP_ATTR(1, 8, 14, 3); HB_GROUP_ATTR(1, 8, 7, 4); HB_GROUP_ATTR(1, 2, 4, 10); HB_GROUP_ATTR(1, 1, 2, 20);
     HB_GROUP_ATTR(3, 1, 2, 20); HB_GROUP_ATTR(7, 1, 2, 20);
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2921,9 +2926,13 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // one workgroup) beside k_pre / k_hotlist, which need all the other compute units. The chain must be launched BEFORE the
     // first mat-vec launch (it needs a compute unit with all of its LDS free, and back-to-back mat-vec launches never leave
     // one), so both branches start together after the join.
+    // the models in which every marker moves (BayesRR / A / L) at panel 512: k_chain_dense + k_fold_dense (hb_chain_dense.hpp)
+    const bool dense = kp == 1 && (model == 1 || model == 2 || model == 5) && c->P == 512 && c->dense_chain && !c->chain_alone &&
+                       getenv("HB_CHAIN_ALONE") == nullptr && c->L <= HB_LBMAX;
     hipLaunchKernelGGL(k_sweep_init, dim3(256), dim3(256), 0, sA, first ? c->acc : nullptr, c->flags, c->ev_count, c->npanels,
                        reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad, pb,
-                       c->fwd_group ? reinterpret_cast<unsigned long long *>(c->fcorr) : nullptr);
+                       (c->fwd_group || dense) ? reinterpret_cast<unsigned long long *>(c->fcorr) : nullptr,
+                       dense ? reinterpret_cast<unsigned long long *>(c->ddense) : nullptr);
     const bool fx = c->precise == 2;
     if (fx) {
         HB_HIP(hipEventRecord(c->ev_dot[0], sA));
@@ -2958,14 +2967,22 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // (chain_kind bit 0: BayesB / BayesC; bit 1: the dense models too — BayesR and RR / A / L at one panel per group)
     const int shape = (D <= 1 && Lv * D <= 2) ? 2 : (D <= 2 && Lv * D <= 4) ? 1 : (D <= 8 && Lv * D <= 14) ? 0 : (c->fwd_group && Lv == 3 && D == 7 && c->P == 512) ? 0 : -1;
     const bool sparse_model = kp == 1 && (model == 3 || model == 4);
-    const bool group_chain = shape >= 0 && !c->chain_alone && (sparse_model ? (c->chain_kind & 1) != 0 : ((c->chain_kind & 2) != 0 && shape == 2));
+    const bool group_chain = !dense && shape >= 0 && !c->chain_alone && (sparse_model ? (c->chain_kind & 1) != 0 : ((c->chain_kind & 2) != 0 && shape == 2));
     // k_fwd beside the wide group chain: the chain folds a move into its own group and the next (15 rows, four moves per trip),
     // a second workgroup into the group after that (HB_FWD=0: the chain does all 22 rows itself, three moves per trip)
     const bool fwd = group_chain && kp == 1 && (Lv == 2 || Lv == 3) && D == 7 && c->P == 512 && c->fwd_group && !alone;
     if (fwd) pv.fcorr = c->fcorr;
     if (c->L > HB_LBMAX && !fwd)
         return hb_fail(HB_ERR_UNSUPPORTED, "three groups of seven panels of look-ahead need the group chain with k_fwd (BayesB / BayesC, panel 512)");
+    if (dense) pv.fcorr = c->fcorr;
     auto launch_the_chain = [&](hipStream_t st) -> int {
+        if (dense) {
+            if (model == 5) hipLaunchKernelGGL((k_chain_dense<true>), dim3(1), dim3(512), persist_smem(c->P), st, c->d_in, cv, pv, c->ddense);
+            else hipLaunchKernelGGL((k_chain_dense<false>), dim3(1), dim3(512), persist_smem(c->P), st, c->d_in, cv, pv, c->ddense);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_dense launch: ") + hipGetErrorString(e));
+            return HB_OK;
+        }
         if (group_chain) {
             const size_t sm = persist_smem(c->P);
             if (fwd) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
@@ -2988,7 +3005,12 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // the L2 warmers (k_warm): a third branch of the graph, 4 workgroups per XCD of which only the chain's XCD's stay
     int warm = 4;
     if (const char *e = getenv("HB_WARM")) warm = std::max(0, std::min(16, atoi(e)));
-    if (alone || (group_chain && !c->warm_group) || fwd) warm = 0;
+    if (alone || (group_chain && !c->warm_group) || fwd || dense) warm = 0;
+    if (dense && c->L > 0) {
+        HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
+        hipLaunchKernelGGL(k_fold_dense, dim3(8 * c->L), dim3(256), 0, c->s_upd, cv, pv, c->ddense);
+        HB_HIP(hipGetLastError());
+    }
     if (fwd) {
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         if (Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
@@ -3025,7 +3047,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
                            make_upd(c, (g0 + h) * D, std::min(np, (g0 + h) * D + D), slot2(h - 1), slot2(h), c->flags, g0 + h));
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
-    if (warm || fwd) {
+    if (warm || fwd || (dense && c->L > 0)) {
         HB_HIP(hipEventRecord(c->ev_upd[0], c->s_upd));
         HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[0], 0));
     }
