@@ -43,6 +43,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int count_pip = pin->count_pip, store = pin->store;
     if (t < 8) misc[t] = 0;
     if (t < 2) sabs[t] = 0.0;
+    if (t == 0) { // "the chain is resident": k_gate holds the first mat-vec launch back until then
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        st_flag(pv.flags + HB_FLAG_XCC, (xcc & 15u) + 1u);
+    }
 
     double wacc = 0.0, mbr = v.mb ? v.mb[0] : 0.0, absd_grp = 0.0;
     int nact = 0, evacc = 0, gcount = pv.p0 / D;
@@ -82,16 +87,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int p = pv.p0; ok && p < np; p++) {
         const size_t j = (size_t)p * P + t;
         const bool group_end = ((p - pv.p0) % D == D - 1) || p == np - 1;
-        if (wave == 7 && p > pv.p0) {
-            // the previous panel's moves: every wave has drained its stores before that panel's last barrier; this one now
-            // drains its own and raises chain_done (the update rows of the group wait for it), then fetches what the others
-            // requested a panel ahead
+        if (p > pv.p0) {
+            // every wave drains the stores of the previous panel (its moves, results) before this panel's first barrier, after which
+            // the last wave raises chain_done for it — no wave ever waits for a store to reach memory on the critical path
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const bool prev_end = ((p - 1 - pv.p0) % D == D - 1);
-            if (prev_end && lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)p);
-            load_coeffs(p);
-            load_dg(p);
+            __syncthreads();
+            if (wave == 7) { // (the others requested these a panel ahead, right after their serial pass)
+                if (lane == 0 && ((p - 1 - pv.p0) % D == D - 1)) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)p);
+                load_coeffs(p);
+                load_dg(p);
+            }
+            if (wave > 0) HBD_REQUEST(bufA, p, 0);
         }
+        HB_STAMP(11);
         // ---- opening: the panel's dots and what the band owes it ----
         const bool use_fc = p > pv.p0 && pv.Lb > 0;
         double rhs;
@@ -99,21 +107,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const double *fcp = use_fc ? pv.fcorr : v.dsum;
             double dj = ld_sc1(&v.dsum[j]), fc = ld_sc1(&fcp[j]);
             bool bad = HBD_SENT(dj) || (use_fc && HBD_SENT(fc));
+#if HB_STAMPS
+            long long c12 = HBD_SENT(dj) ? 0 : 1;
+#endif
             if (__any(bad)) {
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
                     dj = ld_sc1(&v.dsum[j]);
                     fc = ld_sc1(&fcp[j]);
+#if HB_STAMPS
+                    if (v.dbg && t == 0 && !HBD_SENT(dj) && c12 == 0) c12 = clock64();
+#endif
                     bad = HBD_SENT(dj) || (use_fc && HBD_SENT(fc));
                     if (!__any(bad)) break;
-                    if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
+                    const bool own = wall_clock64() - t0 > HB_TIMEOUT_TICKS;
+                    if (ld_flag(pv.flags + HB_FLAG_ABORT) || own) {
                         if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); misc[2] = 1; }
+                        if (bad) { st_flag(pv.flags + 9, (unsigned)p + 1u); st_flag(pv.flags + 10, (HBD_SENT(dj) ? 1u : 2u) + (own ? 0x100u : 0u)); }
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
             rhs = dj - (use_fc ? fc : 0.0);
+#if HB_STAMPS
+            if (v.dbg && t == 0) v.dbg[(size_t)p * 32 + 12] = c12;
+#endif
         }
         const bool act = c_thr < 0.0; // -inf: in the model (always, for these models); +inf: monomorphic or padding (src/Bayes.cpp:589)
         const double gold = c_gold, invv = c_invv, sdz = c_sdz;
@@ -131,10 +150,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 rhs = fma(-(double)BUF[k + 1], dk_.y, rhs);                                                                       \
             }                                                                                                                     \
         }                                                                                                                         \
-        if ((s) == 7 && wave < 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this panel's stores of waves 0..6 */        \
         {                                                                                                                         \
-            const int rs_ = ((s) + 1) & 7, pp_ = p + ((s) == 7 ? 1 : 0);                                                          \
-            if (rs_ != 7 && wave > rs_ && pp_ < np) HBD_REQUEST(BUF, pp_, rs_);                                                   \
+            const int rs_ = (s) + 1;                                                                                              \
+            if (rs_ < 7 && wave > rs_) HBD_REQUEST(BUF, p, rs_);                                                                  \
         }                                                                                                                         \
         if (wave == (((s) + 1) & 7)) { /* the next serial wave prepares its diagonal block: row k only reaches the lanes after k */ \
             _Pragma("unroll") for (int k = 0; k < 64; k++) dg[k] = lane > k ? dg[k] : 0;                                          \
@@ -156,6 +174,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             st_sc1(&dd[j], dmine); /* k_fold_dense is waiting for exactly this */                                                 \
         }                                                                                                                         \
         __syncthreads();                                                                                                          \
+        HB_STAMP(2 + (s));                                                                                                        \
         if ((s) == 0 && misc[2]) { ok = false; break; }                                                                           \
         if (wave == (s)) { /* off the critical path: the move list, the results, next panel's requests */                         \
             const unsigned long long moved_ = __ballot(dmine != 0.0);                                                             \
@@ -206,6 +225,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         HBD_STEP(5, bufA);
         HBD_STEP(6, bufB);
         HBD_STEP(7, bufA);
+        if (t == 0 && p == pv.p0) { const unsigned long long now = wall_clock64(); st_flag(pv.flags + 16, (unsigned)now); st_flag(pv.flags + 17, (unsigned)(now >> 32)); }
         if (group_end) gcount++;
         HB_STAMP(1);
     }
@@ -213,12 +233,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef HBD_REQUEST
 
     // ---- the last panel's moves: drain and publish ----
-    if (wave == 7 && ok) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)np);
-    }
-    // ---- sweep totals for the hyper-parameter draws (:603 g.g; class counts exclude monomorphic markers) ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (wave == 7 && ok && lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)np);
+    // ---- sweep totals for the hyper-parameter draws (:603 g.g; class counts exclude monomorphic markers) ----
     const double wsum = block_sum(wacc, red);
     const double ev = block_sum((double)(lane == 0 ? evacc : 0), red);
     const double na = block_sum((double)nact, red);
@@ -253,7 +271,7 @@ __global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view p
     if (LBW <= 0) return;
     const int tq = blockIdx.x >> 3, ch = blockIdx.x & 7;
     const size_t PP = (size_t)P * P, pblk = (size_t)(pv.Lg + 1) * PP;
-    if (t == 0) s_abort = 0;
+    if (t == 0) { s_abort = 0; atomicAdd(pv.flags + 13, 1u); }
     __syncthreads();
     for (int q = pv.p0 + 1 + tq; q < np; q += LBW) {
         const int nsrc = min(pv.Lv * D + (q - pv.p0) % D, q - pv.p0); // source panels q - nsrc .. q - 1
@@ -266,36 +284,49 @@ __global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view p
 #pragma unroll
             for (int i = 0; i < 16; i++) g[i] = gp[(size_t)i * P];
         };
+        auto dptr = [&](int st) {
+            const int l = nsrc - (st >> 3), s = st & 7;
+            return dd + (size_t)(q - l) * P + 64 * s + 16 * wave + (lane & 15);
+        };
         request(0, gv);
+        double d = ld_sc1(dptr(0));
         bool dead = false;
         for (int st = 0; st < nsteps; st++) {
-            if (st + 1 < nsteps) request(st + 1, gn);
-            const int l = nsrc - (st >> 3), s = st & 7;
-            const double *dp = dd + (size_t)(q - l) * P + 64 * s + 16 * wave + (lane & 15);
-            double d = ld_sc1(dp);
+            // the next step's Gram entries AND its changes are requested before this step's are looked at: a step whose changes
+            // were already published costs no round trip of its own (a target's first source panels are complete when it starts)
+            const int stn = min(st + 1, nsteps - 1);
+            request(stn, gn);
+            double dn = ld_sc1(dptr(stn));
             if (__any(HBD_SENT(d))) {
+                const double *dp = dptr(st);
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
                     d = ld_sc1(dp);
                     if (!__any(HBD_SENT(d))) break;
-                    if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
-                        if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); s_abort = 1; }
+                    const bool own = wall_clock64() - t0 > HB_TIMEOUT_TICKS;
+                    if (ld_flag(pv.flags + HB_FLAG_ABORT) || own) {
+                        if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); s_abort = 1; st_flag(pv.flags + 11, (unsigned)q + 1u); st_flag(pv.flags + 12, (unsigned)st + (own ? 0x100u : 0u));
+                            if (own) { const unsigned long long now = wall_clock64(); st_flag(pv.flags + 20, (unsigned)now); st_flag(pv.flags + 21, (unsigned)(now >> 32)); st_flag(pv.flags + 22, (unsigned)t0); st_flag(pv.flags + 23, (unsigned)(t0 >> 32));
+                                       st_flag(pv.flags + 24, (unsigned)__double_as_longlong(d)); st_flag(pv.flags + 25, (unsigned)(__double_as_longlong(d) >> 32)); st_flag(pv.flags + 26, (unsigned)(dp - dd)); } }
                         dead = true;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (st + 1 < nsteps) dn = ld_sc1(dptr(st + 1)); // (looked at before this step was there: likely stale)
             }
             if (dead) break;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc = fma((double)gv[i], readlane_f64(d, i), acc);
 #pragma unroll
             for (int i = 0; i < 16; i++) gv[i] = gn[i];
+            d = dn;
         }
         part[wave][lane] = acc;
         __syncthreads();
         if (s_abort) return;
         if (wave == 0) st_sc1(&pv.fcorr[(size_t)q * P + 64 * ch + lane], ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
+        if (t == 0) atomicAdd(pv.flags + 14, 1u);
         __syncthreads();
     }
 }

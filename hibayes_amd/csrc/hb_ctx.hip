@@ -216,7 +216,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     {
         hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&c->h_acc), sizeof(double) * HB_ACC_N);
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_in), sizeof(hb_sweep_in));
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_flags), 64);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_flags), 256);
         if (e != hipSuccess) {
             hb_ctx_destroy(c);
             return hb_fail(HB_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
@@ -761,10 +761,27 @@ int hb_ctx_matmul(hb_ctx *c, const double *A, int64_t ldA, int32_t R, double *ou
 static int fetch_acc(hb_ctx *c)
 {
     HB_HIP(hipMemcpyAsync(c->h_acc, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToHost, c->stream));
-    HB_HIP(hipMemcpyAsync(c->h_flags, c->flags, 16, hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipMemcpyAsync(c->h_flags, c->flags, 256, hipMemcpyDeviceToHost, c->stream));
     if (c->blk_n) HB_HIP(hipMemcpyAsync(c->h_blk, c->blk, sizeof(double) * c->blk_n, hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
-    if (c->h_flags[1]) return hb_fail(HB_ERR_HIP, "device pipeline timed out waiting on a flag (sweep aborted)");
+    if (c->h_flags[1]) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "device pipeline timed out waiting on a flag (sweep aborted) [chain_done %u; gave up: update rows waiting for %u, chain at panel %u (%u), fold at panel %u step %u, fold workgroups started %u, targets delivered %u]",
+                 c->h_flags[0], c->h_flags[8], c->h_flags[9], c->h_flags[10], c->h_flags[11], c->h_flags[12], c->h_flags[13], c->h_flags[14]);
+        if (getenv("HB_DEBUG_ABORT")) {
+            const unsigned *f = c->h_flags;
+            fprintf(stderr, "abort clocks (100 MHz): chain finished its first panel at %llu; fold gave up at %llu after waiting since %llu; it last read %08x%08x at dd[%u]\n",
+                    ((unsigned long long)f[17] << 32) | f[16], ((unsigned long long)f[21] << 32) | f[20], ((unsigned long long)f[23] << 32) | f[22], f[25], f[24], f[26]);
+            unsigned long long w[9];
+            int evc[4] = {0, 0, 0, 0};
+            const double *src[9] = {c->ddense, c->ddense + 64, c->ddense + 512, c->fcorr + 512, c->fcorr + 1024, c->dsum, c->dsum + 512, c->dsum + 1024, c->dsum + 1536};
+            for (int i = 0; i < 9; i++) (void)hipMemcpy(&w[i], src[i], 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(evc, c->ev_count, 16, hipMemcpyDeviceToHost);
+            fprintf(stderr, "abort state: dd[0] %llx dd[64] %llx dd[512] %llx fcorr[512] %llx fcorr[1024] %llx dsum[0,512,1024,1536] %llx %llx %llx %llx ev_count %d %d %d %d\n",
+                    w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], evc[0], evc[1], evc[2], evc[3]);
+        }
+        return hb_fail(HB_ERR_HIP, msg);
+    }
     return HB_OK;
 }
 

@@ -135,11 +135,12 @@ __global__ __launch_bounds__(64) void k_dotq2(dq_view v, upd_view uq)
     unsigned long long t0 = 0;
     if (v.stamp) t0 = wall_clock64();
     int b = blockIdx.x;
-    if (b < v.nupd) { // residual update of an earlier group (2-bit columns: upd_view.X2), lists staged in the tile buffers
-        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096));
-    } else if (b < v.nupd + v.nfin) {
-        const int col = (b - v.nupd) * 64 + threadIdx.x;
+    if (b < v.nfin) { // (finalize blocks first: see dotq_block)
+        const int col = b * 64 + threadIdx.x;
         if (col < v.fin_ncols) hbq_finalize(v.fin_acc, v.accstride, col, *v.fin_exp, v.fin_out);
+    } else if (b < v.nfin + v.nupd) { // residual update of an earlier group (2-bit columns: upd_view.X2), lists staged in the tile buffers
+        b -= v.nfin;
+        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096));
     } else {
         dotq2_tile<CPL, RS>(v, smem, b - v.nupd - v.nfin);
     }
@@ -265,11 +266,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     unsigned long long t0 = 0;
     if (v.stamp) t0 = wall_clock64();
     int b = blockIdx.x;
-    if (b < v.nupd) {
-        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096));
-    } else if (b < v.nupd + v.nfin) {
-        const int col = (b - v.nupd) * 64 + threadIdx.x;
+    if (b < v.nfin) {
+        const int col = b * 64 + threadIdx.x;
         if (col < v.fin_ncols) hbq_finalize(v.fin_acc, v.accstride, col, *v.fin_exp, v.fin_out);
+    } else if (b < v.nfin + v.nupd) {
+        b -= v.nfin;
+        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096));
     } else {
         dotq2r_tile(v, b - v.nupd - v.nfin);
     }

@@ -38,6 +38,7 @@ __device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store
 __device__ __forceinline__ void st_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // one lane waits until *word >= want; bounded; returns false when the run is being aborted
+template <int SLEEP = 8>
 __device__ __forceinline__ bool wait_ge(unsigned *flags, int word, unsigned want)
 {
     const unsigned long long t0 = wall_clock64();
@@ -46,9 +47,10 @@ __device__ __forceinline__ bool wait_ge(unsigned *flags, int word, unsigned want
         if (ld_flag(flags + HB_FLAG_ABORT)) return false;
         if (wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
             st_flag(flags + HB_FLAG_ABORT, 1u);
+            st_flag(flags + 8, want); // (diagnostics: who gave up, hb_ctx.hip fetch_acc)
             return false;
         }
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(SLEEP);
     }
 }
 
@@ -157,6 +159,7 @@ struct upd_view {
     int *vexp_out;               // exponent of the output slot
     const uint32_t *X2;          // non-null: the genotypes in the 2-bit resident layout (hb_dotq2.hpp), ld2w words per column
     int64_t ld2w;
+    int dense;                   // (nearly) every marker of a panel moves (BayesRR / A / L): one row per lane, 64 rows per wave (update_rows_dense)
 };
 
 // four consecutive individuals (row0 a multiple of 4) of one column, one genotype per byte: from the int8 matrix, or expanded in
@@ -243,7 +246,8 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
         __syncthreads();
         if (!mine) continue;
         const int64_t col0 = (int64_t)p * q.P;
-        for (int e = 0; e < nev; e += 8) {
+        int e = 0;
+        for (; e < nev; e += 8) {
             int w[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) w[k] = hb_ld4(q.X, ld, q.X2, q.ld2w, col0 + s_ix[min(e + k, nev - 1)], row0);
@@ -268,6 +272,111 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
         *reinterpret_cast<double2 *>(q.u + row0) = u01;
         *reinterpret_cast<double2 *>(q.u + row0 + 2) = u23;
     }
+}
+
+// The same update where (nearly) every marker of a panel moved (BayesRR / A / L: a second pass over the panel's genotypes).
+// A mat-vec launch has ONE update wave per 256 rows with update_rows, and such a wave walks the panel in batches of a few loads
+// per lane, one loaded memory round trip (~3 us beside the streaming tiles) per batch: measured 60-77 us per panel of 512 at
+// n = 50k with 8 or 32 loads in flight, software-pipelined or not, and the same with one row per lane and 32 byte loads in
+// flight (16 round trips). Here a wave owns 64 rows and fetches its whole 64 x 512 slab of genotypes — 32 KB — into LDS with 32
+// LDS-DMA instructions that are ALL in flight together (global_load_lds_dwordx4: lane l brings rows 16 (l & 3) .. + 15 of moved
+// column 16 i + l / 4, so piece i is 16 columns x 64 rows): one round trip, then one sign-extending LDS byte read, one convert and
+// one fused multiply-add per column, lane = row. Blocks b and b + 8 — the same XCD under round-robin dispatch — take the two
+// halves of the same 128-byte lines. Same sums in the same order as update_rows: the same residual bit for bit.
+// The slab travels in chunks of 128 columns through two 8-KB buffers (24 KB of LDS per block in all, so that a launch's update
+// blocks and tiles are all resident): the first two chunks are in flight together, the others land under the arithmetic.
+// smem: [0, 2048) move indices, [2048, 6144) changes, [6144, 6160) flags, [HBU_SLAB, HBU_SLAB + 16384) two chunk buffers.
+#define HBU_SLAB 8192
+#define HBU_LDS (HBU_SLAB + 16384)
+__device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q, int blk, int nblk, char *smem)
+{
+    int *s_ix = reinterpret_cast<int *>(smem);
+    double *s_dl = reinterpret_cast<double *>(smem + 2048);
+    int *s_ok = reinterpret_cast<int *>(smem + 6144);
+    const signed char *slab = reinterpret_cast<const signed char *>(smem + HBU_SLAB);
+    const unsigned slab_lds = (unsigned)(uintptr_t)(smem + HBU_SLAB);
+    const int lane = threadIdx.x;
+    const int full = nblk & ~15;
+    const int rc = blk < full ? (blk & ~15) + ((blk & 7) << 1) + ((blk >> 3) & 1) : blk;
+    const int64_t row0 = (int64_t)rc * 64, row = row0 + lane;
+    double r0 = q.r_in[row], u0 = q.u[row];
+    if (q.flags) {
+        if (lane == 0) *s_ok = wait_ge(q.flags, HB_FLAG_CHAIN_DONE, (unsigned)q.p1) ? 1 : 0;
+        __syncthreads();
+        if (!*s_ok) return;
+    }
+    int fixE = 0;
+    if (q.rq) {
+        __syncthreads();
+        if (lane == 0) s_ok[1] = hb_fix_exp(ld_sc1(q.mbv));
+        __syncthreads();
+        fixE = s_ok[1];
+        if (blk == 0 && lane == 0) *q.vexp_out = fixE;
+    }
+    double a = 0.0;
+    int total = 0;
+    for (int p = q.p0; p < q.p1; p++) {
+        const int nev = ld_sc1(q.ev_count + p);
+        if (nev == 0) continue;
+        total += nev;
+        __syncthreads();
+        for (int e = lane; e < nev; e += 64) {
+            s_ix[e] = ld_sc1(q.ev_idx + (size_t)p * q.P + e);
+            s_dl[e] = ld_sc1(q.ev_delta + (size_t)p * q.P + e);
+        }
+        __syncthreads();
+        const int8_t *xp = q.X + (int64_t)p * q.P * ld + row0 + (lane & 3) * 16;
+        // chunks of 128 moved columns (8 pieces of 1 KiB, always 8: a short chunk repeats its last column, so that the waits
+        // can be counted), two buffers: chunk c + 2 is requested into the buffer chunk c has just been read from
+        const int nch = (nev + 127) >> 7;
+        auto issue = [&](int ch) {
+            const unsigned dst = slab_lds + (unsigned)(ch & 1) * 8192u;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int8_t *src = xp + (int64_t)s_ix[min(128 * ch + 16 * i + (lane >> 2), nev - 1)] * ld;
+                unsigned keep; // (M0, the LDS destination base, is compiler-reserved: set and restored inside the statement)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src), "s"(dst + (unsigned)i * 1024u)
+                             : "memory");
+            }
+        };
+        issue(0);
+        if (nch > 1) issue(1);
+        for (int ch = 0; ch < nch; ch++) {
+            if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const signed char *sl = slab + (ch & 1) * 8192 + lane;
+            const int e0 = ch << 7, ne = min(128, nev - e0);
+            int e = 0;
+            for (; e + 8 <= ne; e += 8) {
+                int w[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) w[k] = sl[(e + k) * 64];
+#pragma unroll
+                for (int k = 0; k < 8; k++) a = fma((double)w[k], s_dl[e0 + e + k], a);
+            }
+            for (; e < ne; e++) a = fma((double)sl[e * 64], s_dl[e0 + e], a);
+            if (ch + 2 < nch) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (every read of this buffer has returned)
+                issue(ch + 2);
+            }
+        }
+    }
+    if (total == 0 && q.r_in == q.r) return;
+    r0 -= a;
+    q.r[row] = r0;
+    q.r32[row] = (float)r0;
+    if (q.rq) { // balanced base-256 digits of rint(yadj 2^E), one byte per plane (hb_store_digits for one row)
+        long long qv = __double2ll_rn(ldexp(r0, fixE));
+#pragma unroll
+        for (int k = 0; k < HB_ND; k++) {
+            const int d = (k == HB_ND - 1) ? (int)qv : (int)(int8_t)(qv & 0xff);
+            qv = (qv - d) >> 8;
+            q.rq[(int64_t)k * ld + row] = (int8_t)d;
+        }
+    }
+    if (total) q.u[row] = u0 + a;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,8 +517,8 @@ __global__ __launch_bounds__(256) void k_dot(const int8_t *__restrict__ X, int64
 // vector-memory queue); a lane reads its own column with ds_read_b128 and the digits with wave-uniform (broadcast)
 // ds_read_b128. No cross-lane reduction anywhere. The slot stride of 1040 bytes rotates the LDS banks between the
 // eight DMA pieces of a stage.
-// Block roles by index: [0, nupd) residual update of an earlier group (its digits included), [nupd, nupd + nfin)
-// finalize the previous launch's columns into dsum[], then the tiles.
+// Block roles by index: [0, nfin) finalize the previous launch's columns into dsum[], [nfin, nfin + nupd) residual update of an
+// earlier group (its digits included), then the tiles.
 // ---------------------------------------------------------------------------------------------
 typedef int hb_v4i __attribute__((ext_vector_type(4)));
 #define HBQ_RS 128                       /* rows per stage */
@@ -474,18 +583,22 @@ __device__ __forceinline__ void dotq_block(const dq_view &v, const upd_view &uq,
 {
     const int lane = threadIdx.x;
     int b = blockIdx.x;
-    if (b < v.nupd) { // residual update of an earlier group: 256 rows per block, lists staged in the (unused) tile buffers
-        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048),
-                    reinterpret_cast<int *>(smem + 2048 + 4096));
-        return;
-    }
-    b -= v.nupd;
+    // (the finalize blocks come FIRST: the chain workgroup is waiting for their sums, and the update blocks behind them wait for
+    // the chain — with one update wave per 64 rows they can fill every slot of the chip, and a finalize block queued behind them
+    // would never start)
     if (b < v.nfin) {
         const int col = b * 64 + lane;
         if (col < v.fin_ncols) hbq_finalize(v.fin_acc, v.accstride, col, *v.fin_exp, v.fin_out);
         return;
     }
     b -= v.nfin;
+    if (b < v.nupd) { // residual update of an earlier group: 256 rows per block (64 where every marker moves), lists staged in the (unused) tile buffers
+        if (uq.dense) update_rows_dense(v.ld, uq, b, v.nupd, smem); // (launched with HBU_LDS bytes of dynamic LDS)
+        else update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048),
+                         reinterpret_cast<int *>(smem + 2048 + 4096));
+        return;
+    }
+    b -= v.nupd;
     const int cg = b % v.ncg, sp = b / v.ncg;
     if (b == 0 && lane == 0) *v.gexp_out = *v.vexp_in;
     const int st0 = sp * v.NS, st1 = min(v.nstages, st0 + v.NS);
@@ -2013,6 +2126,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #include "hb_chain_group.hpp"
 #include "hb_chain_dense.hpp"
 
+// k_gate: one lane on the mat-vec stream, ahead of the sweep's first launch, that waits until the chain workgroup is resident
+// (it publishes HB_FLAG_XCC as its first act). The chain needs a compute unit with ALL of its LDS free; it is launched first,
+// but the graph's branches start together, and once mat-vec blocks have touched every compute unit it only gets one when a
+// compute unit drains completely — which never happens where a launch's update blocks, one per 64 rows, sit on every compute
+// unit waiting for the chain (measured: the sweep then times out; with fewer update blocks than compute units the late start
+// went unnoticed). While this lane waits the chip is empty, so the chain starts at once.
+__global__ void k_gate(unsigned *flags)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (ld_flag(flags + HB_FLAG_XCC) == 0u) {
+        if (ld_flag(flags + HB_FLAG_ABORT)) return;
+        if (wall_clock64() - t0 > HB_TIMEOUT_TICKS) { st_flag(flags + HB_FLAG_ABORT, 1u); return; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_warm: the chain workgroup's memory traffic, pulled into ITS L2 ahead of time by other compute units.
 // One compute unit gets ~18 bytes per clock out of HBM however many loads it keeps in flight (its miss queue is the limit;
@@ -2098,6 +2228,12 @@ __global__ __launch_bounds__(256) void k_warm(persist_view pv, chain_view v, int
 // thread = 4 consecutive rows; the event list is staged in LDS once, then the column loads of 8
 // events are in flight together.
 // ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_update_dense(int64_t ld, upd_view q)
+{
+    __shared__ __attribute__((aligned(16))) char smem[HBU_LDS];
+    update_rows_dense(ld, q, blockIdx.x, gridDim.x, smem);
+}
+
 __global__ __launch_bounds__(256) void k_update(int64_t ld, upd_view q)
 {
     __shared__ int s_ix[512];
@@ -2564,7 +2700,7 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
             v.NS = NC;
             v.ncg = ncols / NC;
             v.nstages = (int)((c->ld2 * 4 + Q2R_RB - 1) / Q2R_RB);
-            v.nupd = (uq.p1 > uq.p0) ? (int)(c->ld / 256) : 0;
+            v.nupd = (uq.p1 > uq.p0) ? (int)(c->ld / (uq.dense ? 64 : 256)) : 0;
             v.nfin = fin_ncols > 0 ? (fin_ncols + 63) / 64 : 0;
             v.fin_acc = c->accq + fin_col0;
             v.fin_out = c->dsum + fin_col0;
@@ -2603,7 +2739,7 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     v.nstages = nst;
     v.NS = NS;
     v.ncg = ncg;
-    v.nupd = (uq.p1 > uq.p0) ? (int)(c->ld / 256) : 0;
+    v.nupd = (uq.p1 > uq.p0) ? (int)(c->ld / (uq.dense ? 64 : 256)) : 0;
     v.nfin = fin_ncols > 0 ? (fin_ncols + 63) / 64 : 0;
     v.fin_acc = c->accq + fin_col0;
     v.fin_out = c->dsum + fin_col0;
@@ -2645,7 +2781,7 @@ static void launch_dotq(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st
     v.nstages = (int)(c->ld / HBQ_RS);
     v.NS = NS;
     v.ncg = ncg;
-    v.nupd = (uq.p1 > uq.p0) ? (int)(c->ld / 256) : 0;
+    v.nupd = (uq.p1 > uq.p0) ? (int)(c->ld / (uq.dense ? 64 : 256)) : 0;
     v.nfin = fin_ncols > 0 ? (fin_ncols + 63) / 64 : 0;
     v.fin_acc = c->accq + fin_col0;
     v.fin_out = c->dsum + fin_col0;
@@ -2658,7 +2794,7 @@ static void launch_dotq(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st
         c->lstamp_nblk[gidx] = nblk;
         c->lstamp_cols[gidx] = ncols;
     }
-    hipLaunchKernelGGL(k_dotq, dim3(nblk), dim3(64), HBQ_LDS, st, v, uq);
+    hipLaunchKernelGGL(k_dotq, dim3(nblk), dim3(64), uq.dense ? HBU_LDS : HBQ_LDS, st, v, uq);
 }
 
 static void launch_dot(hb_ctx *c, int col0, int ncols, int slot = 0, hipStream_t st = nullptr, bool pipeline = false,
@@ -2745,7 +2881,7 @@ static upd_view make_upd(hb_ctx *c, int p0, int p1, int sin, int sout, unsigned 
     return upd_view{c->X, c->P, p0, p1, c->ev_count, c->ev_idx, c->ev_delta, c->r + (size_t)sin * c->ld,
                     c->r + (size_t)sout * c->ld, c->u, c->r32 + (size_t)sout * c->ld, flags,
                     fx ? c->rq + (size_t)sout * HB_ND * c->ld : nullptr, c->mb + 1 + mbi, c->vexp + sout,
-                    c->layout == 2 ? c->X2 : nullptr, c->ld2 / 4};
+                    c->layout == 2 ? c->X2 : nullptr, c->ld2 / 4, 0};
 }
 
 struct phase_timer {
@@ -2929,6 +3065,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // the models in which every marker moves (BayesRR / A / L) at panel 512: k_chain_dense + k_fold_dense (hb_chain_dense.hpp)
     const bool dense = kp == 1 && (model == 1 || model == 2 || model == 5) && c->P == 512 && c->dense_chain && !c->chain_alone &&
                        getenv("HB_CHAIN_ALONE") == nullptr && c->L <= HB_LBMAX;
+    const bool dense_upd = dense && getenv("HB_DENSE_UPD") == nullptr;
     hipLaunchKernelGGL(k_sweep_init, dim3(256), dim3(256), 0, sA, first ? c->acc : nullptr, c->flags, c->ev_count, c->npanels,
                        reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad, pb,
                        (c->fwd_group || dense) ? reinterpret_cast<unsigned long long *>(c->fcorr) : nullptr,
@@ -3001,7 +3138,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         return HB_OK;
     };
     if (alone) HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->flags + HB_FLAG_CHAIN_DONE), 0x7ffffff0, 1, sA));
-    else if (int rc = launch_the_chain(sB)) return rc;
+    else {
+        if (int rc = launch_the_chain(sB)) return rc;
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sA, c->flags); // (the first mat-vec launch starts when the chain is resident)
+    }
     // the L2 warmers (k_warm): a third branch of the graph, 4 workgroups per XCD of which only the chain's XCD's stay
     int warm = 4;
     if (const char *e = getenv("HB_WARM")) warm = std::max(0, std::min(16, atoi(e)));
@@ -3036,15 +3176,20 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         const int h = g - Lv, ha = g0 + h;
         upd_view uq{};
         if (h >= 0) uq = make_upd(c, ha * D, std::min(np, ha * D + D), slot2(h - 1), slot2(h), c->flags, ha);
+        uq.dense = (dense_upd && fx && c->layout == 8) ? 1 : 0; // (one row per lane where every marker moved; the fixed-point mat-vec's single-wave update blocks)
         launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, true, h >= 0 ? &uq : nullptr,
                    g > 0 ? (ga - 1) * D * c->P : 0, g > 0 ? D * c->P : 0, ga);
     }
     launch_reduce(c, (g0 + ngroups - 1) * D * c->P, last_panels * c->P, sA, g0 + ngroups - 1);
     if (alone)
         if (int rc = launch_the_chain(sA)) return rc;
-    for (int h = std::max(0, ngroups - Lv); h < ngroups; h++) // the updates that had no later mat-vec to ride on
-        hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sA, c->ld,
-                           make_upd(c, (g0 + h) * D, std::min(np, (g0 + h) * D + D), slot2(h - 1), slot2(h), c->flags, g0 + h));
+    for (int h = std::max(0, ngroups - Lv); h < ngroups; h++) { // the updates that had no later mat-vec to ride on
+        upd_view uq = make_upd(c, (g0 + h) * D, std::min(np, (g0 + h) * D + D), slot2(h - 1), slot2(h), c->flags, g0 + h);
+        if (dense_upd && c->layout == 8) {
+            uq.dense = 1;
+            hipLaunchKernelGGL(k_update_dense, dim3((unsigned)(c->ld / 64)), dim3(64), 0, sA, c->ld, uq);
+        } else hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sA, c->ld, uq);
+    }
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
     if (warm || fwd || (dense && c->L > 0)) {

@@ -15,7 +15,7 @@ Pi, fold = ([0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2]) if model == "BayesR
 a = BayesArgs(); a.n, a.m = n, m; yv = np.ascontiguousarray(y); a.y = yv.ctypes.data; a.model = model.encode()
 pv = np.array(Pi); a.Pi, a.n_pi = pv.ctypes.data, pv.size
 if fold: fv = np.array(fold, dtype=float); a.fold, a.n_fold = fv.ctypes.data, fv.size
-a.niter, a.nburn, a.thin = burn + (K + 20) * len(geos) * 12 + 5, 0, 5; a.seed = 1; a.ctx = c.h
+a.precise = int(os.environ.get("PRECISE", "2")); a.niter, a.nburn, a.thin = burn + (K + 20) * len(geos) * 12 + 5, 0, 5; a.seed = 1; a.ctx = c.h
 run = ct.c_void_p(); check(c.L.hb_run_create(ct.byref(a), ct.byref(run)))
 fin = ct.c_int32(); info = RunInfo()
 t0 = time.time(); check(c.L.hb_run_step(run, burn, ct.byref(fin))); print("burn %d sweeps %.1f s" % (burn, time.time() - t0), flush=True)

@@ -50,7 +50,7 @@ with H.Context(n, m, seed=20240901) as c:
         a = buf[:2 * k].reshape(k, 2).astype(np.int64)
         ok = a[:, 0] > 0
         s0 = a[ok, 0].min()
-        up, fi, ti = a[:nupd][ok[:nupd]], a[nupd:nupd + nfin][ok[nupd:nupd + nfin]], a[nupd + nfin:][ok[nupd + nfin:]]
+        fi, up, ti = a[:nfin][ok[:nfin]], a[nfin:nfin + nupd][ok[nfin:nfin + nupd]], a[nupd + nfin:][ok[nupd + nfin:]]  # (block roles by index: finalize, update, tiles)
         rows.append((s0, up[:, 1].max() - s0 if len(up) else 0, (up[:, 1] - up[:, 0]).mean() if len(up) else 0, fi[:, 1].max() - s0 if len(fi) else 0,
                      ti[:, 1].max() - s0, np.percentile(ti[:, 1] - s0, 50), (ti[:, 1] - ti[:, 0]).mean(), a[ok, 1].max(), ti[:, 0].max() - s0))
     r = np.array(rows, dtype=np.float64)
