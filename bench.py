@@ -56,6 +56,7 @@ def parse():
                          "(hb_comm_*); torch = torch.distributed callback (host-synchronous; also the fall-back)")
     ap.add_argument("--model", default="BayesCpi", help="BASELINE.json north_star target: BayesCpi at n=50k, m=500k")
     ap.add_argument("--secondary", default="BayesR", help="second model measured on the same genotypes ('' = none)")
+    ap.add_argument("--tertiary", default="BayesRR", help="a model in which every marker moves every sweep (BayesRR / A / L), reported under 'all_move' ('' = none)")
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--precise", type=int, default=2,
                     help="panel mat-vec arithmetic: 2 = exact fixed point (7 int8 digit planes of the fp64 residual, int32 dot4 "
@@ -196,7 +197,7 @@ def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8):
 
 PIPELINE = {  # (pipeline, look-ahead groups, panels per mat-vec launch): see DESIGN.md §2
     "BayesCpi": (1, 3, 7), "BayesC": (1, 3, 7), "BayesB": (1, 3, 7), "BayesBpi": (1, 3, 7),
-    "BayesR": (1, 2, 1), "BayesRR": (1, 2, 1), "BayesA": (1, 2, 1), "BayesL": (1, 2, 1),
+    "BayesR": (1, 2, 1), "BayesRR": (1, 2, 2), "BayesA": (1, 2, 2), "BayesL": (1, 2, 2),   # (RR / A / L at panel 512: k_chain_dense, hb_run's own choice)
 }
 
 
@@ -451,33 +452,39 @@ def main():
         "roofline": roof,
         "regime_curve": curve_main,   # sweeps/s is set by the serial chain, i.e. by how many markers change per sweep
     }
-    if args.secondary and args.secondary != args.model and world == 1:
-        # the other model family of BASELINE.json's configs on the same genotypes, shorter run
-        geo2 = PIPELINE.get(args.secondary, (1, 1, 1))
+    sides = [(args.secondary, "secondary", args.burnin_secondary, max(10, K // 4), max(5, min(W, 30))),
+             (args.tertiary, "all_move", 20, max(10, K // 8), 5)]
+    for side, key, burn_s, K2, W2 in sides:
+        if not side or side == args.model or world != 1 or (key == "all_move" and side == args.secondary):
+            continue
+        # the other model families of BASELINE.json's configs on the same genotypes, shorter runs
+        geo2 = PIPELINE.get(side, (1, 1, 1))
         ctx.set_pipeline(*geo2)
-        bits2 = bits
-        if bits == 2 and geo2[2] == 1:
-            # one panel per mat-vec launch (the dense models): the launch is 512 columns, the sweep is bound by the chain workgroup,
-            # and the ALU-heavier 2-bit kernel only lengthens the launches beside it (measured: 31.5 vs 26.4 ms per BayesR sweep)
+        bits2 = ctx.layout()[0]
+        if bits2 == 2 and geo2[2] <= 2:
+            # one or two panels per mat-vec launch (the dense models): the sweep is bound by the chain workgroup and the update rows,
+            # and the ALU-heavier 2-bit kernel only lengthens the launches beside them (measured: 31.5 vs 26.4 ms per BayesR sweep)
             ctx.set_layout(8)
             bits2 = 8
         ctx.build_gram()
-        K2, W2 = max(10, K // 4), max(5, min(W, 30))
-        y2 = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, args.secondary)
-        el2, ev2, nnz2, miss2 = measure(H, L, ctx, y2, args.secondary, K2, W2, args, rank, local_rank, world, m_offset,
-                                 m_global, comm, torch, note, burn=args.burnin_secondary)
+        y2 = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, side)
+        el2, ev2, nnz2, miss2 = measure(H, L, ctx, y2, side, K2, W2, args, rank, local_rank, world, m_offset,
+                                 m_global, comm, torch, note, burn=burn_s)
         ins2 = measure.insitu
         ctx.time_matvec(reps=1)
         iso2, launches2, cols2 = ctx.time_matvec(reps=2)
         curve2 = list(getattr(measure, "curve", []))
         curve2.append({"sweeps": "timed region", "moves_per_sweep": round(ev2, 1), "sweeps_per_s": round(K2 / el2, 2)})
-        res["secondary"] = {"model": args.secondary, "value": K2 / el2, "unit": "sweeps/s", "steps": K2, "warmup": W2,
-                            "roofline": roofline_block(args, n, cols2, launches2, ins2, iso2, None, bits2), "resident_genotype_bits": bits2,
-                            "ms_per_step": el2 / K2 * 1e3, "achieved_frac_of_hbm_peak": K2 / el2 * n * m / 1e9 / HBM_PEAK_GBPS,
-                            "mcmc_burn_in_sweeps_before_warmup": args.burnin_secondary,
-                          "mean_changed_markers_per_sweep": ev2, "row_cache_misses_per_sweep": miss2, "NumNZSnp_last": nnz2,
-                            "regime_curve": curve2,
-                            "pipeline": {"persistent_chain": geo2[0], "lookahead_groups": geo2[1], "panels_per_matvec": geo2[2]}}
+        res[key] = {"model": side, "value": K2 / el2, "unit": "sweeps/s", "steps": K2, "warmup": W2,
+                    "roofline": roofline_block(args, n, cols2, launches2, ins2, iso2, None, bits2), "resident_genotype_bits": bits2,
+                    "ms_per_step": el2 / K2 * 1e3, "achieved_frac_of_hbm_peak": K2 / el2 * n * m / 1e9 / HBM_PEAK_GBPS,
+                    "mcmc_burn_in_sweeps_before_warmup": burn_s,
+                    "mean_changed_markers_per_sweep": ev2, "row_cache_misses_per_sweep": miss2, "NumNZSnp_last": nnz2,
+                    "regime_curve": curve2,
+                    "pipeline": {"persistent_chain": geo2[0], "lookahead_groups": geo2[1], "panels_per_matvec": geo2[2]}}
+        if key == "all_move":
+            res[key]["note"] = ("every marker moves every sweep: a sweep reads the genotypes twice (mat-vec and residual update), "
+                                "2 n m bytes; frac prices the n m of SURVEY 8d like the other lines")
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
             res["cpu_baseline"] = cpu_baseline(ctx, y, args, Pi, fold, g_main)

@@ -78,10 +78,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     load_coeffs(pv.p0);
     load_dg(pv.p0);
     if (wave > 0) HBD_REQUEST(bufA, pv.p0, 0);
-    if (wave == 0) {
-#pragma unroll
-        for (int k = 0; k < 64; k++) dg[k] = lane > k ? dg[k] : 0;
-    }
+#define HBD_PREP(w_)                                                                                               \
+    do { /* the serial wave's diagonal block: row k only reaches the lanes after k */                                  \
+        _Pragma("unroll") for (int k = 0; k < 64; k++) dg[k] = lane > k ? dg[k] : 0;                                   \
+    } while (0)
+    if (wave == 0) HBD_PREP(0);
     __syncthreads();
 
     for (int p = pv.p0; ok && p < np; p++) {
@@ -150,29 +151,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 rhs = fma(-(double)BUF[k + 1], dk_.y, rhs);                                                                       \
             }                                                                                                                     \
         }                                                                                                                         \
+        if (HB_STAMPS && (s) == 2 && lane == 0 && v.dbg) v.dbg[(size_t)p * 32 + 24 + wave] = clock64(); /* after the apply */     \
         {                                                                                                                         \
             const int rs_ = (s) + 1;                                                                                              \
             if (rs_ < 7 && wave > rs_) HBD_REQUEST(BUF, p, rs_);                                                                  \
         }                                                                                                                         \
-        if (wave == (((s) + 1) & 7)) { /* the next serial wave prepares its diagonal block: row k only reaches the lanes after k */ \
-            _Pragma("unroll") for (int k = 0; k < 64; k++) dg[k] = lane > k ? dg[k] : 0;                                          \
-        }                                                                                                                         \
+        if (wave == (((s) + 1) & 7)) HBD_PREP((s) + 1); /* the next serial wave prepares its diagonal block (wave 0: the next panel's) */ \
         double gn_f = 0.0, dmine = 0.0;                                                                                           \
         if (wave == (s)) {                                                                                                        \
-            double r_ = rhs;                                                                                                      \
-            _Pragma("unroll") for (int k = 0; k < 64; k++) {                                                                      \
-                double gn_ = fma(r_, invv, sdz);                                                                                  \
-                if (LASSO) gn_ = (act && fabs(gn_) < 1e-6) ? 1e-6 : gn_; /* :728 */                                               \
-                const double dk_ = readlane_f64(gn_ - gold, k);                                                                   \
-                r_ = fma(-(double)dg[k], dk_, r_);                                                                                \
+            /* The serial pass in units of the CHANGE: sv_j = what marker j's change would be if it were drawn now              */ \
+            /* (rhs_j / v_j + sd_j z_j - g_j); marker k's change is then sv_k as it stands at step k, and it moves the later      */ \
+            /* markers' by H[k][j] = -G[k][j] / v_j: per step two v_readlane and ONE fused multiply-add on the dependent chain     */ \
+            /* (the convert and the product with -1 / v_j do not depend on it and are issued ahead; carrying the right-hand side   */ \
+            /* itself is fma - sub - readlane - fma on the chain: 70 cycles per marker, the first version).                        */ \
+            double sv_ = fma(rhs, invv, sdz) - gold;                                                                              \
+            const double ninvv_ = -invv;                                                                                          \
+            if (!LASSO) {                                                                                                         \
+                _Pragma("unroll") for (int k = 0; k < 64; k++) sv_ = fma((double)dg[k] * ninvv_, readlane_f64(sv_, k), sv_);      \
+                gn_f = act ? gold + sv_ : 0.0;                                                                                    \
+                dmine = act ? sv_ : 0.0;                                                                                          \
+            } else { /* :728 clamps an effect with |g| < 1e-6 to 1e-6 (common while the effects are small): decided in the loop   */ \
+                const double forced_ = 1e-6 - gold;                                                                               \
+                _Pragma("unroll") for (int k = 0; k < 64; k++) {                                                                  \
+                    const double cur_ = (act && fabs(gold + sv_) < 1e-6) ? forced_ : sv_;                                         \
+                    sv_ = fma((double)dg[k] * ninvv_, readlane_f64(cur_, k), sv_);                                                \
+                }                                                                                                                 \
+                const bool cl_ = act && fabs(gold + sv_) < 1e-6;                                                                  \
+                gn_f = act ? (cl_ ? 1e-6 : gold + sv_) : 0.0;                                                                     \
+                dmine = act ? (cl_ ? forced_ : sv_) : 0.0;                                                                        \
             }                                                                                                                     \
-            gn_f = fma(r_, invv, sdz); /* a lane's right-hand side is not touched after its own step */                           \
-            if (LASSO) gn_f = (act && fabs(gn_f) < 1e-6) ? 1e-6 : gn_f;                                                           \
-            if (!act) gn_f = 0.0;                                                                                                 \
-            dmine = act ? gn_f - gold : 0.0;                                                                                      \
             dl[t] = dmine;                                                                                                        \
             st_sc1(&dd[j], dmine); /* k_fold_dense is waiting for exactly this */                                                 \
         }                                                                                                                         \
+        if (HB_STAMPS && (s) == 2 && lane == 0 && v.dbg) v.dbg[(size_t)p * 32 + 16 + wave] = clock64(); /* at the barrier */      \
         __syncthreads();                                                                                                          \
         HB_STAMP(2 + (s));                                                                                                        \
         if ((s) == 0 && misc[2]) { ok = false; break; }                                                                           \
@@ -329,4 +340,58 @@ __global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view p
         if (t == 0) atomicAdd(pv.flags + 14, 1u);
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_warm_dense: the chain workgroup's own reads — the diagonal blocks and strips of the NEXT panels' Gram blocks, 576 KB per panel —
+// pulled into ITS L2 ahead of time. One compute unit gets ~18 bytes per clock out of HBM however many loads it keeps in flight,
+// but ~64 out of its XCD's L2, and with the serial pass at 28 cycles per marker the chain would otherwise wait for
+// its strips. 8 x per_xcd workgroups are launched; those that did not land on the chain's XCD (it publishes HB_FLAG_XCC) leave.
+// The order is static, so this is exact prefetching: rows k of panel q from the diagonal block's first column to the row's end,
+// one workgroup per row residue, paced `ahead` panels in front of chain_done. A hint with no dependency: results are discarded.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_warm_dense(chain_view v, persist_view pv, int per_xcd, int ahead, int *__restrict__ sink)
+{
+    __shared__ int s_rank;
+    constexpr int P = HBD_P;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        unsigned my;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my));
+        my &= 15u;
+        unsigned want = 0;
+        const unsigned long long t0 = wall_clock64();
+        while ((want = ld_flag(pv.flags + HB_FLAG_XCC)) == 0u) {
+            if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > 100000000ull) break; // (1 s: the chain never started)
+            __builtin_amdgcn_s_sleep(16);
+        }
+        s_rank = (want == my + 1u) ? (int)(blockIdx.x >> 3) % per_xcd : -1;
+    }
+    __syncthreads();
+    const int rank = s_rank;
+    if (rank < 0) return;
+    const int np = pv.npanels;
+    const size_t PP = (size_t)P * P, pblk = (size_t)(pv.Lg + 1) * PP;
+    int acc = 0;
+    for (int q = pv.p0 + 1; q < np; q++) {
+        unsigned done;
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+            done = ld_flag(pv.flags + HB_FLAG_CHAIN_DONE);
+            if ((int)done + ahead >= q || ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if ((int)done >= np || ld_flag(pv.flags + HB_FLAG_ABORT) || (int)done + ahead < q) break;
+        if (q <= (int)done) continue; // the chain is already past this panel
+        const int32_t *gp = v.gram + (size_t)q * pblk;
+        // two rows per pass (128 lanes x 16 bytes each); row k is read from column 64 (k / 64) on
+        for (int k = 2 * rank + (t >> 7); k < P; k += 2 * per_xcd) {
+            const int c = 4 * (t & 127);
+            if (c >= (k & ~63)) {
+                const int4 x = *reinterpret_cast<const int4 *>(gp + (size_t)k * P + c);
+                acc += x.x ^ x.y ^ x.z ^ x.w;
+            }
+        }
+    }
+    if (acc == 0x7fffffff) *sink = acc; // (keeps the loads alive)
 }

@@ -159,7 +159,8 @@ struct upd_view {
     int *vexp_out;               // exponent of the output slot
     const uint32_t *X2;          // non-null: the genotypes in the 2-bit resident layout (hb_dotq2.hpp), ld2w words per column
     int64_t ld2w;
-    int dense;                   // (nearly) every marker of a panel moves (BayesRR / A / L): one row per lane, 64 rows per wave (update_rows_dense)
+    int dense;                   // every marker of a panel moves (BayesRR / A / L with k_chain_dense): one row per lane, 64 rows per wave (update_rows_dense)
+    const double *dd;            // ... and the changes by marker, zero where nothing moved (k_chain_dense's dd[])
 };
 
 // four consecutive individuals (row0 a multiple of 4) of one column, one genotype per byte: from the int8 matrix, or expanded in
@@ -274,96 +275,84 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
     }
 }
 
-// The same update where (nearly) every marker of a panel moved (BayesRR / A / L: a second pass over the panel's genotypes).
+// The same update where every marker of a panel moved (BayesRR / A / L with k_chain_dense: a second pass over the panel's genotypes).
 // A mat-vec launch has ONE update wave per 256 rows with update_rows, and such a wave walks the panel in batches of a few loads
 // per lane, one loaded memory round trip (~3 us beside the streaming tiles) per batch: measured 60-77 us per panel of 512 at
 // n = 50k with 8 or 32 loads in flight, software-pipelined or not, and the same with one row per lane and 32 byte loads in
-// flight (16 round trips). Here a wave owns 64 rows and fetches its whole 64 x 512 slab of genotypes — 32 KB — into LDS with 32
-// LDS-DMA instructions that are ALL in flight together (global_load_lds_dwordx4: lane l brings rows 16 (l & 3) .. + 15 of moved
-// column 16 i + l / 4, so piece i is 16 columns x 64 rows): one round trip, then one sign-extending LDS byte read, one convert and
-// one fused multiply-add per column, lane = row. Blocks b and b + 8 — the same XCD under round-robin dispatch — take the two
-// halves of the same 128-byte lines. Same sums in the same order as update_rows: the same residual bit for bit.
-// The slab travels in chunks of 128 columns through two 8-KB buffers (24 KB of LDS per block in all, so that a launch's update
-// blocks and tiles are all resident): the first two chunks are in flight together, the others land under the arithmetic.
-// smem: [0, 2048) move indices, [2048, 6144) changes, [6144, 6160) flags, [HBU_SLAB, HBU_SLAB + 16384) two chunk buffers.
-#define HBU_SLAB 8192
+// flight (16 round trips). Here a wave owns 64 rows and brings its 64 x 512 slab of genotypes into LDS by LDS-DMA
+// (global_load_lds_dwordx4: lane l = rows 16 (l & 3) .. + 15 of column 16 i + l / 4, so a piece of 1 KiB is 16 columns x 64 rows),
+// in chunks of 128 columns through two 8-KB buffers: the first two chunks are requested BEFORE the wave waits for the chain (the
+// genotypes do not depend on it), the others land under the arithmetic — one sign-extending LDS byte read, one convert and one
+// fused multiply-add per column, lane = row. The changes come from k_chain_dense's dd[] (one double per marker, zero for a
+// marker that did not move: a term x * 0 changes no sum), so no move list is read and every address is known at once.
+// Blocks b and b + 8 — the same XCD under round-robin dispatch — take the two halves of the same 128-byte lines.
+// Same sums in the same (marker) order as update_rows: the same residual bit for bit. Groups of at most 2 panels.
+// smem: [0, 8192) the group's changes (<= 1024 doubles), [8192, 8208) flags, [HBU_SLAB, HBU_SLAB + 16384) two chunk buffers.
+#define HBU_SLAB 8448
 #define HBU_LDS (HBU_SLAB + 16384)
 __device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q, int blk, int nblk, char *smem)
 {
-    int *s_ix = reinterpret_cast<int *>(smem);
-    double *s_dl = reinterpret_cast<double *>(smem + 2048);
-    int *s_ok = reinterpret_cast<int *>(smem + 6144);
+    double *s_dl = reinterpret_cast<double *>(smem);
+    int *s_ok = reinterpret_cast<int *>(smem + 8192);
     const signed char *slab = reinterpret_cast<const signed char *>(smem + HBU_SLAB);
     const unsigned slab_lds = (unsigned)(uintptr_t)(smem + HBU_SLAB);
     const int lane = threadIdx.x;
     const int full = nblk & ~15;
     const int rc = blk < full ? (blk & ~15) + ((blk & 7) << 1) + ((blk >> 3) & 1) : blk;
     const int64_t row0 = (int64_t)rc * 64, row = row0 + lane;
+    const int ncol = (q.p1 - q.p0) * q.P, nch = ncol >> 7; // (P is a multiple of 128: panel 512)
+    const int8_t *xp = q.X + (int64_t)q.p0 * q.P * ld + row0 + (lane & 3) * 16 + (int64_t)(lane >> 2) * ld;
+    auto issue = [&](int ch) { // columns 128 ch .. 128 ch + 127 of the group: 8 pieces
+        const unsigned dst = slab_lds + (unsigned)(ch & 1) * 8192u;
+        const int8_t *src = xp + (int64_t)ch * 128 * ld;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            unsigned keep; // (M0, the LDS destination base, is compiler-reserved: set and restored inside the statement)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src + (int64_t)i * 16 * ld), "s"(dst + (unsigned)i * 1024u)
+                         : "memory");
+        }
+    };
+    issue(0);
+    if (nch > 1) issue(1);
     double r0 = q.r_in[row], u0 = q.u[row];
     if (q.flags) {
         if (lane == 0) *s_ok = wait_ge(q.flags, HB_FLAG_CHAIN_DONE, (unsigned)q.p1) ? 1 : 0;
         __syncthreads();
-        if (!*s_ok) return;
+        if (!*s_ok) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
     }
+    // the group's changes (and the bound the digits' exponent comes from) in one round trip
+    double dv[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) dv[i] = ld_sc1(q.dd + (size_t)q.p0 * q.P + min(64 * i + lane, ncol - 1));
     int fixE = 0;
-    if (q.rq) {
-        __syncthreads();
-        if (lane == 0) s_ok[1] = hb_fix_exp(ld_sc1(q.mbv));
-        __syncthreads();
-        fixE = s_ok[1];
-        if (blk == 0 && lane == 0) *q.vexp_out = fixE;
-    }
+    if (q.rq) fixE = hb_fix_exp(ld_sc1(q.mbv)); // (every lane the same word: one broadcast load)
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        if (64 * i + lane < ncol) s_dl[64 * i + lane] = dv[i];
+    if (q.rq && blk == 0 && lane == 0) *q.vexp_out = fixE;
+    __syncthreads();
     double a = 0.0;
-    int total = 0;
-    for (int p = q.p0; p < q.p1; p++) {
-        const int nev = ld_sc1(q.ev_count + p);
-        if (nev == 0) continue;
-        total += nev;
-        __syncthreads();
-        for (int e = lane; e < nev; e += 64) {
-            s_ix[e] = ld_sc1(q.ev_idx + (size_t)p * q.P + e);
-            s_dl[e] = ld_sc1(q.ev_delta + (size_t)p * q.P + e);
+    for (int ch = 0; ch < nch; ch++) {
+        // (in flight behind chunk ch: chunk ch + 1 — 8 pieces — and nothing else: the loads above have been consumed)
+        if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const signed char *sl = slab + (ch & 1) * 8192 + lane;
+        const double *dl = s_dl + (ch << 7);
+#pragma unroll 4
+        for (int e = 0; e < 128; e += 8) {
+            int w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = sl[(e + k) * 64];
+#pragma unroll
+            for (int k = 0; k < 8; k++) a = fma((double)w[k], dl[e + k], a);
         }
-        __syncthreads();
-        const int8_t *xp = q.X + (int64_t)p * q.P * ld + row0 + (lane & 3) * 16;
-        // chunks of 128 moved columns (8 pieces of 1 KiB, always 8: a short chunk repeats its last column, so that the waits
-        // can be counted), two buffers: chunk c + 2 is requested into the buffer chunk c has just been read from
-        const int nch = (nev + 127) >> 7;
-        auto issue = [&](int ch) {
-            const unsigned dst = slab_lds + (unsigned)(ch & 1) * 8192u;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int8_t *src = xp + (int64_t)s_ix[min(128 * ch + 16 * i + (lane >> 2), nev - 1)] * ld;
-                unsigned keep; // (M0, the LDS destination base, is compiler-reserved: set and restored inside the statement)
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep)
-                             : "v"(src), "s"(dst + (unsigned)i * 1024u)
-                             : "memory");
-            }
-        };
-        issue(0);
-        if (nch > 1) issue(1);
-        for (int ch = 0; ch < nch; ch++) {
-            if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const signed char *sl = slab + (ch & 1) * 8192 + lane;
-            const int e0 = ch << 7, ne = min(128, nev - e0);
-            int e = 0;
-            for (; e + 8 <= ne; e += 8) {
-                int w[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) w[k] = sl[(e + k) * 64];
-#pragma unroll
-                for (int k = 0; k < 8; k++) a = fma((double)w[k], s_dl[e0 + e + k], a);
-            }
-            for (; e < ne; e++) a = fma((double)sl[e * 64], s_dl[e0 + e], a);
-            if (ch + 2 < nch) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (every read of this buffer has returned)
-                issue(ch + 2);
-            }
+        if (ch + 2 < nch) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (every read of this buffer has returned)
+            issue(ch + 2);
         }
     }
-    if (total == 0 && q.r_in == q.r) return;
     r0 -= a;
     q.r[row] = r0;
     q.r32[row] = (float)r0;
@@ -376,7 +365,7 @@ __device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q,
             q.rq[(int64_t)k * ld + row] = (int8_t)d;
         }
     }
-    if (total) q.u[row] = u0 + a;
+    q.u[row] = u0 + a;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2881,7 +2870,7 @@ static upd_view make_upd(hb_ctx *c, int p0, int p1, int sin, int sout, unsigned 
     return upd_view{c->X, c->P, p0, p1, c->ev_count, c->ev_idx, c->ev_delta, c->r + (size_t)sin * c->ld,
                     c->r + (size_t)sout * c->ld, c->u, c->r32 + (size_t)sout * c->ld, flags,
                     fx ? c->rq + (size_t)sout * HB_ND * c->ld : nullptr, c->mb + 1 + mbi, c->vexp + sout,
-                    c->layout == 2 ? c->X2 : nullptr, c->ld2 / 4, 0};
+                    c->layout == 2 ? c->X2 : nullptr, c->ld2 / 4, 0, c->ddense};
 }
 
 struct phase_timer {
@@ -3151,6 +3140,19 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         hipLaunchKernelGGL(k_fold_dense, dim3(8 * c->L), dim3(256), 0, c->s_upd, cv, pv, c->ddense);
         HB_HIP(hipGetLastError());
     }
+    bool warm_dense = false;
+    if (dense) { // the chain's own Gram reads, into its XCD's L2 ahead of it (HB_WARM_DENSE=0: off; = workgroups per XCD)
+        int wd = 0; // (measured at n = 50k: 4.45-4.52 ms per 200 panels with 0, 2, 4, 8 or 16 workgroups per XCD, 2 or 4 panels ahead: no gain, off by default)
+        if (const char *e = getenv("HB_WARM_DENSE")) wd = std::max(0, std::min(16, atoi(e)));
+        if (wd > 0) {
+            if (c->L <= 0) HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
+            int ahead = D + 1;
+            if (const char *e = getenv("HB_WARM_AHEAD")) ahead = std::max(1, atoi(e));
+            hipLaunchKernelGGL(k_warm_dense, dim3(8 * wd), dim3(256), 0, c->s_upd, cv, pv, wd, ahead, reinterpret_cast<int *>(c->flags + 48));
+            HB_HIP(hipGetLastError());
+            warm_dense = true;
+        }
+    }
     if (fwd) {
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         if (Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
@@ -3176,7 +3178,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         const int h = g - Lv, ha = g0 + h;
         upd_view uq{};
         if (h >= 0) uq = make_upd(c, ha * D, std::min(np, ha * D + D), slot2(h - 1), slot2(h), c->flags, ha);
-        uq.dense = (dense_upd && fx && c->layout == 8) ? 1 : 0; // (one row per lane where every marker moved; the fixed-point mat-vec's single-wave update blocks)
+        uq.dense = (dense_upd && fx && c->layout == 8 && D <= 2) ? 1 : 0; // (one row per lane where every marker moved; the fixed-point mat-vec's single-wave update blocks)
         launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, true, h >= 0 ? &uq : nullptr,
                    g > 0 ? (ga - 1) * D * c->P : 0, g > 0 ? D * c->P : 0, ga);
     }
@@ -3185,14 +3187,14 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         if (int rc = launch_the_chain(sA)) return rc;
     for (int h = std::max(0, ngroups - Lv); h < ngroups; h++) { // the updates that had no later mat-vec to ride on
         upd_view uq = make_upd(c, (g0 + h) * D, std::min(np, (g0 + h) * D + D), slot2(h - 1), slot2(h), c->flags, g0 + h);
-        if (dense_upd && c->layout == 8) {
+        if (dense_upd && c->layout == 8 && D <= 2) {
             uq.dense = 1;
             hipLaunchKernelGGL(k_update_dense, dim3((unsigned)(c->ld / 64)), dim3(64), 0, sA, c->ld, uq);
         } else hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, sA, c->ld, uq);
     }
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
-    if (warm || fwd || (dense && c->L > 0)) {
+    if (warm || fwd || (dense && c->L > 0) || warm_dense) {
         HB_HIP(hipEventRecord(c->ev_upd[0], c->s_upd));
         HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[0], 0));
     }

@@ -435,7 +435,9 @@ int hb_run::setup(const hb_bayes_args *args)
         cp.n = n;
         cp.m = m;
         cp.panel = a.panel;
-        if (!cp.panel && always_in) cp.panel = m >= 128 ? 128 : 64; // every marker moves: keep all Gram rows LDS-resident
+        // every marker moves: panels of 512 run k_chain_dense (hb_chain_dense.hpp: static order, the band folded by other compute
+        // units); small problems keep small panels, whose Gram rows are all LDS-resident in k_chain_persist
+        if (!cp.panel && always_in) cp.panel = m >= 4096 ? 512 : (m >= 128 ? 128 : 64);
         cp.precise = a.precise;
         cp.m_offset = sharded ? a.m_offset : 0;
         cp.seed = a.seed;
@@ -448,7 +450,9 @@ int hb_run::setup(const hb_bayes_args *args)
         if (rowmode) rc = hb_ctx_set_pipeline(c, 0, 0, 1); // per-panel kernels: an exchange sits between each mat-vec and its chain
         else if (model_index == 3 || model_index == 4) // three groups of look-ahead pay where the chain, not HBM, sets the pace: 2-bit genotypes
             rc = hb_ctx_set_pipeline(c, 1, a.genotype_bits == 2 ? 3 : 2, 7); // ((2, 7) where k_fwd is not available: panels other than 512)
-        else rc = hb_ctx_set_pipeline(c, 1, 2, 1); // (BayesR; RR / A / L: 6.3 instead of 4.9 sweeps/s at n=50k, m=500k with the second group of look-ahead)
+        else if (always_in && c->P == 512) // k_chain_dense: two panels per launch (45.6 against 39.4 sweeps/s at n=50k, m=500k; (1, 1) 24.8, (1, 2) 27.7)
+            rc = hb_ctx_set_pipeline(c, 1, 2, 2);
+        else rc = hb_ctx_set_pipeline(c, 1, 2, 1); // (BayesR; RR / A / L on small panels: the second group of look-ahead hides the update + launch boundary)
         if (rc) return rc;
         if (a.X_i8) rc = hb_ctx_upload_genotype_i8(c, a.X_i8, a.ld_i8, 0, m);
         else rc = hb_ctx_upload_genotype_f64(c, a.X_f64, a.ld_f64, 0, m);

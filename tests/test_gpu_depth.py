@@ -209,3 +209,44 @@ def test_all_move_models_at_panel_256(big, model):
     ref = O.bayes(y, X, model, [0.95, 0.05], rng=O.RNG_PHILOX, store_alpha=True, **kw)
     r = H.Bayes(y, X, model, [0.95, 0.05], verbose=False, panel=256, **kw)
     _compare(r, ref, tol=1e-6 if model == "BayesL" else 1e-9)
+
+
+@pytest.mark.parametrize("model", ["BayesRR", "BayesA", "BayesL"])
+@pytest.mark.parametrize("geo", [(1, 2, 2), (1, 2, 1), (1, 1, 1), (1, 1, 2)])
+def test_dense_chain_of_the_all_move_models_at_panel_512(big, model, geo):
+    """BayesRR / A / L at panel 512 run k_chain_dense + k_fold_dense (hb_chain_dense.hpp: static order, the 64 x 64 diagonal
+    blocks in registers, the band folded by workgroups spread over the chip and handed back through fcorr[]) and, with the
+    fixed-point mat-vec, the one-row-per-lane update with the panel's slab through LDS-DMA. Draw for draw against the oracle
+    (src/Bayes.cpp:587-625, :719-741) under every geometry the kernel supports, on a marker count that leaves a ragged last
+    panel, with monomorphic markers, from a cold start and from installed effects; BayesL to 1e-6 (see above)."""
+    X, y = big["X"][:, :8192 + 100], big["y"]
+    m = X.shape[1]
+    tol = 1e-6 if model == "BayesL" else 1e-9
+    kw = dict(niter=6, nburn=2, thin=2, seed=31337)
+    ref = O.bayes(y, X, model, [0.95, 0.05], rng=O.RNG_PHILOX, store_alpha=True, **kw)
+    rng = np.random.default_rng(77)
+    g0 = rng.normal(0, 0.01, m)
+    g0[7::997] = 0.0
+    refw = O.bayes(y, X, model, [0.95, 0.05], rng=O.RNG_PHILOX, store_alpha=True, g_init=g0, **kw)
+    with H.Context(X.shape[0], m, panel=512, seed=31337) as c:
+        c.upload(X)
+        c.set_pipeline(*geo)
+        assert c.pipeline()[:3] == geo and c.panel == 512
+        r = H.Bayes(y, None, model, [0.95, 0.05], verbose=False, ctx=c, **kw)
+        _compare(r, ref, tol=tol)
+        assert r["timing"]["mean_events"] == m - len(range(7, m, 997))     # every polymorphic marker moves every sweep
+        rw = H.Bayes(y, None, model, [0.95, 0.05], verbose=False, ctx=c, g_init=g0, **kw)
+        _compare(rw, refw, tol=tol)
+
+
+@pytest.mark.parametrize("precise", [2, 1])
+def test_dense_chain_through_the_one_call_boundary(big, precise):
+    """hb_bayes_run's own choice for BayesRR on a problem of this size is panel 512 at (Lv, D) = (2, 2); precise = 1 keeps the
+    fp64 mat-vec with its 256-thread update rows beside the dense chain; a sweep cut into blocks is the same chain."""
+    X, y = big["X"][:, :8192], big["y"]
+    kw = dict(niter=6, nburn=2, thin=2, seed=2468)
+    ref = O.bayes(y, X, "BayesRR", [0.95, 0.05], rng=O.RNG_PHILOX, store_alpha=True, **kw)
+    r = H.Bayes(y, X, "BayesRR", [0.95, 0.05], verbose=False, precise=precise, **kw)
+    _compare(r, ref)
+    rb = H.Bayes(y, X, "BayesRR", [0.95, 0.05], verbose=False, precise=precise, sync_every_blocks=3, **kw)
+    _compare(rb, ref)

@@ -8,7 +8,7 @@ from oracle import oracle as O
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from test_gpu_depth import geno, pheno, _compare
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 8192 + 100
-geos = [tuple(int(v) for v in g.split(",")) for g in (sys.argv[2] if len(sys.argv) > 2 else "2,1 1,1").split()]
+geos = [tuple(int(v) for v in g.split(",")) for g in (sys.argv[2] if len(sys.argv) > 2 else "2,1 1,1 2,2 1,2 3,1").split()]
 rng = np.random.default_rng(11)
 n = 2048
 X = geno(rng, n, m); y = pheno(rng, X)

@@ -58,4 +58,7 @@ with H.Context(n, m, panel=512, seed=20240901) as c:
             per.mean(), (a[:, 0] - a[:, 11]).mean(), [int((a[:, 2 + s] - (a[:, 1 + s] if s else a[:, 0])).mean()) for s in range(8)], (a[:, 1] - a[:, 9]).mean()))
         w12 = a[:, 12] > 1; print('panels whose dot (lane 0) was there at the first look: %d of %d' % ((a[:, 12] == 1).sum(), len(a)))
         print("panels that polled: %d of %d; lane 0's dot seen valid %d cycles after the panel's top (then the wait is for fcorr / the other lanes)" % (w12.sum(), len(a), (a[w12, 12] - a[w12, 11]).mean() if w12.any() else 0))
+        ref = a[:, 3]  # after barrier 1 = start of step 2
+        print("step 2, cycles after its start, by wave: apply done %s; at the barrier %s; barrier released %d" % (
+            [int((a[:, 24 + w] - ref).mean()) for w in range(8)], [int((a[:, 16 + w] - ref).mean()) for w in range(8)], (a[:, 4] - ref).mean()))
         print("poll percentiles", np.percentile(a[:, 0] - a[:, 11], [10, 50, 90]).astype(int), "panel percentiles", np.percentile(per, [10, 50, 90]).astype(int))
