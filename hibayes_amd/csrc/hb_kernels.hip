@@ -1177,6 +1177,9 @@ struct persist_view {
 #define HB_NPF 1 /* candidates per panel whose band rows are requested ahead (1 or 2) */
 #endif
 #define HB_CROWD 8 /* candidates in a round from which their Gram entries are gathered up front */
+#ifndef HB_SERIAL_BRANCHLESS
+#define HB_SERIAL_BRANCHLESS 1
+#endif
 
 // Row-cache list of every panel, in marker order, capped at nslot rows: the markers that are certain to move
 // (polymorphic, g_old != 0) and the markers that are LIKELY to enter the model this sweep. Entry means q >= thr0
@@ -1814,6 +1817,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         for (int k = 0; k < ncr; k++) {
                             const double gcur = gnx;
                             r2 = cg[min(k + 2, ncr - 1) * 64 + lane];
+#if HB_SERIAL_BRANCHLESS
+                            // (no test for "lane k stays at zero": its change is then an exact zero, and a ballot, a scalar test and a
+                            // branch per step cost more than the decide they skip)
+                            {
+                                int cls;
+                                double gn;
+                                decide(crhs, cls, gn);
+                                const double dk = readlane_f64(gn - cgold, k);
+                                crhs = fma(-gcur, dk, crhs);
+                            }
+#else
                             bool stays = false;
                             if (!((hotm >> k) & 1ull)) { // (uniform) a marker at zero moves only if it crosses its entry threshold
                                 const unsigned long long mv = __ballot(crhs * crhs >= cthr[0]) & vmask;
@@ -1826,6 +1840,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                 const double dk = readlane_f64(gn - cgold, k);
                                 crhs = fma(-gcur, dk, crhs);
                             }
+#endif
                             gnx = (double)r1; // (landed an iteration ago)
                             r1 = r2;
                         }
@@ -3129,7 +3144,11 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     if (alone) HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->flags + HB_FLAG_CHAIN_DONE), 0x7ffffff0, 1, sA));
     else {
         if (int rc = launch_the_chain(sB)) return rc;
-        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sA, c->flags); // (the first mat-vec launch starts when the chain is resident)
+        // (the first mat-vec launch starts when the chain is resident; HB_GATE=0 / 1 overrides: by default only where a launch's
+        // update blocks can sit on every compute unit)
+        bool gate = dense;
+        if (const char *e = getenv("HB_GATE")) gate = atoi(e) != 0;
+        if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sA, c->flags);
     }
     // the L2 warmers (k_warm): a third branch of the graph, 4 workgroups per XCD of which only the chain's XCD's stay
     int warm = 4;
