@@ -288,6 +288,7 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
 // Blocks b and b + 8 — the same XCD under round-robin dispatch — take the two halves of the same 128-byte lines.
 // Same sums in the same (marker) order as update_rows: the same residual bit for bit. Groups of at most 2 panels.
 // smem: [0, 8192) the group's changes (<= 1024 doubles), [8192, 8208) flags, [HBU_SLAB, HBU_SLAB + 16384) two chunk buffers.
+#define HBU_SENT(x) (__double_as_longlong(x) == -1ll)
 #define HBU_SLAB 8448
 #define HBU_LDS (HBU_SLAB + 16384)
 __device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q, int blk, int nblk, char *smem)
@@ -317,17 +318,37 @@ __device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q,
     issue(0);
     if (nch > 1) issue(1);
     double r0 = q.r_in[row], u0 = q.u[row];
-    if (q.flags) {
-        if (lane == 0) *s_ok = wait_ge(q.flags, HB_FLAG_CHAIN_DONE, (unsigned)q.p1) ? 1 : 0;
-        __syncthreads();
-        if (!*s_ok) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-    }
-    // the group's changes (and the bound the digits' exponent comes from) in one round trip
-    double dv[16];
+    // the group's changes and the bound the digits' exponent comes from, polled directly (both are sentinel-prefilled and written
+    // once per sweep: every 8-byte value lands whole) — one round trip where waiting for chain_done first and loading them
+    // afterwards is two
+    double dv[16], mbv = 0.0;
+    {
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) dv[i] = ld_sc1(q.dd + (size_t)q.p0 * q.P + min(64 * i + lane, ncol - 1));
+            for (int i = 0; i < 16; i++) dv[i] = ld_sc1(q.dd + (size_t)q.p0 * q.P + min(64 * i + lane, ncol - 1));
+            if (q.rq) mbv = ld_sc1(q.mbv); // (every lane the same word: one broadcast load)
+            bool bad = q.rq && HBU_SENT(mbv);
+#pragma unroll
+            for (int i = 0; i < 16; i++) bad |= HBU_SENT(dv[i]);
+            if (!q.flags || !__any(bad)) break; // (no flags: the serial kernels, everything is final)
+            // not there yet: wait on ONE word — the group's last change, or the bound, both written at its very end — and look at
+            // everything again afterwards (784 waves polling 17 words each would be traffic the chain does not need)
+            const double *last = q.rq ? q.mbv : q.dd + (size_t)q.p0 * q.P + (ncol - 1);
+            bool dead = false;
+            while (HBU_SENT(ld_sc1(last))) {
+                if (ld_flag(q.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (dead) {
+                if (lane == 0) { st_flag(q.flags + HB_FLAG_ABORT, 1u); st_flag(q.flags + 8, (unsigned)q.p1); }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                return;
+            }
+        }
+    }
     int fixE = 0;
-    if (q.rq) fixE = hb_fix_exp(ld_sc1(q.mbv)); // (every lane the same word: one broadcast load)
+    if (q.rq) fixE = hb_fix_exp(mbv);
 #pragma unroll
     for (int i = 0; i < 16; i++)
         if (64 * i + lane < ncol) s_dl[64 * i + lane] = dv[i];
@@ -660,7 +681,8 @@ __global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
 // One workgroup (n is a few hundred KB).
 __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, unsigned *__restrict__ flags, int32_t *__restrict__ ev_count,
                                                     int np, unsigned long long *__restrict__ dsum, int m_pad, int p_lo,
-                                                    unsigned long long *__restrict__ fcorr, unsigned long long *__restrict__ dd)
+                                                    unsigned long long *__restrict__ fcorr, unsigned long long *__restrict__ dd,
+                                                    unsigned long long *__restrict__ mbs, int mb_lo, int mb_hi)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (acc && i < HB_ACC_N) acc[i] = 0.0; // (null: a later range of the same sweep keeps the sums)
@@ -671,6 +693,8 @@ __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, un
         for (int k = i; k < m_pad; k += stride) fcorr[k] = ~0ull;
     if (dd)
         for (int k = i; k < m_pad; k += stride) dd[k] = ~0ull;
+    if (mbs) // (the dense update rows poll the group's bound on max |yadj| together with its changes: "not written yet")
+        for (int k = mb_lo + i; k < mb_hi; k += stride) mbs[k] = ~0ull;
 }
 
 __global__ __launch_bounds__(1024) void k_quant0(const double *__restrict__ r, int64_t ld, int8_t *__restrict__ rq,
@@ -3073,7 +3097,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     hipLaunchKernelGGL(k_sweep_init, dim3(256), dim3(256), 0, sA, first ? c->acc : nullptr, c->flags, c->ev_count, c->npanels,
                        reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad, pb,
                        (c->fwd_group || dense) ? reinterpret_cast<unsigned long long *>(c->fcorr) : nullptr,
-                       dense ? reinterpret_cast<unsigned long long *>(c->ddense) : nullptr);
+                       dense ? reinterpret_cast<unsigned long long *>(c->ddense) : nullptr,
+                       (dense && c->precise == 2) ? reinterpret_cast<unsigned long long *>(c->mb) : nullptr, 1 + pb / c->D, c->npanels + 2);
     const bool fx = c->precise == 2;
     if (fx) {
         HB_HIP(hipEventRecord(c->ev_dot[0], sA));
