@@ -210,3 +210,29 @@ def test_config3_pipeline_vs_serial_kernels_precise_and_fast(model, Pi, fold, ge
     same = ft1 == t1
     np.testing.assert_allclose(f1[same], g1[same], rtol=0, atol=2e-3 * max(1e-12, np.abs(g1).max()))
     np.testing.assert_allclose(fr1 + fu1, y - y.mean(), rtol=0, atol=1e-9)  # the f64 master residual stays exact in both modes
+
+
+@pytest.mark.parametrize("model,geo", [("BayesRR", (1, 2, 2)), ("BayesA", (1, 2, 1)), ("BayesL", (1, 2, 2))])
+def test_all_move_models_at_n50k_against_live_oracle(model, geo):
+    """BayesRR / A / L with the BASELINE's 50 000 individuals (src/Bayes.cpp:587-625, :719-741): 784 update blocks per launch —
+    one per 64 rows, more than the chip has compute units, the shape under which a late chain workgroup never found a free one
+    before k_gate —, the slab of every block through LDS-DMA, k_chain_dense and k_fold_dense over 100 panels. Three sweeps from
+    cold against the oracle on the downloaded genotypes: every effect to 1e-8 (BayesL 1e-6: see test_gpu_depth)."""
+    n, m = 50000, 51200
+    kw = dict(niter=3, nburn=0, thin=1, seed=20240901)
+    with H.Context(n, m, seed=20240901, panel=512) as c:
+        c.generate(20240901, mono_every=1000)
+        y = synth_y(c, n, m, 17)
+        c.set_pipeline(*geo)
+        r = H.Bayes(y, None, model, [0.95, 0.05], verbose=False, ctx=c, store_alpha=False, **kw)
+        invariants(c, y, r)
+        g_gpu, trk, _ = c.get_effects()
+        X = c.download()
+    ref = O.bayes(y, X, model, [0.95, 0.05], rng=O.RNG_PHILOX, store_alpha=True, **kw)
+    g_ref = ref["s_alpha"][:, -1]
+    tol = 1e-6 if model == "BayesL" else 1e-8
+    assert np.array_equal(g_gpu != 0, g_ref != 0)
+    np.testing.assert_allclose(g_gpu, g_ref, rtol=tol, atol=1e-12)
+    np.testing.assert_allclose([r["Vg"], r["Ve"], r["h2"], r["mu"]], [ref["Vg"], ref["Ve"], ref["h2"], ref["mu"]], rtol=tol)
+    np.testing.assert_allclose(r["g"], ref["g"], rtol=1e-7, atol=1e-8)
+    assert r["timing"]["mean_events"] > 0.99 * m
