@@ -250,3 +250,18 @@ def test_dense_chain_through_the_one_call_boundary(big, precise):
     _compare(r, ref)
     rb = H.Bayes(y, X, "BayesRR", [0.95, 0.05], verbose=False, precise=precise, sync_every_blocks=3, **kw)
     _compare(rb, ref)
+
+
+@pytest.mark.parametrize("n,m", [(100, 300), (333, 600)])
+@pytest.mark.parametrize("bits", [8, 2])
+def test_dense_chain_on_a_single_or_ragged_panel(n, m, bits):
+    """Panel 512 forced on problems of less than one panel and of one panel and a ragged second one, few individuals (four
+    update blocks), int8 and 2-bit resident genotypes (the 2-bit layout keeps the 256-row update rows beside k_chain_dense)."""
+    rng = np.random.default_rng(3 + m)
+    X = geno(rng, n, m)
+    y = pheno(rng, X, ncausal=20)
+    kw = dict(niter=5, nburn=1, thin=2, seed=99)
+    for model in ("BayesRR", "BayesL"):
+        ref = O.bayes(y, X, model, [0.95, 0.05], rng=O.RNG_PHILOX, store_alpha=True, **kw)
+        r = H.Bayes(y, X, model, [0.95, 0.05], verbose=False, panel=512, genotype_bits=bits, **kw)
+        _compare(r, ref, tol=1e-6 if model == "BayesL" else 1e-9)

@@ -42,6 +42,10 @@ with H.Context(n, m, panel=512, seed=20240901) as c:
         fi, up, ti = a[:nfin], a[nfin:nfin + nupd], a[nfin + nupd:]
         f = lambda x: "start %.1f..%.1f end %.1f..%.1f (life %.1f)" % ((x[:, 0].min() - s0) / 100, (x[:, 0].max() - s0) / 100, (x[:, 1].min() - s0) / 100, (x[:, 1].max() - s0) / 100, (x[:, 1] - x[:, 0]).mean() / 100)
         print("launch %d: %d blocks, us from its first block: finalize %s | update (%d) %s | tiles (%d) %s" % (g, k, f(fi), len(up), f(up), len(ti), f(ti)), flush=True)
+        if g == 41:
+            qs = [0, 10, 25, 50, 75, 90, 100]
+            print("   start-time quantiles (us) %s: update %s | tiles %s" % (qs, np.round(np.percentile((up[:, 0] - s0) / 100, qs), 1), np.round(np.percentile((ti[:, 0] - s0) / 100, qs), 1)))
+            print("   end-time quantiles (us): update %s | tiles %s" % (np.round(np.percentile((up[:, 1] - s0) / 100, qs), 1), np.round(np.percentile((ti[:, 1] - s0) / 100, qs), 1)))
     c.set_profiling(0)
     ms, nl, nc = c.time_matvec(reps=3)
     print("isolated replay (no update rows): %.2f us per launch" % (ms * 1e3))
