@@ -265,3 +265,18 @@ def test_dense_chain_on_a_single_or_ragged_panel(n, m, bits):
         ref = O.bayes(y, X, model, [0.95, 0.05], rng=O.RNG_PHILOX, store_alpha=True, **kw)
         r = H.Bayes(y, X, model, [0.95, 0.05], verbose=False, panel=512, genotype_bits=bits, **kw)
         _compare(r, ref, tol=1e-6 if model == "BayesL" else 1e-9)
+
+
+def test_dense_update_rows_are_the_old_update_rows_bit_for_bit(big, monkeypatch):
+    """update_rows_dense (one row per lane, the panel's genotype slab through LDS-DMA, changes from dd[]) sums the same products in
+    the same marker order as update_rows (four rows per lane, move list): the whole run must agree BIT FOR BIT with the one that
+    keeps the old update rows beside k_chain_dense (HB_DENSE_UPD=0)."""
+    X, y = big["X"][:, :8192 + 100], big["y"]
+    kw = dict(niter=6, nburn=2, thin=2, seed=777)
+    r_new = H.Bayes(y, X, "BayesRR", [0.95, 0.05], verbose=False, **kw)
+    monkeypatch.setenv("HB_DENSE_UPD", "0")
+    r_old = H.Bayes(y, X, "BayesRR", [0.95, 0.05], verbose=False, **kw)
+    for k in ("alpha", "g", "Vg", "Ve", "h2", "mu"):     # (g: the final u = X g, accumulated by the update rows themselves)
+        assert np.array_equal(np.asarray(r_new[k]), np.asarray(r_old[k])), k
+    assert np.array_equal(r_new["MCMCsamples"]["alpha"], r_old["MCMCsamples"]["alpha"])
+    np.testing.assert_allclose(r_new["e"], r_old["e"], rtol=0, atol=1e-10)   # (X * alpha sums its column blocks with atomics: last bits)
