@@ -9,18 +9,21 @@
 // time (~41 GB/s). So:
 //   * k_chain_dense — one persistent workgroup, thread = marker of the panel, wave w = sub-block w of 64 markers. A panel is
 //     eight steps: wave s runs the serial pass of its 64 markers with the 64 x 64 diagonal block of the panel's Gram block in
-//     REGISTERS (one column per lane, requested a panel ahead — the order is static, so everything is) and the loop fully
-//     unrolled: per marker  fma (new effect) - sub (change) - 2 v_readlane (broadcast) - fma (the later lanes' right-hand
-//     sides); then the later waves take the 64 changes with the strip G[64 s .. 64 s + 63][t] they requested two steps
-//     earlier (64 registers per thread, double-buffered). Nothing is ever decided, gathered or rolled back.
+//     REGISTERS (one column per lane, requested a panel ahead — the order is static, so everything is), the loop fully
+//     unrolled, in units of the CHANGE of effect: sv_j = rhs_j / v_j + sd_j z_j - g_j is what marker j's change would be if
+//     it were drawn now, marker k's change is sv_k as it stands at step k and moves the later markers' by -G[k][j] / v_j —
+//     two v_readlane and one fma per marker on the dependent chain. Then the later waves take the 64 changes with the strip
+//     G[64 s .. 64 s + 63][t] they requested two steps earlier (64 registers per thread, double-buffered). Nothing is ever
+//     decided, gathered or rolled back (BayesL's clamp of tiny effects, src/Bayes.cpp:728, is a select inside the loop).
 //   * k_fold_dense — the band: panel q is owed  sum_l G_l[q]^T delta_{q-l}  by the panels whose moves its mat-vec has not
 //     seen, a dense 512 x 512 product per band block. 8 Lb small workgroups spread over the chip (one per 64 columns of a
 //     target panel, its four waves a quarter of the rows each) take the chain's changes sub-block by sub-block as they are
 //     published (dd[], sentinel-prefilled like the dots: no flag) and hand the finished sums to the chain through fcorr[],
 //     which the chain polls with its dots. The chain's compute unit never reads a band row.
-// Same chain as k_chain / k_chain_persist: the same fused multiply-adds per marker in the same order inside a panel; the band
-// sums are added in a different order (per row quarter), i.e. effects agree to the last bits' rounding (tests: draw for draw
-// against the oracle at 1e-9, tests/test_gpu_depth.py, test_gpu_parity.py).
+// Same chain as k_chain / k_chain_persist in exact arithmetic: the moves in the same order; a change is computed in its own
+// units instead of from the carried right-hand side and the band sums are added per row quarter, i.e. effects agree to the
+// last bits' rounding (tests: draw for draw against the oracle at 1e-9, BayesL 1e-6 — tests/test_gpu_depth.py
+// test_dense_chain_*, test_gpu_configs.py test_all_move_models_at_n50k_*, test_gpu_parity.py).
 #pragma once
 
 #define HBD_P 512
