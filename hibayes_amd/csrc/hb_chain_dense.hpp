@@ -13,13 +13,19 @@
 //     unrolled, in units of the CHANGE of effect: sv_j = rhs_j / v_j + sd_j z_j - g_j is what marker j's change would be if
 //     it were drawn now, marker k's change is sv_k as it stands at step k and moves the later markers' by -G[k][j] / v_j —
 //     two v_readlane and one fma per marker on the dependent chain. Then the later waves take the 64 changes with the strip
-//     G[64 s .. 64 s + 63][t] they requested two steps earlier (64 registers per thread, double-buffered). Nothing is ever
-//     decided, gathered or rolled back (BayesL's clamp of tiny effects, src/Bayes.cpp:728, is a select inside the loop).
+//     G[64 s .. 64 s + 63][t] they requested two steps earlier (64 registers per thread, double-buffered) — the next
+//     HBD_NEAR sub-blocks only: what sub-block s owes the sub-blocks more than HBD_NEAR after it comes back from
+//     k_fold_dense through fcorr2[] (10 of a panel's 28 strips at HBD_NEAR = 3, 15 at 2, never touch the chain's compute
+//     unit; the serial wave of step s looks at fcorr2[] a step before it needs it). Nothing is ever decided, gathered or
+//     rolled back (BayesL's clamp of tiny effects, src/Bayes.cpp:728, is a select inside the loop).
 //   * k_fold_dense — the band: panel q is owed  sum_l G_l[q]^T delta_{q-l}  by the panels whose moves its mat-vec has not
-//     seen, a dense 512 x 512 product per band block. 8 Lb small workgroups spread over the chip (one per 64 columns of a
-//     target panel, its four waves a quarter of the rows each) take the chain's changes sub-block by sub-block as they are
-//     published (dd[], sentinel-prefilled like the dots: no flag) and hand the finished sums to the chain through fcorr[],
-//     which the chain polls with its dots. The chain's compute unit never reads a band row.
+//     seen, a dense 512 x 512 product per band block — and, since the near window, the panel's OWN far sub-blocks (block 0
+//     of its Gram blocks, rows of the sub-blocks more than HBD_NEAR before the target's). 8 (Lb + 1) small workgroups spread
+//     over the chip (one per 64 columns of a target panel, its four waves a quarter of the rows each; Lb + 1 target panels are
+//     open at any time: Lb ahead for their band, the chain's own for its far sub-blocks) take the chain's changes sub-block
+//     by sub-block as they are published (dd[], sentinel-prefilled like the dots: no flag) and hand the finished sums to the
+//     chain through fcorr[] (band, polled with the panel's dots) and fcorr2[] (own panel, polled by the serial wave). The
+//     chain's compute unit never reads a band row.
 // Same chain as k_chain / k_chain_persist in exact arithmetic: the moves in the same order; a change is computed in its own
 // units instead of from the carried right-hand side and the band sums are added per row quarter, i.e. effects agree to the
 // last bits' rounding (tests: draw for draw against the oracle at 1e-9, BayesL 1e-6 — tests/test_gpu_depth.py
@@ -27,11 +33,12 @@
 #pragma once
 
 #define HBD_P 512
+#define HBD_NEAR 2 /* a sub-block's changes are applied by the chain itself to the next HBD_NEAR sub-blocks of its panel; the farther ones get them from k_fold_dense (fcorr2[]) */
 #define HBD_SENT(x) (__double_as_longlong(x) == -1ll)
 
 template <bool LASSO>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_dense(const hb_sweep_in *__restrict__ pin, chain_view v,
-                                                                                                 persist_view pv, double *__restrict__ dd)
+                                                                                                 persist_view pv, double *__restrict__ dd, const double *__restrict__ fcorr2)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *dl = reinterpret_cast<double *>(smem); // [512] the panel's changes of effect, by marker
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } while (0)
     load_coeffs(pv.p0);
     load_dg(pv.p0);
-    if (wave > 0) HBD_REQUEST(bufA, pv.p0, 0);
+    if (wave > 0 && wave <= HBD_NEAR) HBD_REQUEST(bufA, pv.p0, 0);
 #define HBD_PREP(w_)                                                                                               \
     do { /* the serial wave's diagonal block: row k only reaches the lanes after k */                                  \
         _Pragma("unroll") for (int k = 0; k < 64; k++) dg[k] = lane > k ? dg[k] : 0;                                   \
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 load_coeffs(p);
                 load_dg(p);
             }
-            if (wave > 0) HBD_REQUEST(bufA, p, 0);
+            if (wave > 0 && wave <= HBD_NEAR) HBD_REQUEST(bufA, p, 0);
         }
         HB_STAMP(11);
         // ---- opening: the panel's dots and what the band owes it ----
@@ -142,11 +149,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const double gold = c_gold, invv = c_invv, sdz = c_sdz;
         if (gold != 0.0) rhs = fma(c_xx, gold, rhs); // :594 / :616 / :725
         nact += act ? 1 : 0;
+        double fc2 = 0.0; // what the sub-blocks more than HBD_NEAR before this one owe it (k_fold_dense; waves >= HBD_NEAR + 1)
         HB_STAMP(0);
 
 #define HBD_STEP(s, BUF)                                                                                                          \
     do {                                                                                                                          \
-        if ((s) > 0 && wave >= (s)) { /* the changes of sub-block s - 1 onto the later markers of the panel */                    \
+        if ((s) > 0 && wave >= (s) && wave - ((s) - 1) <= HBD_NEAR) { /* the changes of sub-block s - 1 onto the NEAR later markers of the panel */                    \
             const double2 *d2_ = reinterpret_cast<const double2 *>(dl + 64 * ((s) - 1));                                          \
             _Pragma("unroll") for (int k = 0; k < 64; k += 2) {                                                                   \
                 const double2 dk_ = d2_[k >> 1];                                                                                  \
@@ -157,11 +165,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (HB_STAMPS && (s) == 2 && lane == 0 && v.dbg) v.dbg[(size_t)p * 32 + 24 + wave] = clock64(); /* after the apply */     \
         {                                                                                                                         \
             const int rs_ = (s) + 1;                                                                                              \
-            if (rs_ < 7 && wave > rs_) HBD_REQUEST(BUF, p, rs_);                                                                  \
+            if (rs_ < 7 && wave > rs_ && wave - rs_ <= HBD_NEAR) HBD_REQUEST(BUF, p, rs_);                                                                  \
         }                                                                                                                         \
         if (wave == (((s) + 1) & 7)) HBD_PREP((s) + 1); /* the next serial wave prepares its diagonal block (wave 0: the next panel's) */ \
+        if ((s) + 1 > HBD_NEAR && wave == (s) + 1) fc2 = ld_sc1(&fcorr2[j]); /* (looked at a step before it is needed) */          \
         double gn_f = 0.0, dmine = 0.0;                                                                                           \
         if (wave == (s)) {                                                                                                        \
+            if ((s) > HBD_NEAR) { /* the far sub-blocks' share, summed by k_fold_dense while the near ones were being applied */     \
+                if (__any(HBD_SENT(fc2))) {                                                                                       \
+                    const unsigned long long t0_ = wall_clock64();                                                                \
+                    for (;;) {                                                                                                    \
+                        fc2 = ld_sc1(&fcorr2[j]);                                                                                 \
+                        if (!__any(HBD_SENT(fc2))) break;                                                                         \
+                        if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0_ > HB_TIMEOUT_TICKS) {                       \
+                            if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); st_flag(pv.flags + 9, (unsigned)p + 1u); st_flag(pv.flags + 10, 3u); } \
+                            fc2 = 0.0;                                                                                            \
+                            break;                                                                                                \
+                        }                                                                                                         \
+                        __builtin_amdgcn_s_sleep(1);                                                                              \
+                    }                                                                                                             \
+                }                                                                                                                 \
+                rhs -= fc2;                                                                                                       \
+            }                                                                                                                     \
             /* The serial pass in units of the CHANGE: sv_j = what marker j's change would be if it were drawn now              */ \
             /* (rhs_j / v_j + sd_j z_j - g_j); marker k's change is then sv_k as it stands at step k, and it moves the later      */ \
             /* markers' by H[k][j] = -G[k][j] / v_j: per step two v_readlane and ONE fused multiply-add on the dependent chain     */ \
@@ -268,38 +293,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ---------------------------------------------------------------------------------------------
 // k_fold_dense: what the band owes a panel, summed by workgroups spread over the chip.
 // Target panel q is owed  fcorr[q P + c] = sum over the source panels p = q - l (l = 1 .. Lv D + q mod D: the panels whose moves
-// the mat-vec of q's group has not seen) of  sum_k G_l[q][k][c] delta_p[k].  Workgroup (tq, ch): the targets q = p0 + 1 + tq,
-// + LBW, + 2 LBW, ... (LBW = Lb targets are open at any time), columns 64 ch .. 64 ch + 63; wave w = rows 16 w .. 16 w + 15 of
-// every source sub-block of 64. The 16 Gram entries of the next sub-block are requested BEFORE the chain's changes are polled
+// the mat-vec of q's group has not seen) of  sum_k G_l[q][k][c] delta_p[k];  fcorr2[q P + c] = the same sum over the sub-blocks
+// of panel q ITSELF (band block 0) that lie more than HBD_NEAR before column c's (columns of sub-block ch: sub-blocks 0 ..
+// ch - HBD_NEAR - 1; the nearer ones the chain applies itself).  Workgroup (tq, ch): the targets q = p0 + tq, + nsets,
+// + 2 nsets, ... (nsets = Lb + 1 targets are open at any time), columns 64 ch .. 64 ch + 63; wave w = rows 16 w .. 16 w + 15 of
+// every source sub-block of 64; the band's sub-blocks first, then the own panel's. The 16 Gram entries of the next sub-block are requested BEFORE the chain's changes are polled
 // (dd[] is sentinel-prefilled: every 8-byte value lands whole), so that what follows the arrival of a sub-block's changes is
 // 16 fused multiply-adds; after the last sub-block of panel q - 1 the four row quarters are added in order and the sum is written
-// through to fcorr[] — the chain polls it with the panel's dots.
+// through to fcorr[] — the chain polls it with the panel's dots —, the accumulator restarts, and after the last far sub-block of
+// panel q the same goes to fcorr2[].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view pv, const double *__restrict__ dd)
+__global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view pv, const double *__restrict__ dd, double *__restrict__ fcorr2, int nsets)
 {
     __shared__ double part[4][64];
     __shared__ int s_abort;
     constexpr int P = HBD_P;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int LBW = pv.Lb, np = pv.npanels, D = pv.D;
-    if (LBW <= 0) return;
+    const int np = pv.npanels, D = pv.D;
     const int tq = blockIdx.x >> 3, ch = blockIdx.x & 7;
     const size_t PP = (size_t)P * P, pblk = (size_t)(pv.Lg + 1) * PP;
     if (t == 0) { s_abort = 0; atomicAdd(pv.flags + 13, 1u); }
     __syncthreads();
-    for (int q = pv.p0 + 1 + tq; q < np; q += LBW) {
-        const int nsrc = min(pv.Lv * D + (q - pv.p0) % D, q - pv.p0); // source panels q - nsrc .. q - 1
+    const int nfar = ch > HBD_NEAR ? ch - HBD_NEAR : 0; // sub-blocks 0 .. nfar - 1 of the target's own panel
+    for (int q = pv.p0 + tq; q < np; q += nsets) {
+        const int nsrc = pv.Lb > 0 ? min(pv.Lv * D + (q - pv.p0) % D, q - pv.p0) : 0; // source panels q - nsrc .. q - 1
+        const int nband = nsrc * 8, nsteps = nband + nfar;
+        if (nsteps == 0) continue;
         double acc = 0.0;
-        const int nsteps = nsrc * 8;
         int gv[16], gn[16];
+        // step st: the band's sub-blocks first (panel q - l through band block l), then the target panel's own far sub-blocks (block 0)
         auto request = [&](int st, int (&g)[16]) {
-            const int l = nsrc - (st >> 3), s = st & 7; // source panel q - l, its sub-block s
+            const int l = st < nband ? nsrc - (st >> 3) : 0, s = st < nband ? (st & 7) : st - nband;
             const int32_t *gp = v.gram + (size_t)q * pblk + (size_t)l * PP + (size_t)(64 * s + 16 * wave) * P + 64 * ch + lane;
 #pragma unroll
             for (int i = 0; i < 16; i++) g[i] = gp[(size_t)i * P];
         };
         auto dptr = [&](int st) {
-            const int l = nsrc - (st >> 3), s = st & 7;
+            const int l = st < nband ? nsrc - (st >> 3) : 0, s = st < nband ? (st & 7) : st - nband;
             return dd + (size_t)(q - l) * P + 64 * s + 16 * wave + (lane & 15);
         };
         request(0, gv);
@@ -319,9 +349,7 @@ __global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view p
                     if (!__any(HBD_SENT(d))) break;
                     const bool own = wall_clock64() - t0 > HB_TIMEOUT_TICKS;
                     if (ld_flag(pv.flags + HB_FLAG_ABORT) || own) {
-                        if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); s_abort = 1; st_flag(pv.flags + 11, (unsigned)q + 1u); st_flag(pv.flags + 12, (unsigned)st + (own ? 0x100u : 0u));
-                            if (own) { const unsigned long long now = wall_clock64(); st_flag(pv.flags + 20, (unsigned)now); st_flag(pv.flags + 21, (unsigned)(now >> 32)); st_flag(pv.flags + 22, (unsigned)t0); st_flag(pv.flags + 23, (unsigned)(t0 >> 32));
-                                       st_flag(pv.flags + 24, (unsigned)__double_as_longlong(d)); st_flag(pv.flags + 25, (unsigned)(__double_as_longlong(d) >> 32)); st_flag(pv.flags + 26, (unsigned)(dp - dd)); } }
+                        if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); s_abort = 1; st_flag(pv.flags + 11, (unsigned)q + 1u); st_flag(pv.flags + 12, (unsigned)st + (own ? 0x100u : 0u)); }
                         dead = true;
                         break;
                     }
@@ -335,13 +363,21 @@ __global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view p
 #pragma unroll
             for (int i = 0; i < 16; i++) gv[i] = gn[i];
             d = dn;
+            if (st + 1 == nband || st + 1 == nsteps) { // the band's sum (-> fcorr[], polled at the opening) / the far sub-blocks' (-> fcorr2[])
+                part[wave][lane] = acc;
+                __syncthreads();
+                if (wave == 0) {
+                    const double tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+                    if (st + 1 == nband) st_sc1(&pv.fcorr[(size_t)q * P + 64 * ch + lane], tot);
+                    else st_sc1(&fcorr2[(size_t)q * P + 64 * ch + lane], tot);
+                }
+                acc = 0.0;
+                __syncthreads();
+            }
         }
-        part[wave][lane] = acc;
         __syncthreads();
         if (s_abort) return;
-        if (wave == 0) st_sc1(&pv.fcorr[(size_t)q * P + 64 * ch + lane], ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
         if (t == 0) atomicAdd(pv.flags + 14, 1u);
-        __syncthreads();
     }
 }
 

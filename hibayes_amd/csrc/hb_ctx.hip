@@ -201,6 +201,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->dsum, mp));
     TRY(dev_alloc(&c->fcorr, mp));
     TRY(dev_alloc(&c->ddense, mp));
+    TRY(dev_alloc(&c->fcorr2, mp));
     TRY(dev_alloc(&c->dots, mp));
     TRY(dev_alloc(&c->ev_count, (size_t)c->npanels));
     TRY(dev_alloc(&c->ev_idx, mp));
@@ -271,7 +272,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
     void *ptrs[] = {c->X, c->X2, c->xpx, c->vx, c->s1, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
-                    c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->fcorr, c->ddense, c->dots, c->ev_count, c->ev_idx,
+                    c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->fcorr, c->ddense, c->fcorr2, c->dots, c->ev_count, c->ev_idx,
                     c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -99,6 +99,7 @@ struct hb_ctx {
     double *partial = nullptr;                              // nsplit x m_pad
     double *dsum = nullptr;                                 // m_pad: the partials added up (by the next mat-vec launch)
     double *fcorr = nullptr;                                // m_pad: k_fwd's corrections for the group after next (sentinel-prefilled like dsum)
+    double *fcorr2 = nullptr;                               // m_pad: k_fold_dense's sums of a panel's own far sub-blocks (sentinel-prefilled)
     double *ddense = nullptr;                               // m_pad: the dense chain's changes of effect by marker (k_chain_dense -> k_fold_dense; sentinel-prefilled)
     double *dots = nullptr;                                 // m_pad (hb_ctx_dot)
     int nchunks = 0, nsplit = 0;

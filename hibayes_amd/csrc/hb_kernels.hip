@@ -682,7 +682,8 @@ __global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
 __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, unsigned *__restrict__ flags, int32_t *__restrict__ ev_count,
                                                     int np, unsigned long long *__restrict__ dsum, int m_pad, int p_lo,
                                                     unsigned long long *__restrict__ fcorr, unsigned long long *__restrict__ dd,
-                                                    unsigned long long *__restrict__ mbs, int mb_lo, int mb_hi)
+                                                    unsigned long long *__restrict__ mbs, int mb_lo, int mb_hi,
+                                                    unsigned long long *__restrict__ fc2)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (acc && i < HB_ACC_N) acc[i] = 0.0; // (null: a later range of the same sweep keeps the sums)
@@ -693,6 +694,8 @@ __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, un
         for (int k = i; k < m_pad; k += stride) fcorr[k] = ~0ull;
     if (dd)
         for (int k = i; k < m_pad; k += stride) dd[k] = ~0ull;
+    if (fc2)
+        for (int k = i; k < m_pad; k += stride) fc2[k] = ~0ull;
     if (mbs) // (the dense update rows poll the group's bound on max |yadj| together with its changes: "not written yet")
         for (int k = mb_lo + i; k < mb_hi; k += stride) mbs[k] = ~0ull;
 }
@@ -3098,7 +3101,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
                        reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad, pb,
                        (c->fwd_group || dense) ? reinterpret_cast<unsigned long long *>(c->fcorr) : nullptr,
                        dense ? reinterpret_cast<unsigned long long *>(c->ddense) : nullptr,
-                       (dense && c->precise == 2) ? reinterpret_cast<unsigned long long *>(c->mb) : nullptr, 1 + pb / c->D, c->npanels + 2);
+                       (dense && c->precise == 2) ? reinterpret_cast<unsigned long long *>(c->mb) : nullptr, 1 + pb / c->D, c->npanels + 2,
+                       dense ? reinterpret_cast<unsigned long long *>(c->fcorr2) : nullptr);
     const bool fx = c->precise == 2;
     if (fx) {
         HB_HIP(hipEventRecord(c->ev_dot[0], sA));
@@ -3143,8 +3147,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     if (dense) pv.fcorr = c->fcorr;
     auto launch_the_chain = [&](hipStream_t st) -> int {
         if (dense) {
-            if (model == 5) hipLaunchKernelGGL((k_chain_dense<true>), dim3(1), dim3(512), persist_smem(c->P), st, c->d_in, cv, pv, c->ddense);
-            else hipLaunchKernelGGL((k_chain_dense<false>), dim3(1), dim3(512), persist_smem(c->P), st, c->d_in, cv, pv, c->ddense);
+            if (model == 5) hipLaunchKernelGGL((k_chain_dense<true>), dim3(1), dim3(512), persist_smem(c->P), st, c->d_in, cv, pv, c->ddense, c->fcorr2);
+            else hipLaunchKernelGGL((k_chain_dense<false>), dim3(1), dim3(512), persist_smem(c->P), st, c->d_in, cv, pv, c->ddense, c->fcorr2);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_dense launch: ") + hipGetErrorString(e));
             return HB_OK;
@@ -3179,9 +3183,9 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     int warm = 4;
     if (const char *e = getenv("HB_WARM")) warm = std::max(0, std::min(16, atoi(e)));
     if (alone || (group_chain && !c->warm_group) || fwd || dense) warm = 0;
-    if (dense && c->L > 0) {
+    if (dense) { // (Lb + 1 target panels are open at any time: Lb ahead for their band, the chain's own for its far sub-blocks)
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
-        hipLaunchKernelGGL(k_fold_dense, dim3(8 * c->L), dim3(256), 0, c->s_upd, cv, pv, c->ddense);
+        hipLaunchKernelGGL(k_fold_dense, dim3(8 * (c->L + 1)), dim3(256), 0, c->s_upd, cv, pv, c->ddense, c->fcorr2, c->L + 1);
         HB_HIP(hipGetLastError());
     }
     bool warm_dense = false;
@@ -3189,7 +3193,6 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         int wd = 0; // (measured at n = 50k: 4.45-4.52 ms per 200 panels with 0, 2, 4, 8 or 16 workgroups per XCD, 2 or 4 panels ahead: no gain, off by default)
         if (const char *e = getenv("HB_WARM_DENSE")) wd = std::max(0, std::min(16, atoi(e)));
         if (wd > 0) {
-            if (c->L <= 0) HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
             int ahead = D + 1;
             if (const char *e = getenv("HB_WARM_AHEAD")) ahead = std::max(1, atoi(e));
             hipLaunchKernelGGL(k_warm_dense, dim3(8 * wd), dim3(256), 0, c->s_upd, cv, pv, wd, ahead, reinterpret_cast<int *>(c->flags + 48));
@@ -3247,7 +3250,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     }
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
-    if (warm || fwd || (dense && c->L > 0) || warm_dense) {
+    if (warm || fwd || dense || warm_dense) {
         HB_HIP(hipEventRecord(c->ev_upd[0], c->s_upd));
         HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[0], 0));
     }
