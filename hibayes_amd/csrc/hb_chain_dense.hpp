@@ -33,7 +33,10 @@
 #pragma once
 
 #define HBD_P 512
-#define HBD_NEAR 2 /* a sub-block's changes are applied by the chain itself to the next HBD_NEAR sub-blocks of its panel; the farther ones get them from k_fold_dense (fcorr2[]) */
+#ifndef HBD_NEAR
+#define HBD_NEAR 2
+#endif
+// HBD_NEAR: a sub-block's changes are applied by the chain itself to the next HBD_NEAR sub-blocks of its panel; the farther ones get them from k_fold_dense (fcorr2[])
 #define HBD_SENT(x) (__double_as_longlong(x) == -1ll)
 
 template <bool LASSO>

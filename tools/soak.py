@@ -1,5 +1,5 @@
 """Development aid: long runs for stability (no device-side time-outs, sane posterior) — config 2 (BayesCpi n=10k m=100k, 5000 iterations)
-and a few thousand sweeps at config-3 size."""
+and a few thousand sweeps at config-3 size; `soak.py dense`: BayesRR / A / L at config-3 size."""
 import sys, os, time, ctypes as ct
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -27,6 +27,21 @@ def run(n, m, model, niter, nburn, seed=20240901):
     print("  done: h2-ish %.3f, max|r+u-(y-mu)| %.2e" % (info.vara / (info.vara + info.vare), np.max(np.abs(r + u - (y - info.mu)))), flush=True)
     c.L.hb_run_destroy(run); c.close()
 
-run(10000, 100000, "BayesCpi", 5000, 2500)
-run(50000, 500000, "BayesCpi", 3000, 1500)
-run(50000, 500000, "BayesR", 600, 300)
+if len(sys.argv) > 1 and sys.argv[1] == "dense":  # the models in which every marker moves (k_chain_dense, k_fold_dense)
+    nfail = 0
+    cases = (("BayesRR", 50000, 500000, 3000), ("BayesA", 50000, 500000, 1500), ("BayesL", 50000, 500000, 1500),
+             ("BayesRR", 20000, 100000 + 300, 3000))  # (the last: ragged last panel)
+    if len(sys.argv) > 2 and sys.argv[2] == "rr":
+        cases = (("BayesRR", 50000, 500000, 3000),) * 3
+    for model, n, m, it in cases:
+        try:
+            run(n, m, model, it, 500)
+        except Exception as e:  # a device-side time-out: say so and go on, the count is the result
+            nfail += 1
+            print("  FAILED %s n=%d m=%d: %s" % (model, n, m, e), flush=True)
+    print("dense soak: %d of %d runs failed" % (nfail, len(cases)), flush=True)
+    sys.exit(1 if nfail else 0)
+else:
+    run(10000, 100000, "BayesCpi", 5000, 2500)
+    run(50000, 500000, "BayesCpi", 3000, 1500)
+    run(50000, 500000, "BayesR", 600, 300)
