@@ -340,6 +340,8 @@ __device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q,
                 if (ld_flag(q.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) { dead = true; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
+            // (the last word is there and an earlier one is not yet visible: look again, but never without the bound on the wait)
+            if (!dead && (ld_flag(q.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS)) dead = true;
             if (dead) {
                 if (lane == 0) { st_flag(q.flags + HB_FLAG_ABORT, 1u); st_flag(q.flags + 8, (unsigned)q.p1); }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
