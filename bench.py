@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--cpu-m", type=int, default=8000, help="markers of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-sweeps", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check (no GPU needed): the ranks rendezvous, count each other with one all-reduce and rank 0 prints "
+                         "a JSON line with n_gpus = the world size; nothing is measured")
     return ap.parse_args()
 
 
@@ -315,13 +318,53 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
     return elapsed, ev, info.nnz, ms
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU, exactly as the driver's
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` does;
+    rank 0's JSON line is the child's stdout, i.e. ours. (--m travels as HB_BENCH_M: see parse().)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+        elif a == "--m":
+            skip = True
+        elif not a.startswith("--m="):
+            argv.append(a)
+    env = dict(os.environ, HB_BENCH_M=str(args.m), MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    print("[bench] --gpus %d without a launcher: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     comm = None
     import torch
+    if args.dry_run:
+        seen = 1
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group(backend="gloo")
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_counted_by_all_reduce": seen, "gpus_asked_for": args.gpus,
+                              "config": {"collective": "gloo all_reduce over %d ranks (launcher check only)" % world}}))
+        return
     if world > 1:
         import torch.distributed as dist
         local_rank = local_rank % max(1, torch.cuda.device_count())  # (several ranks on one GPU: --backend gloo only)

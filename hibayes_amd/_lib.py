@@ -77,6 +77,7 @@ class BayesOut(C.Structure):
         ("setup_seconds", C.c_double), ("loop_seconds", C.c_double),
         ("iters_done", C.c_int32),
         ("mean_events", C.c_double),
+        ("sweeps_replayed", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -111,6 +112,7 @@ class RunInfo(C.Structure):
         ("vara", C.c_double), ("vare", C.c_double), ("varg", C.c_double), ("mu", C.c_double),
         ("pi", C.c_double * HB_MAX_FOLD), ("mean_events", C.c_double), ("mean_misses", C.c_double), ("mean_redo", C.c_double),
         ("loop_seconds", C.c_double), ("setup_seconds", C.c_double), ("gram_seconds", C.c_double),
+        ("sweeps_replayed", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -166,6 +168,7 @@ SYMBOLS = [
     "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec", "hb_ctx_matvec_stamps", "hb_ctx_set_layout", "hb_ctx_get_layout",
     "hb_ctx_download_gram_band", "hb_ctx_set_adaptive", "hb_ctx_get_pipeline", "hb_ctx_get_events", "hb_ctx_pipeline_note", "hb_ctx_matmul",
     "hb_comm_unique_id", "hb_comm_init", "hb_comm_world", "hb_comm_rank", "hb_comm_selftest", "hb_comm_destroy",
+    "hb_ctx_debug_inject_abort",
     "hb_run_create", "hb_run_step", "hb_run_state", "hb_run_ctx", "hb_run_finish", "hb_run_destroy",
 ]
 
@@ -258,6 +261,7 @@ def lib():
     L.hb_ctx_set_layout.argtypes = [vp, i32, i32]
     L.hb_ctx_get_layout.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.hb_ctx_matvec_stamps.argtypes = [vp, C.POINTER(LaunchStats)]
+    L.hb_ctx_debug_inject_abort.argtypes = [vp, i32, i32]
     L.hb_run_create.argtypes = [C.POINTER(BayesArgs), C.POINTER(vp)]
     L.hb_run_step.argtypes = [vp, i32, C.POINTER(i32)]
     L.hb_run_state.argtypes = [vp, C.POINTER(RunInfo)]

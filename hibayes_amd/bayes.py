@@ -207,7 +207,8 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
     res["MCMCsamples"] = mc
     res["alpha_sd"] = bufs["alpha_sd"]
     res["timing"] = {"setup_seconds": o.setup_seconds, "loop_seconds": o.loop_seconds,
-                     "iters_done": o.iters_done, "mean_events": o.mean_events}
+                     "iters_done": o.iters_done, "mean_events": o.mean_events,
+                     "sweeps_replayed": o.sweeps_replayed}
     res["nzct"], res["n_records"] = o.nzct, o.n_records
     del keep
     return res

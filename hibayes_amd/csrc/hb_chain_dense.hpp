@@ -126,6 +126,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
             if (__any(bad)) {
                 const unsigned long long t0 = wall_clock64();
+                unsigned looks = 0;
                 for (;;) {
                     dj = ld_sc1(&v.dsum[j]);
                     fc = ld_sc1(&fcp[j]);
@@ -138,9 +139,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (ld_flag(pv.flags + HB_FLAG_ABORT) || own) {
                         if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); misc[2] = 1; }
                         if (bad) { st_flag(pv.flags + 9, (unsigned)p + 1u); st_flag(pv.flags + 10, (HBD_SENT(dj) ? 1u : 2u) + (own ? 0x100u : 0u)); }
+                        { // (diagnostics: the first lane of the wave that is still waiting says for what)
+                            const unsigned long long bm = __ballot(bad);
+                            if (bm && lane == __ffsll((long long)bm) - 1)
+                                hb_abort_log(pv.flags, HBD_SENT(dj) ? HB_LOG_CHAIN_DOT : HB_LOG_CHAIN_FCORR, own, (unsigned)j, (unsigned)p,
+                                             (unsigned long long)__double_as_longlong(HBD_SENT(dj) ? dj : fc));
+                        }
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    hb_poll_pause(looks, 1);
                 }
             }
             rhs = dj - (use_fc ? fc : 0.0);
@@ -177,15 +184,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if ((s) > HBD_NEAR) { /* the far sub-blocks' share, summed by k_fold_dense while the near ones were being applied */     \
                 if (__any(HBD_SENT(fc2))) {                                                                                       \
                     const unsigned long long t0_ = wall_clock64();                                                                \
+                    unsigned looks_ = 0;                                                                                          \
                     for (;;) {                                                                                                    \
                         fc2 = ld_sc1(&fcorr2[j]);                                                                                 \
                         if (!__any(HBD_SENT(fc2))) break;                                                                         \
-                        if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0_ > HB_TIMEOUT_TICKS) {                       \
-                            if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); st_flag(pv.flags + 9, (unsigned)p + 1u); st_flag(pv.flags + 10, 3u); } \
+                        const bool own_ = wall_clock64() - t0_ > HB_TIMEOUT_TICKS;                                                \
+                        if (ld_flag(pv.flags + HB_FLAG_ABORT) || own_) {                                                          \
+                            if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); st_flag(pv.flags + 9, (unsigned)p + 1u); st_flag(pv.flags + 10, 3u); misc[2] = 1; } \
+                            const unsigned long long bm_ = __ballot(HBD_SENT(fc2));                                               \
+                            if (bm_ && lane == __ffsll((long long)bm_) - 1)                                                       \
+                                hb_abort_log(pv.flags, HB_LOG_CHAIN_FC2, own_, (unsigned)j, (unsigned)p, ~0ull);                  \
                             fc2 = 0.0;                                                                                            \
                             break;                                                                                                \
                         }                                                                                                         \
-                        __builtin_amdgcn_s_sleep(1);                                                                              \
+                        hb_poll_pause(looks_, 1);                                                                                 \
                     }                                                                                                             \
                 }                                                                                                                 \
                 rhs -= fc2;                                                                                                       \
@@ -347,16 +359,20 @@ __global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view p
             if (__any(HBD_SENT(d))) {
                 const double *dp = dptr(st);
                 const unsigned long long t0 = wall_clock64();
+                unsigned looks = 0;
                 for (;;) {
                     d = ld_sc1(dp);
                     if (!__any(HBD_SENT(d))) break;
                     const bool own = wall_clock64() - t0 > HB_TIMEOUT_TICKS;
                     if (ld_flag(pv.flags + HB_FLAG_ABORT) || own) {
                         if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); s_abort = 1; st_flag(pv.flags + 11, (unsigned)q + 1u); st_flag(pv.flags + 12, (unsigned)st + (own ? 0x100u : 0u)); }
+                        const unsigned long long bm = __ballot(HBD_SENT(d));
+                        if (bm && lane == __ffsll((long long)bm) - 1)
+                            hb_abort_log(pv.flags, HB_LOG_FOLD_DD, own, (unsigned)(dp - dd), (unsigned)q | ((unsigned)st << 16), ~0ull);
                         dead = true;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    hb_poll_pause(looks, 1);
                 }
                 if (st + 1 < nsteps) dn = ld_sc1(dptr(st + 1)); // (looked at before this step was there: likely stale)
             }

@@ -156,8 +156,13 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
             delete c;
             return hb_fail(HB_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         }
-        if (hipStreamCreateWithFlags(&c->s_chain, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&c->s_upd, hipStreamNonBlocking) != hipSuccess ||
+        // HB_STREAM_PRIO=1 (an A/B for the dense stall): the streams of the persistent kernels at the highest
+        // priority, so that they can never share a hardware queue with the stream of the mat-vec launches
+        int plo = 0, phi = 0;
+        const bool prio = getenv("HB_STREAM_PRIO") && atoi(getenv("HB_STREAM_PRIO")) != 0 && hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess;
+        auto mk = [&](hipStream_t *st) { return prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, phi) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+        if (mk(&c->s_chain) != hipSuccess ||
+            mk(&c->s_upd) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) {
             hb_ctx_destroy(c);
             return hb_fail(HB_ERR_HIP, "hipStreamCreate failed");
@@ -214,6 +219,10 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->hot_list, (size_t)(c->npanels + 1) * 256));
     TRY(dev_alloc(&c->thr0f, mp + 1024));
     TRY(dev_alloc(&c->hot_n, (size_t)c->npanels));
+    if (getenv("HB_DEBUG_ABORT")) {
+        TRY(dev_alloc(&c->ldiag, ((size_t)c->npanels + 2) * 4));
+        c->ldiag_nblk.assign((size_t)c->npanels + 2, 0);
+    }
     {
         hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&c->h_acc), sizeof(double) * HB_ACC_N);
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_in), sizeof(hb_sweep_in));
@@ -271,9 +280,10 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
+    if (c->s_dbg) (void)hipStreamDestroy(c->s_dbg);
     void *ptrs[] = {c->X, c->X2, c->xpx, c->vx, c->s1, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->fcorr, c->ddense, c->fcorr2, c->dots, c->ev_count, c->ev_idx,
-                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa};
+                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa, c->snap, c->ldiag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     blocks_free(c);
@@ -759,30 +769,122 @@ int hb_ctx_matmul(hb_ctx *c, const double *A, int64_t ldA, int32_t R, double *ou
     return HB_OK;
 }
 
+// Diagnostics of a pipeline time-out (HB_DEBUG_ABORT=1): the abort log of the waiters (hb_abort_log), what memory holds now at the
+// words they were waiting for, and the start / end of the mat-vec launches around the stall (hb_ldiag_note).
+static void print_abort_diagnostics(hb_ctx *c)
+{
+    std::vector<unsigned> f(4096, 0u);
+    if (hipMemcpy(f.data(), c->flags, sizeof(unsigned) * 4096, hipMemcpyDeviceToHost) != hipSuccess) return;
+    const unsigned nlog = std::min<unsigned>(f[64], 480u);
+    static const char *kinds[] = {"?", "chain<-dsum", "chain<-fcorr", "chain<-fcorr2", "fold<-dd", "update-rows<-dd/mb", "wait_ge", "group-chain"};
+    unsigned long long first_clock = ~0ull;
+    int stall_panel = -1;
+    fprintf(stderr, "abort log: %u records (chain_done %u)\n", f[64], f[0]);
+    for (unsigned i = 0; i < nlog; i++) {
+        const unsigned *r = f.data() + 128 + 8 * i;
+        const unsigned kind = r[0] & 0xffffu, own = (r[0] >> 16) & 1u, xcc = (r[0] >> 20) & 15u;
+        const unsigned long long clk = ((unsigned long long)r[5] << 32) | r[4], seen = ((unsigned long long)r[7] << 32) | r[6];
+        unsigned long long mem = 0;
+        const double *src = kind == 1 ? c->dsum : kind == 2 ? c->fcorr : kind == 3 ? c->fcorr2 : kind == 4 ? c->ddense : nullptr;
+        if (src && r[1] < (unsigned)c->m_pad) (void)hipMemcpy(&mem, src + r[1], 8, hipMemcpyDeviceToHost);
+        if (own && clk < first_clock) first_clock = clk;
+        if ((kind == 1 || kind == 2) && stall_panel < 0) stall_panel = (int)r[2];
+        if (i < 24 || own)
+            fprintf(stderr, "  [%3u] %-18s own=%u xcd=%u block=%u a=%u (panel %d, +%d) b=%u/%u clock=%llu saw=%016llx memory-now=%016llx\n", i,
+                    kinds[std::min(kind, 7u)], own, xcc, r[3], r[1], (int)(r[1] / (unsigned)c->P), (int)(r[1] % (unsigned)c->P), r[2] & 0xffffu, r[2] >> 16, clk, seen, mem);
+    }
+    if (c->ldiag) {
+        const int G = (c->npanels + c->D - 1) / c->D;
+        std::vector<unsigned long long> ld((size_t)(c->npanels + 2) * 4, 0ull);
+        (void)hipMemcpy(ld.data(), c->ldiag, sizeof(unsigned long long) * ld.size(), hipMemcpyDeviceToHost);
+        const int gs = stall_panel >= 0 ? stall_panel / c->D : 0;
+        fprintf(stderr, "mat-vec launches around group %d (first own time-out at clock %llu; 100 MHz):\n", gs, first_clock);
+        for (int g = std::max(0, gs - 3); g <= std::min(G, gs + 4); g++)
+            fprintf(stderr, "  launch %4d: start %llu (%+.1f us vs the time-out)  last block end %llu (%+.1f us)  blocks finished %llu of %d\n", g, ld[4 * (size_t)g],
+                    ((double)ld[4 * (size_t)g] - (double)first_clock) / 100.0, ld[4 * (size_t)g + 1], ((double)ld[4 * (size_t)g + 1] - (double)first_clock) / 100.0,
+                    ld[4 * (size_t)g + 2], g < (int)c->ldiag_nblk.size() ? c->ldiag_nblk[g] : -1);
+    }
+}
+
 static int fetch_acc(hb_ctx *c)
 {
     HB_HIP(hipMemcpyAsync(c->h_acc, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipMemcpyAsync(c->h_flags, c->flags, 256, hipMemcpyDeviceToHost, c->stream));
     if (c->blk_n) HB_HIP(hipMemcpyAsync(c->h_blk, c->blk, sizeof(double) * c->blk_n, hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
-    if (c->h_flags[1]) {
-        char msg[256];
-        snprintf(msg, sizeof msg, "device pipeline timed out waiting on a flag (sweep aborted) [chain_done %u; gave up: update rows waiting for %u, chain at panel %u (%u), fold at panel %u step %u, fold workgroups started %u, targets delivered %u]",
-                 c->h_flags[0], c->h_flags[8], c->h_flags[9], c->h_flags[10], c->h_flags[11], c->h_flags[12], c->h_flags[13], c->h_flags[14]);
-        if (getenv("HB_DEBUG_ABORT")) {
-            const unsigned *f = c->h_flags;
-            fprintf(stderr, "abort clocks (100 MHz): chain finished its first panel at %llu; fold gave up at %llu after waiting since %llu; it last read %08x%08x at dd[%u]\n",
-                    ((unsigned long long)f[17] << 32) | f[16], ((unsigned long long)f[21] << 32) | f[20], ((unsigned long long)f[23] << 32) | f[22], f[25], f[24], f[26]);
-            unsigned long long w[9];
-            int evc[4] = {0, 0, 0, 0};
-            const double *src[9] = {c->ddense, c->ddense + 64, c->ddense + 512, c->fcorr + 512, c->fcorr + 1024, c->dsum, c->dsum + 512, c->dsum + 1024, c->dsum + 1536};
-            for (int i = 0; i < 9; i++) (void)hipMemcpy(&w[i], src[i], 8, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(evc, c->ev_count, 16, hipMemcpyDeviceToHost);
-            fprintf(stderr, "abort state: dd[0] %llx dd[64] %llx dd[512] %llx fcorr[512] %llx fcorr[1024] %llx dsum[0,512,1024,1536] %llx %llx %llx %llx ev_count %d %d %d %d\n",
-                    w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], evc[0], evc[1], evc[2], evc[3]);
-        }
-        return hb_fail(HB_ERR_HIP, msg);
+    c->aborted = false;
+    // (a sharded sweep: the rank whose pipeline gave up poisons the sums it contributes, so every rank sees a NaN here — hb_run.hip)
+    if (c->h_flags[1] || c->h_acc[HB_ACC_EVENTS] != c->h_acc[HB_ACC_EVENTS]) {
+        c->aborted = true;
+        char msg[320];
+        snprintf(msg, sizeof msg, "device pipeline timed out waiting on a flag (sweep aborted) [chain_done %u; gave up: update rows waiting for %u, chain at panel %u (%u), fold at panel %u step %u, fold workgroups started %u, targets delivered %u%s]",
+                 c->h_flags[0], c->h_flags[8], c->h_flags[9], c->h_flags[10], c->h_flags[11], c->h_flags[12], c->h_flags[13], c->h_flags[14],
+                 c->h_flags[1] ? "" : "; raised on another rank");
+        if (getenv("HB_DEBUG_ABORT") && c->h_flags[1]) print_abort_diagnostics(c);
+        return hb_fail(HB_ERR_ABORTED, msg);
     }
+    return HB_OK;
+}
+
+// ---- snapshot / restore around a sweep (hb_internal.hpp) ----
+int hb_ctx_snapshot(hb_ctx *c, int model_index, bool store, bool count_pip)
+{
+    std::vector<hb_ctx::snap_seg> segs;
+    size_t off = 0;
+    auto add = [&](void *p, size_t bytes) {
+        if (!p || !bytes) return;
+        segs.push_back({p, off, bytes});
+        off += (bytes + 255) / 256 * 256;
+    };
+    const size_t mp = (size_t)c->m_pad;
+    add(c->g, sizeof(double) * mp);
+    add(c->tracker, mp);
+    add(c->r, sizeof(double) * (size_t)c->ld);
+    add(c->r32, sizeof(float) * (size_t)c->ld);
+    add(c->u, sizeof(double) * (size_t)c->ld);
+    if (model_index == 5) add(c->vargL, sizeof(double) * mp);
+    if (store) {
+        add(c->alpha_sum, sizeof(double) * mp);
+        add(c->alpha_sq, sizeof(double) * mp);
+    }
+    if (count_pip) {
+        add(c->nzrate, sizeof(uint32_t) * mp);
+        if (c->nw) {
+            add(c->wflag, (size_t)c->nw);
+            add(c->wppa, sizeof(double) * (size_t)c->nw);
+        }
+    }
+    if (off > c->snap_cap) {
+        HB_HIP(hipStreamSynchronize(c->stream));
+        if (c->snap) (void)hipFree(c->snap);
+        c->snap = nullptr;
+        c->snap_cap = 0;
+        // (room for every segment a later sweep of the run may add: the counters and moments start after the burn-in)
+        const size_t cap = off + (sizeof(double) * 3 + sizeof(uint32_t)) * mp + 9 * (size_t)c->nw + 8 * 256;
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->snap), cap));
+        c->snap_cap = cap;
+    }
+    c->snap_segs = segs;
+    return hbk_copy_segs(c, segs, false);
+}
+
+int hb_ctx_restore(hb_ctx *c)
+{
+    if (!c->snap || c->snap_segs.empty()) return hb_fail(HB_ERR_INVALID, "hb_ctx_restore: no snapshot");
+    HB_HIP(hipStreamSynchronize(c->stream)); // (every kernel of the aborted sweep has left: the fetch waited for them)
+    int rc = hbk_copy_segs(c, c->snap_segs, true);
+    if (rc) return rc;
+    HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * 4096, c->stream));
+    c->aborted = false;
+    return HB_OK;
+}
+
+extern "C" int hb_ctx_debug_inject_abort(hb_ctx *c, int32_t panel, int32_t times)
+{
+    if (!c) return hb_fail(HB_ERR_INVALID, "hb_ctx_debug_inject_abort: null context");
+    c->inject_abort_panel = times > 0 ? panel : -1;
+    c->inject_abort_times = times;
+    if (panel >= 0 && !c->s_dbg) HB_HIP(hipStreamCreateWithFlags(&c->s_dbg, hipStreamNonBlocking));
     return HB_OK;
 }
 

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void k_dotq2(dq_view v, upd_view uq)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long t0 = 0;
-    if (v.stamp) t0 = wall_clock64();
+    if (v.stamp || v.ldiag) t0 = wall_clock64();
     int b = blockIdx.x;
     if (b < v.nfin) { // (finalize blocks first: see dotq_block)
         const int col = b * 64 + threadIdx.x;
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(64) void k_dotq2(dq_view v, upd_view uq)
         v.stamp[2 * (size_t)blockIdx.x] = t0;
         v.stamp[2 * (size_t)blockIdx.x + 1] = wall_clock64();
     }
+    if (v.ldiag) hb_ldiag_note(v.ldiag, t0);
 }
 static constexpr int q2_lds(int cpl, int rs) { return 2 * ((64 * cpl / (4096 / rs)) * HBQ_SLOT + ((HB_ND + 1024 / rs - 1) / (1024 / rs)) * 1024); }
 
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 {
     __shared__ __attribute__((aligned(16))) char smem[2048 + 4096 + 16]; // the update rows' move lists
     unsigned long long t0 = 0;
-    if (v.stamp) t0 = wall_clock64();
+    if (v.stamp || v.ldiag) t0 = wall_clock64();
     int b = blockIdx.x;
     if (b < v.nfin) {
         const int col = b * 64 + threadIdx.x;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         v.stamp[2 * (size_t)blockIdx.x] = t0;
         v.stamp[2 * (size_t)blockIdx.x + 1] = wall_clock64();
     }
+    if (v.ldiag) hb_ldiag_note(v.ldiag, t0);
 }
 
 // int8 column-major -> the packed layout above; thread = one 32-bit word (16 individuals) of one column. Codes must be 0..3

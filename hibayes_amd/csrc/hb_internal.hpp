@@ -157,7 +157,28 @@ struct hb_ctx {
     bool chain_alone = false; // hb_ctx_set_profiling bit 2: the pipeline's kernels, mat-vec launches first, the chain alone afterwards
     hb_sweep_timing timing{};
     std::vector<hipEvent_t> ev_pool;
+
+    // ---- an aborted sweep is replayed ----
+    // Every wait of the persistent pipeline is bounded; a waiter that gives up raises the abort flag, all kernels of the sweep
+    // leave, and fetch_acc() reports HB_ERR_ABORTED. The state a sweep changes (effects, residual, u, the posterior counters) is
+    // copied aside before each sweep of a run (hb_ctx_snapshot: one kernel, a few MB) and put back by hb_ctx_restore(); the
+    // per-SNP draws are counter-based, so the replayed sweep is the same chain.
+    struct snap_seg { void *live; size_t off, bytes; };
+    char *snap = nullptr;
+    size_t snap_cap = 0;
+    std::vector<snap_seg> snap_segs; // what the last snapshot holds
+    bool aborted = false;            // the last fetch found the abort flag raised
+    int inject_abort_panel = -1;     // debug hook (hb_ctx_debug_inject_abort): the next sweeps are aborted once chain_done reaches this panel
+    int inject_abort_times = 0;
+    hipStream_t s_dbg = nullptr;
+    // HB_DEBUG_ABORT=1: start / latest end / finished blocks of every mat-vec launch of the sweep ([npanels + 2][4], hb_ldiag_note)
+    unsigned long long *ldiag = nullptr;
+    std::vector<int> ldiag_nblk;
 };
+
+extern "C" int hb_ctx_snapshot(hb_ctx *c, int model_index, bool store, bool count_pip);
+extern "C" int hb_ctx_restore(hb_ctx *c);
+int hbk_copy_segs(hb_ctx *c, const std::vector<hb_ctx::snap_seg> &segs, bool restore);
 
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed);
 extern "C" int hb_ctx_sweep_range(hb_ctx *c, const hb_sweep_in *in, int block, int nblocks);

@@ -27,8 +27,21 @@
 #define HB_FLAG_CHAIN_DONE 0
 #define HB_FLAG_ABORT 1
 #define HB_FLAG_XCC 2               /* 1 + the XCD the chain workgroup runs on (k_warm) */
-#define HB_NFLAGS 64                /* words in the flag block */
+#define HB_NFLAGS 72                /* words in the flag block that every sweep clears */
 #define HB_TIMEOUT_TICKS 300000000ull /* wall_clock64() runs at 100 MHz: 3 s */
+// Abort log (diagnostics of a pipeline time-out, read by fetch_acc in hb_ctx.hip): whoever leaves a wait because the sweep is
+// being aborted appends one record of 8 words — what it was waiting for, whether the time-out was its own, the clock, the value
+// it last saw. flags[HB_FLAG_LOGN] counts the records, they start at flags + HB_LOG_BASE (the flag block has 4096 words).
+#define HB_FLAG_LOGN 64
+#define HB_LOG_BASE 128
+#define HB_LOG_CAP 480
+#define HB_LOG_CHAIN_DOT 1    /* k_chain_dense: a = marker index into dsum[], b = panel */
+#define HB_LOG_CHAIN_FCORR 2  /* ... into fcorr[] */
+#define HB_LOG_CHAIN_FC2 3    /* ... into fcorr2[] */
+#define HB_LOG_FOLD_DD 4      /* k_fold_dense: a = index into dd[], b = target panel | step << 16 */
+#define HB_LOG_UPD_DENSE 5    /* update_rows_dense: a = first panel of the group, b = block */
+#define HB_LOG_WAIT_GE 6      /* wait_ge: a = word, b = value wanted */
+#define HB_LOG_GROUP 7        /* k_chain_group / k_fwd / k_chain_persist: a = code, b = panel or group */
 
 __device__ __forceinline__ unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_flag(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -36,6 +49,44 @@ __device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_
 __device__ __forceinline__ int ld_sc1(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void hb_abort_log(unsigned *flags, unsigned kind, bool own, unsigned a, unsigned b, unsigned long long seen)
+{
+    const unsigned i = atomicAdd(flags + HB_FLAG_LOGN, 1u);
+    if (i >= HB_LOG_CAP) return;
+    unsigned *r = flags + HB_LOG_BASE + 8 * i;
+    const unsigned long long now = wall_clock64();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    r[0] = kind | (own ? 0x10000u : 0u) | ((xcc & 15u) << 20);
+    r[1] = a;
+    r[2] = b;
+    r[3] = blockIdx.x;
+    r[4] = (unsigned)now;
+    r[5] = (unsigned)(now >> 32);
+    r[6] = (unsigned)seen;
+    r[7] = (unsigned)(seen >> 32);
+}
+
+// Polling pace. A waiter looks again after a short sleep; HB_BACKOFF builds (an A/B for the dense stall) stretch the
+// sleep once a wait has lasted a few hundred looks, so that a long wait stops being continuous traffic on the memory path.
+#ifndef HB_BACKOFF
+#define HB_BACKOFF 0
+#endif
+__device__ __forceinline__ void hb_poll_pause(unsigned &looks, int base)
+{
+#if HB_BACKOFF
+    looks++;
+    if (looks > 4096u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+    else if (looks > 256u) __builtin_amdgcn_s_sleep(64);
+    else if (base <= 1) __builtin_amdgcn_s_sleep(1);
+    else __builtin_amdgcn_s_sleep(8);
+#else
+    (void)looks;
+    if (base <= 1) __builtin_amdgcn_s_sleep(1);
+    else __builtin_amdgcn_s_sleep(8);
+#endif
+}
 
 // one lane waits until *word >= want; bounded; returns false when the run is being aborted
 template <int SLEEP = 8>
@@ -48,6 +99,7 @@ __device__ __forceinline__ bool wait_ge(unsigned *flags, int word, unsigned want
         if (wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
             st_flag(flags + HB_FLAG_ABORT, 1u);
             st_flag(flags + 8, want); // (diagnostics: who gave up, hb_ctx.hip fetch_acc)
+            hb_abort_log(flags, HB_LOG_WAIT_GE, true, (unsigned)word, want, ld_flag(flags + word));
             return false;
         }
         __builtin_amdgcn_s_sleep(SLEEP);
@@ -336,14 +388,20 @@ __device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q,
             // everything again afterwards (784 waves polling 17 words each would be traffic the chain does not need)
             const double *last = q.rq ? q.mbv : q.dd + (size_t)q.p0 * q.P + (ncol - 1);
             bool dead = false;
+            unsigned looks = 0;
             while (HBU_SENT(ld_sc1(last))) {
                 if (ld_flag(q.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) { dead = true; break; }
-                __builtin_amdgcn_s_sleep(8);
+                hb_poll_pause(looks, 8);
             }
             // (the last word is there and an earlier one is not yet visible: look again, but never without the bound on the wait)
             if (!dead && (ld_flag(q.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS)) dead = true;
             if (dead) {
-                if (lane == 0) { st_flag(q.flags + HB_FLAG_ABORT, 1u); st_flag(q.flags + 8, (unsigned)q.p1); }
+                if (lane == 0) {
+                    const bool own = wall_clock64() - t0 > HB_TIMEOUT_TICKS;
+                    st_flag(q.flags + HB_FLAG_ABORT, 1u);
+                    st_flag(q.flags + 8, (unsigned)q.p1);
+                    if ((blk & 31) == 0 || own) hb_abort_log(q.flags, HB_LOG_UPD_DENSE, own, (unsigned)q.p0, (unsigned)blk, (unsigned long long)__double_as_longlong(ld_sc1(last)));
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 return;
             }
@@ -558,7 +616,17 @@ struct dq_view {
     const uint8_t *X2;     // 2-bit resident layout (k_dotq2): first column of this launch, ld2 bytes per column
     int64_t ld2;
     unsigned long long *stamp; // optional (hb_ctx_set_profiling bit 3): [block][2] = wall_clock64() at the block's start and end
+    unsigned long long *ldiag; // optional (HB_DEBUG_ABORT): [0] start of the launch's first block, [1] latest block end, [2] blocks finished
 };
+
+// (diagnostics of a pipeline time-out: when did each mat-vec launch start and end — fetch_acc prints the launches around the stall)
+__device__ __forceinline__ void hb_ldiag_note(unsigned long long *ld, unsigned long long t0)
+{
+    if (threadIdx.x != 0) return;
+    if (blockIdx.x == 0) __hip_atomic_store(&ld[0], t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(&ld[1], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&ld[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <bool NT>
 __device__ __forceinline__ void hbq_dma16(unsigned voff, const int8_t *sbase, unsigned lds_dst)
@@ -669,12 +737,13 @@ __global__ __launch_bounds__(64) void k_dotq(dq_view v, upd_view uq)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long t0 = 0;
-    if (v.stamp) t0 = wall_clock64();
+    if (v.stamp || v.ldiag) t0 = wall_clock64();
     dotq_block(v, uq, smem);
     if (v.stamp && threadIdx.x == 0) {
         v.stamp[2 * (size_t)blockIdx.x] = t0;
         v.stamp[2 * (size_t)blockIdx.x + 1] = wall_clock64();
     }
+    if (v.ldiag) hb_ldiag_note(v.ldiag, t0);
 }
 
 #include "hb_dotq2.hpp"
@@ -2741,6 +2810,8 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
             v.fin_ncols = fin_ncols;
             const int nblk = v.nupd + v.nfin + v.ncg * v.nstages;
             v.stamp = nullptr;
+            v.ldiag = (c->ldiag && gidx >= 0 && gidx <= c->npanels) ? c->ldiag + 4 * (size_t)gidx : nullptr;
+            if (v.ldiag) c->ldiag_nblk[gidx] = nblk;
             if (c->lstamp && gidx >= 0 && gidx <= c->npanels && nblk <= HB_LSTAMP_BLOCKS) {
                 v.stamp = c->lstamp + (size_t)gidx * HB_LSTAMP_BLOCKS * 2;
                 c->lstamp_nblk[gidx] = nblk;
@@ -2780,6 +2851,8 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     v.fin_ncols = fin_ncols;
     const int nblk = v.nupd + v.nfin + ncg * nsplit;
     v.stamp = nullptr;
+    v.ldiag = (c->ldiag && gidx >= 0 && gidx <= c->npanels) ? c->ldiag + 4 * (size_t)gidx : nullptr;
+    if (v.ldiag) c->ldiag_nblk[gidx] = nblk;
     if (c->lstamp && gidx >= 0 && gidx <= c->npanels && nblk <= HB_LSTAMP_BLOCKS) {
         v.stamp = c->lstamp + (size_t)gidx * HB_LSTAMP_BLOCKS * 2;
         c->lstamp_nblk[gidx] = nblk;
@@ -2822,6 +2895,8 @@ static void launch_dotq(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st
     v.fin_ncols = fin_ncols;
     const int nblk = v.nupd + v.nfin + ncg * nsplit;
     v.stamp = nullptr;
+    v.ldiag = (c->ldiag && gidx >= 0 && gidx <= c->npanels) ? c->ldiag + 4 * (size_t)gidx : nullptr;
+    if (v.ldiag) c->ldiag_nblk[gidx] = nblk;
     if (c->lstamp && gidx >= 0 && gidx <= c->npanels && nblk <= HB_LSTAMP_BLOCKS) {
         v.stamp = c->lstamp + (size_t)gidx * HB_LSTAMP_BLOCKS * 2;
         c->lstamp_nblk[gidx] = nblk;
@@ -3083,6 +3158,16 @@ static hipError_t launch_chain_persist(hb_ctx *c, const chain_view &cv, const pe
 // residual deltas every few mat-vec groups (hb_ctx_sweep_range). A range is self-contained: the residual holds every earlier
 // move when it starts, so its corrections start from zero and its version ring from slot 0. `first` also prepares the
 // per-sweep data (k_pre, k_hotlist, zeroed sums), `last` closes the sweep (BayesL's variances, the residual's sums).
+// debug hook (hb_ctx_debug_inject_abort): raise the abort flag once the chain has published `panel` panels — what a waiter that
+// timed out does — so that the tests can show a replayed sweep to be the same chain
+__global__ void k_inject_abort(unsigned *flags, unsigned panel)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (ld_flag(flags + HB_FLAG_CHAIN_DONE) < panel && !ld_flag(flags + HB_FLAG_ABORT) && wall_clock64() - t0 < HB_TIMEOUT_TICKS)
+        __builtin_amdgcn_s_sleep(32);
+    st_flag(flags + HB_FLAG_ABORT, 1u);
+}
+
 static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int pe, bool first, bool last)
 {
     const int kp = kpad_for(model, n_fold);
@@ -3099,6 +3184,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     const bool dense = kp == 1 && (model == 1 || model == 2 || model == 5) && c->P == 512 && c->dense_chain && !c->chain_alone &&
                        getenv("HB_CHAIN_ALONE") == nullptr && c->L <= HB_LBMAX;
     const bool dense_upd = dense && getenv("HB_DENSE_UPD") == nullptr;
+    if (c->ldiag) HB_HIP(hipMemsetAsync(c->ldiag, 0, sizeof(unsigned long long) * 4 * ((size_t)c->npanels + 2), sA));
     hipLaunchKernelGGL(k_sweep_init, dim3(256), dim3(256), 0, sA, first ? c->acc : nullptr, c->flags, c->ev_count, c->npanels,
                        reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad, pb,
                        (c->fwd_group || dense) ? reinterpret_cast<unsigned long long *>(c->fcorr) : nullptr,
@@ -3215,6 +3301,12 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         hipLaunchKernelGGL(k_warm, dim3(8 * warm), dim3(256), 0, c->s_upd, pv, cv, kp, c->gram, c->P, ahead, warm, reinterpret_cast<int *>(c->flags + 48));
         HB_HIP(hipGetLastError());
     }
+    const bool inject = c->inject_abort_panel >= 0 && c->s_dbg && !alone;
+    if (inject) { // (debug hook: a fourth branch that aborts the sweep in mid-flight)
+        HB_HIP(hipStreamWaitEvent(c->s_dbg, c->ev_fork, 0));
+        hipLaunchKernelGGL(k_inject_abort, dim3(1), dim3(1), 0, c->s_dbg, c->flags, (unsigned)std::min(c->inject_abort_panel, np));
+        HB_HIP(hipGetLastError());
+    }
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
     // Residual versions advance per mat-vec group: version h = every panel of groups <= h applied. Mat-vec launch g
     // reads version g - Lv - 1 and, in one extra grid row, carries update(h = g - Lv): version h-1 -> h, which the
@@ -3256,6 +3348,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         HB_HIP(hipEventRecord(c->ev_upd[0], c->s_upd));
         HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[0], 0));
     }
+    if (inject) {
+        HB_HIP(hipEventRecord(c->ev_dot[0], c->s_dbg));
+        HB_HIP(hipStreamWaitEvent(sA, c->ev_dot[0], 0));
+    }
     const int sfin = slot2(ngroups - 1);
     if (sfin != 0) {
         HB_HIP(hipMemcpyAsync(c->r, c->r + (size_t)sfin * c->ld, sizeof(double) * c->ld, hipMemcpyDeviceToDevice, sA));
@@ -3282,6 +3378,11 @@ int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
         return c->pipeline ? enqueue_sweep_pipeline(c, in->model_index, in->n_fold, pb, pe, first, last)
                            : enqueue_sweep_kernels(c, in->model_index, in->n_fold, false);
     };
+    if (c->inject_abort_panel >= 0 && c->pipeline) { // (debug hook: such a sweep is launched directly, never from a cached graph)
+        const int rc = enqueue();
+        if (last && --c->inject_abort_times <= 0) c->inject_abort_panel = -1;
+        return rc;
+    }
     if (!c->use_graph) return enqueue();
     if (c->graph_model == -1) { // stale: something the graphs point at has moved
         for (auto &ge : c->gcache) {
@@ -3436,6 +3537,55 @@ int hbk_level_sums(hb_ctx *c, int term, double *dev_sums, int nlev)
 int hbk_level_axpy(hb_ctx *c, int term, const double *dev_delta)
 {
     hipLaunchKernelGGL(k_level_axpy, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->r, c->r32, c->zid + (size_t)term * c->n, c->n, dev_delta);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+// ---- snapshot / restore of the state a sweep changes (hb_ctx_snapshot / hb_ctx_restore): every segment in one launch ----
+#define HB_SNAP_MAXSEG 12
+struct seg_args {
+    char *a[HB_SNAP_MAXSEG];       // destination
+    const char *b[HB_SNAP_MAXSEG]; // source
+    size_t bytes[HB_SNAP_MAXSEG];
+};
+__global__ __launch_bounds__(256) void k_copy_segs(seg_args s)
+{
+    const int k = blockIdx.y;
+    char *dst = s.a[k];
+    const char *src = s.b[k];
+    const size_t nb = s.bytes[k], n16 = nb / 16;
+    // (every buffer is a hipMalloc allocation or a 256-byte aligned offset into one)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+    if (blockIdx.x == 0)
+        for (size_t i = n16 * 16 + threadIdx.x; i < nb; i += blockDim.x) dst[i] = src[i];
+}
+
+int hbk_copy_segs(hb_ctx *c, const std::vector<hb_ctx::snap_seg> &segs, bool restore)
+{
+    if (segs.empty()) return HB_OK;
+    if (segs.size() > HB_SNAP_MAXSEG) return hb_fail(HB_ERR_INVALID, "hbk_copy_segs: too many segments");
+    seg_args s{};
+    for (size_t k = 0; k < segs.size(); k++) {
+        char *live = static_cast<char *>(segs[k].live), *copy = c->snap + segs[k].off;
+        s.a[k] = restore ? live : copy;
+        s.b[k] = restore ? copy : live;
+        s.bytes[k] = segs[k].bytes;
+    }
+    hipLaunchKernelGGL(k_copy_segs, dim3(128, (unsigned)segs.size()), dim3(256), 0, c->stream, s);
+    HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+// sharded sweep: the rank whose pipeline gave up turns the event count it contributes to the exchange into a NaN, which the
+// all-reduce hands to every rank — all of them then restore and replay the sweep together (hb_run::step)
+__global__ void k_abort_poison(const unsigned *flags, double *sums)
+{
+    if (ld_flag(flags + HB_FLAG_ABORT)) sums[HB_ACC_EVENTS] = __longlong_as_double(0x7ff8000000000001ll);
+}
+int hbk_abort_poison(hb_ctx *c, double *sums)
+{
+    hipLaunchKernelGGL(k_abort_poison, dim3(1), dim3(1), 0, c->stream, c->flags, sums);
     HB_HIP(hipGetLastError());
     return HB_OK;
 }

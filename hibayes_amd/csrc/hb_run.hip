@@ -22,6 +22,7 @@
 int hbk_delta_pack(hb_ctx *c, const double *r0, const double *u0, double *buf);
 int hbk_delta_unpack(hb_ctx *c, const double *r0, const double *u0, const double *buf);
 int hbk_reduce_ru(hb_ctx *c);
+int hbk_abort_poison(hb_ctx *c, double *sums);
 int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out);
 extern "C" int hb_comm_world(const hb_comm *c);
 extern "C" int hb_comm_rank(const hb_comm *c);
@@ -88,6 +89,8 @@ struct hb_run {
     long long NnzSnp = 0;
     double mu_sum = 0, vara_sum = 0, vare_sum = 0, hsq_sum = 0, events_sum = 0, miss_sum = 0, redo_sum = 0;
     int sync_blocks = 1;       // runs of mat-vec groups per sweep, an exchange after each (hb_bayes_args.sync_blocks)
+    bool recover_on = true;    // replay a sweep whose pipeline timed out (HB_RECOVER=0: fail the run, as before round 4)
+    int aborts = 0;            // sweeps replayed so far
     bool adaptive_geo = false; // choose (Lv, D) per sweep from the previous sweep's moves (BayesB/C)
     int geo_wide_lv = 2;       // look-ahead groups of the wide geometry (3 with k_fwd beside the chain, else 2)
     int geo_cur = 0;           // 0: (2, 7), 1: (2, 2)
@@ -313,6 +316,7 @@ int hb_run::setup(const hb_bayes_args *args)
         if (a.genotype_bits == 2) return hb_fail(HB_ERR_UNSUPPORTED, "shard_rows runs on the int8 layout");
     }
     sync_blocks = std::max(1, std::min(64, (int)a.sync_blocks));
+    if (const char *e = getenv("HB_RECOVER")) recover_on = atoi(e) != 0;
     m_global = (!rowmode && (world > 1 || a.m_global > 0)) ? a.m_global : m;
     if (!rowmode && world > 1 && ((!a.allreduce && !a.comm) || m_global < m))
         return hb_fail(HB_ERR_INVALID, "hb_bayes_run: sharded run needs a communicator (comm or allreduce) and m_global");
@@ -738,31 +742,62 @@ int hb_run::step()
     // The sweep, in sync_blocks runs of mat-vec groups (1: the whole sweep). After each run the shards sum their residual
     // deltas (n doubles; u moves by the negative) — and, after the last one, the 16 scalar sums — all enqueued on the sweep
     // stream behind the run itself; the iteration's only host synchronisation is the fetch below.
-    for (int b = 0; b < sync_blocks; b++) {
-        if (sharded) {
-            HB_HIP(hipMemcpyAsync(r0, c->r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
-            HB_HIP(hipMemcpyAsync(u0, c->u, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
-        }
-        rc = hb_ctx_sweep_range(c, &in, b, sync_blocks);
+    // A sweep whose pipeline gave up waiting (HB_ERR_ABORTED: every wait is bounded) is replayed from the state
+    // saved here: effects, residual, u and the posterior counters, a few MB copied by one kernel. The draws are counter-based, so the
+    // replay is the same chain. A second failure of the same sweep replays it on the event-ordered per-panel kernels, which wait
+    // for nothing on the device; sharded, the abort reaches every rank through the exchange and all of them replay.
+    const bool recover = recover_on && c->pipeline && !rowmode;
+    int saved_geo[4] = {0, 0, 0, 0};
+    bool fell_back = false;
+    if (recover) {
+        rc = hb_ctx_snapshot(c, model_index, in.store != 0, in.count_pip != 0);
         if (rc) return rc;
-        if (sharded) {
-            const bool last = b == sync_blocks - 1;
-            rc = hbk_delta_pack(c, r0, u0, xbuf);
+    }
+    for (int attempt = 0;; attempt++) {
+        for (int b = 0; b < sync_blocks; b++) {
+            if (sharded) {
+                HB_HIP(hipMemcpyAsync(r0, c->r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+                HB_HIP(hipMemcpyAsync(u0, c->u, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+            }
+            rc = hb_ctx_sweep_range(c, &in, b, sync_blocks);
             if (rc) return rc;
-            // (the sums ride along every time — the message has one shape — but only the last run's are the sweep's)
-            HB_HIP(hipMemcpyAsync(xbuf + (size_t)n, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
-            rc = exchange();
-            if (rc) return rc;
-            rc = hbk_delta_unpack(c, r0, u0, xbuf);
-            if (rc) return rc;
-            if (last) {
-                HB_HIP(hipMemcpyAsync(c->acc, xbuf + (size_t)n, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
-                rc = hbk_reduce_ru(c);
+            if (sharded) {
+                const bool last = b == sync_blocks - 1;
+                rc = hbk_delta_pack(c, r0, u0, xbuf);
                 if (rc) return rc;
+                // (the sums ride along every time — the message has one shape — but only the last run's are the sweep's)
+                HB_HIP(hipMemcpyAsync(xbuf + (size_t)n, c->acc, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
+                rc = hbk_abort_poison(c, xbuf + (size_t)n);
+                if (rc) return rc;
+                rc = exchange();
+                if (rc) return rc;
+                rc = hbk_delta_unpack(c, r0, u0, xbuf);
+                if (rc) return rc;
+                if (last) {
+                    HB_HIP(hipMemcpyAsync(c->acc, xbuf + (size_t)n, sizeof(double) * HB_ACC_N, hipMemcpyDeviceToDevice, c->stream));
+                    rc = hbk_reduce_ru(c);
+                    if (rc) return rc;
+                }
             }
         }
+        rc = hb_ctx_sweep_end(c, &so);
+        if (rc != HB_ERR_ABORTED || !recover || attempt >= 3) break;
+        aborts++;
+        fprintf(stderr, "hibayes_gpu: iteration %d: %s — state restored, replaying the sweep%s\n", iter + 1, hb_last_error(),
+                attempt >= 1 ? " on the per-panel kernels" : "");
+        rc = hb_ctx_restore(c);
+        if (rc) return rc;
+        if (attempt >= 1 && !fell_back) {
+            (void)hb_ctx_get_pipeline(c, &saved_geo[0], &saved_geo[1], &saved_geo[2], &saved_geo[3]);
+            rc = hb_ctx_set_pipeline(c, 0, 0, 1);
+            if (rc) return rc;
+            fell_back = true;
+        }
     }
-    rc = hb_ctx_sweep_end(c, &so);
+    if (fell_back) {
+        const int rc2 = hb_ctx_set_pipeline(c, saved_geo[0], saved_geo[1], saved_geo[2]);
+        if (rc2) return rc2;
+    }
     if (rc) return rc;
     events_sum += so.n_events;
     last_events_pp = so.n_events / ((double)std::max(1, world) * std::max(1, c->npanels));
@@ -987,6 +1022,8 @@ int hb_run::finish(hb_bayes_out *o)
     o->loop_seconds = loop_seconds;
     o->iters_done = iter;
     o->mean_events = iter > 0 ? events_sum / iter : 0;
+    o->sweeps_replayed = aborts;
+    o->reserved_ = 0;
     line("Posterior parameters:");
     line("    Mu %f", Mu);
     line("    Genetic var %f", o->Vg);
@@ -1039,6 +1076,8 @@ int hb_run_state(hb_run *r, hb_run_info *info)
     info->mean_events = r->iter > 0 ? r->events_sum / r->iter : 0.0;
     info->mean_misses = r->iter > 0 ? r->miss_sum / r->iter : 0.0;
     info->mean_redo = r->iter > 0 ? r->redo_sum / r->iter : 0.0;
+    info->sweeps_replayed = r->aborts;
+    info->reserved_ = 0;
     info->loop_seconds = r->loop_seconds;
     info->setup_seconds = r->setup_seconds;
     info->gram_seconds = r->gram_seconds;

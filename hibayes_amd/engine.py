@@ -90,6 +90,10 @@ class Context:
     def set_pipeline(self, pipeline=1, lookahead=2, dotgroup=4):
         check(self.L.hb_ctx_set_pipeline(self.h, pipeline, lookahead, dotgroup))
 
+    def debug_inject_abort(self, panel, times=1):
+        """Debug hook: abort the next `times` pipeline sweeps once the chain has published `panel` panels (hb_run_step replays them)."""
+        check(self.L.hb_ctx_debug_inject_abort(self.h, panel, times))
+
     def build_gram(self):
         s = C.c_double()
         check(self.L.hb_ctx_build_gram(self.h, C.byref(s)))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 4
+#define HB_ABI_VERSION 5
 #define HB_MAX_FOLD 8
 
 typedef enum {
@@ -37,7 +37,11 @@ typedef enum {
     HB_ERR_HIP = 3,         /* a HIP call or kernel failed */
     HB_ERR_UNSUPPORTED = 4, /* argument outside the GPU path (BSLMM, epsilon block, non-integer X) */
     HB_ERR_COMM = 5,        /* the multi-GPU all-reduce callback failed */
-    HB_ERR_INTERRUPT = 6    /* interrupt callback asked to stop */
+    HB_ERR_INTERRUPT = 6,   /* interrupt callback asked to stop */
+    HB_ERR_ABORTED = 7      /* a wait inside the device pipeline timed out and the sweep was abandoned (hb_ctx_sweep_end); the
+                               sampler (hb_bayes_run / hb_run_step) restores the state it saved before the sweep and replays
+                               it — the draws are counter-based, so the replay is the same chain — and only fails with this
+                               status when the replays time out as well */
 } hb_status;
 
 int hb_abi_version(void);
@@ -201,6 +205,8 @@ typedef struct hb_bayes_out {
     double loop_seconds;     /* the MCMC loop only                                        */
     int32_t iters_done;
     double mean_events;      /* mean number of markers whose effect changed per sweep     */
+    int32_t sweeps_replayed; /* (ABI 5) sweeps that timed out on the device and were replayed from the saved state */
+    int32_t reserved_;
 } hb_bayes_out;
 
 /* The whole sampler: replaces Bayes() (reference src/Bayes.cpp:60-1094). */
@@ -221,6 +227,8 @@ typedef struct hb_run_info {
     double mean_misses;      /* mean row-cache misses per sweep so far */
     double mean_redo;        /* mean rolled-back chain rounds per sweep so far */
     double loop_seconds, setup_seconds, gram_seconds;
+    int32_t sweeps_replayed; /* (ABI 5) sweeps whose device pipeline timed out and that were replayed from the saved state (HB_ERR_ABORTED) */
+    int32_t reserved_;
 } hb_run_info;
 int hb_run_create(const hb_bayes_args *args, hb_run **out);
 int hb_run_step(hb_run *r, int32_t nsteps, int32_t *finished);
@@ -463,6 +471,11 @@ typedef struct hb_launch_stats {
     double avg_ms, min_ms, max_ms, sum_ms, span_ms;
 } hb_launch_stats;
 int hb_ctx_matvec_stamps(hb_ctx *c, hb_launch_stats *out);
+/* Debug hook for the replay of an aborted sweep (ABI 5): the next `times` sweeps the persistent pipeline runs on the context are
+ * aborted in mid-flight — the abort flag a timed-out waiter raises is set once the chain has published `panel` panels — so
+ * hb_ctx_sweep_end() returns HB_ERR_ABORTED for them; hb_run_step() restores the saved state and replays (twice on the pipeline,
+ * then on the per-panel kernels, which the hook does not touch). times <= 0 disarms it. */
+int hb_ctx_debug_inject_abort(hb_ctx *c, int32_t panel, int32_t times);
 
 #ifdef __cplusplus
 }

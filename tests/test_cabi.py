@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_version_and_error_channel():
     lib = H.lib()
-    assert lib.hb_abi_version() == 4
+    assert lib.hb_abi_version() == 5
     assert b"gfx950" in lib.hb_version()
     assert lib.hb_device_count() >= 0
     assert lib.hb_exchange_count(50000) == 50016

@@ -159,3 +159,23 @@ def test_map_argument_of_ibrm_is_validated_like_the_reference(demo):
             _map_columns(bad)
     with pytest.raises(ValueError, match="map information must be provided."):
         _map_columns(None)
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it must run two ranks (one process per GPU, torch.distributed rendezvous on
+    127.0.0.1) and print ONE JSON line with n_gpus = 2 — north_star asks for sweeps/s at 1, 2, 4 and 8 GPUs."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--m", "20000", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_counted_by_all_reduce"] == 2 and "2 ranks" in out["config"]["collective"]
+    # and one rank stays one process: no launcher, no rendezvous
+    p1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
+    assert p1.returncode == 0 and json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1

@@ -21,25 +21,31 @@ def run(n, m, model, niter, nburn, seed=20240901):
     while done < niter:
         k = min(500, niter - done); check(c.L.hb_run_step(run, k, ct.byref(fin))); done += k
         check(c.L.hb_run_state(run, ct.byref(info)))
-        print("  %s n=%d m=%d iter %5d: %.2f ms/sweep so far, nnz %d, vara %.3f vare %.3f redo/sweep %.1f" % (
-            model, n, m, info.iter, (time.time() - t0) / done * 1e3, info.nnz, info.vara, info.vare, info.mean_redo), flush=True)
+        print("  %s n=%d m=%d iter %5d: %.2f ms/sweep so far, nnz %d, vara %.3f vare %.3f redo/sweep %.1f, sweeps replayed %d" % (
+            model, n, m, info.iter, (time.time() - t0) / done * 1e3, info.nnz, info.vara, info.vare, info.mean_redo, info.sweeps_replayed), flush=True)
     r, u = c.get_residual()
-    print("  done: h2-ish %.3f, max|r+u-(y-mu)| %.2e" % (info.vara / (info.vara + info.vare), np.max(np.abs(r + u - (y - info.mu)))), flush=True)
+    print("  done: %d sweeps, %d replayed after a device time-out; h2-ish %.3f, max|r+u-(y-mu)| %.2e" % (
+        done, info.sweeps_replayed, info.vara / (info.vara + info.vare), np.max(np.abs(r + u - (y - info.mu)))), flush=True)
     c.L.hb_run_destroy(run); c.close()
+    return info.sweeps_replayed
 
 if len(sys.argv) > 1 and sys.argv[1] == "dense":  # the models in which every marker moves (k_chain_dense, k_fold_dense)
-    nfail = 0
-    cases = (("BayesRR", 50000, 500000, 3000), ("BayesA", 50000, 500000, 1500), ("BayesL", 50000, 500000, 1500),
-             ("BayesRR", 20000, 100000 + 300, 3000))  # (the last: ragged last panel)
-    if len(sys.argv) > 2 and sys.argv[2] == "rr":
-        cases = (("BayesRR", 50000, 500000, 3000),) * 3
+    # soak.py dense [all|rr|a|l] [sweeps]: "all" = BayesRR / A / L at config-3 size + a ragged BayesRR; a run that loses a sweep to a
+    # device time-out replays it (hb_run_step) — the counts of replayed sweeps and of FAILED runs are the result
+    nfail = nrep = ntot = 0
+    which = sys.argv[2] if len(sys.argv) > 2 else "all"
+    k = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
+    cases = {"all": (("BayesRR", 50000, 500000, k), ("BayesA", 50000, 500000, k // 2), ("BayesL", 50000, 500000, k // 2),
+                     ("BayesRR", 20000, 100000 + 300, k)),  # (the last: ragged last panel)
+             "rr": (("BayesRR", 50000, 500000, k),), "a": (("BayesA", 50000, 500000, k),), "l": (("BayesL", 50000, 500000, k),)}[which]
     for model, n, m, it in cases:
         try:
-            run(n, m, model, it, 500)
-        except Exception as e:  # a device-side time-out: say so and go on, the count is the result
+            nrep += run(n, m, model, it, min(500, it // 2))
+            ntot += it
+        except Exception as e:  # a run that could not be completed
             nfail += 1
             print("  FAILED %s n=%d m=%d: %s" % (model, n, m, e), flush=True)
-    print("dense soak: %d of %d runs failed" % (nfail, len(cases)), flush=True)
+    print("dense soak: %d of %d runs failed; %d sweeps completed, %d of them replayed after a device time-out" % (nfail, len(cases), ntot, nrep), flush=True)
     sys.exit(1 if nfail else 0)
 else:
     run(10000, 100000, "BayesCpi", 5000, 2500)
