@@ -6,10 +6,13 @@ The headline model is BayesCpi (the model BASELINE.json's north_star target is s
 BayesR (configs[2]) is measured on the same genotypes and reported under "secondary".
 One step = one iteration of the reference's MCMC loop (src/Bayes.cpp:477-917): intercept draw,
 the full m-marker sweep on the device, the end-of-sweep reductions and the host hyper-parameter
-draws — on synthetic int8 genotypes already resident in HBM (SURVEY.md §8 d).
+draws — on synthetic genotypes already resident in HBM (SURVEY.md §8 d). `value` is measured on the 2-bit resident layout
+(--bits 2) with the default v_dot4 mat-vec; the same invocation also measures and reports the int8-column layout
+of SURVEY §8 a1 (`int8`: the HBM-bound kernel north_star's 40 % target is stated for) and the matrix-core A/B kernel (`mfma_ab`).
 
   python bench.py --gpus 1 --steps K --warmup W            single GPU
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   marker-sharded
+  python bench.py --gpus N ...                             starts N ranks itself (torch.distributed.run, one per GPU)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   marker-sharded, launcher supplied
 
 Weak scaling: every rank holds --m markers (m_global = N * m); `value` counts passes over m markers
 by all ranks per second, i.e. N * (global sweeps/s).  Prints ONE JSON line on rank 0.
@@ -56,7 +59,9 @@ def parse():
                          "(hb_comm_*); torch = torch.distributed callback (host-synchronous; also the fall-back)")
     ap.add_argument("--model", default="BayesCpi", help="BASELINE.json north_star target: BayesCpi at n=50k, m=500k")
     ap.add_argument("--secondary", default="BayesR", help="second model measured on the same genotypes ('' = none)")
-    ap.add_argument("--tertiary", default="BayesRR", help="a model in which every marker moves every sweep (BayesRR / A / L), reported under 'all_move' ('' = none)")
+    ap.add_argument("--tertiary", default="BayesRR,BayesA,BayesL",
+                    help="the models in which every marker moves every sweep (comma-separated), each reported in the 'all_move' list ('' = none)")
+    ap.add_argument("--no-ab", action="store_true", help="skip the two side legs of the headline model (matrix-core A/B kernel, int8 columns)")
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--precise", type=int, default=2,
                     help="panel mat-vec arithmetic: 2 = exact fixed point (7 int8 digit planes of the fp64 residual, int32 dot4 "
@@ -169,33 +174,77 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
             "cpu_model": cpu_model}
 
 
-def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8):
-    """roofline of the dominant kernel. achieved = algorithmic bytes per launch (n x columns per launch: one read of the launch's
-    int8 genotypes, SURVEY.md §8 d) / the average duration of the sweep's full-width mat-vec launches AS THE SWEEP RUNS THEM
-    (device-clock stamps of every block, chain and update rows beside them); `isolated` is the same launch shape replayed without
-    update rows and chain between two HIP events (round 2's figure)."""
-    alg = float(n) * cols                # SURVEY §8 d: ALGORITHMIC bytes of a launch = one byte per genotype it covers (n x m per sweep)
+# measured on this chip (tools/dot4_rate.hip, profiles/r04_dot4_rate.txt): a wave64 VALU instruction of the k_dotq2 loop (v_dot4_i32_i8,
+# v_and, v_lshrrev) issues once per this many cycles per SIMD, at this sustained clock; LDS returns 128 bytes per clock per CU
+VALU_CYCLES_PER_WAVE_INSTR = 4.5
+SUSTAINED_GHZ = 2.25
+N_CU, SIMD_PER_CU, LDS_BYTES_PER_CLK_CU = 256, 4, 128.0
+
+
+def valu_block(n, cols, avg_ms, kernel):
+    """What bounds the 2-bit v_dot4 kernel (it is not HBM): per 16 genotypes of a column one lane issues 28 v_dot4 + 7 mask
+    operations and receives 7 broadcast digit reads + a quarter of a 16-byte column read through LDS."""
+    if kernel != "k_dotq2":
+        return None
+    lane_steps = float(n) * cols / 16.0          # (lane, 16-genotype chunk) pairs per launch
+    wave_steps = lane_steps / 64.0
+    dot4, mask, lds_reads = 28.0 * wave_steps, 7.0 * wave_steps, 7.25 * wave_steps
+    t_valu = (dot4 + mask) * VALU_CYCLES_PER_WAVE_INSTR / (N_CU * SIMD_PER_CU) / (SUSTAINED_GHZ * 1e9)
+    t_lds = lds_reads * 1024.0 / (N_CU * LDS_BYTES_PER_CLK_CU) / (SUSTAINED_GHZ * 1e9)
+    dur = avg_ms * 1e-3
+    return {"wave_instructions_per_launch": {"v_dot4_i32_i8": dot4, "mask": mask, "ds_read_b128": lds_reads},
+            "cycles_per_wave_instruction_per_simd": VALU_CYCLES_PER_WAVE_INSTR, "sustained_clock_ghz": SUSTAINED_GHZ,
+            "valu_issue_floor_us": t_valu * 1e6, "lds_return_floor_us": t_lds * 1e6, "measured_us": dur * 1e6,
+            "frac_of_valu_issue_bound": t_valu / dur, "frac_of_lds_return_bound": t_lds / dur,
+            "what": "floors of one launch if nothing else existed: VALU issue of the dot4 + mask stream over 1024 SIMDs, and the LDS->VGPR "
+                    "return path (1 KiB per ds_read_b128, 128 B/clk/CU) of the broadcast digit reads; the larger one bounds the kernel "
+                    "(profiles/r04_dot4_rate.txt, profiles/r04_pmc_sq_k_dotq2.txt)"}
+
+
+def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8, kind=0):
+    """roofline of the dominant kernel (the panel mat-vec), PHYSICAL: achieved = the bytes of genotypes the resident layout holds for
+    one launch (n x columns x bits / 8) / the average duration of the sweep's full-width mat-vec launches AS THE SWEEP RUNS THEM
+    (device-clock stamps of every block, chain workgroup and update rows beside them); frac = achieved / the 8 TB/s HBM peak.
+    `genotypes_priced_at_one_byte` keeps SURVEY 8d's n x m denominator (one byte per genotype whatever the layout) for comparison
+    with the int8 line; `isolated` is the same launch shape replayed without update rows and chain between two HIP events."""
+    one = float(n) * cols                # SURVEY §8 d's algorithmic bytes at one byte per genotype
+    res = one * bits / 8.0               # bytes the kernel really has to pull from HBM
     avg_ms = insitu["avg_ms"] if insitu else iso_ms
-    ach = alg / (avg_ms * 1e-3) / 1e9
-    r = {"bound": "hbm", "kernel": ("k_dotq2" if bits == 2 else "k_dotq") if args.precise == 2 else "k_dot", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": alg, "avg_launch_ms": avg_ms,
+    ach = res / (avg_ms * 1e-3) / 1e9
+    kernel = ("k_dotq2m" if kind == 2 else "k_dotq2r" if kind == 1 else "k_dotq2") if (bits == 2 and args.precise == 2) else ("k_dotq" if args.precise == 2 else "k_dot")
+    bound = "hbm" if kernel in ("k_dotq", "k_dot", "k_dotq2m") else "valu"
+    r = {"bound": bound, "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": res, "avg_launch_ms": avg_ms,
          "launches_per_sweep": insitu["launches_per_sweep"] if insitu else launches, "columns_per_launch": cols,
+         "resident_bits_per_genotype": bits,
          "measured": "in situ: device-clock stamps of every block of every mat-vec launch over %d sweeps following the timed region"
                      % insitu["sweeps"] if insitu else "isolated replay (HIP events)",
-         "isolated": {"avg_launch_ms": iso_ms, "achieved": alg / (iso_ms * 1e-3) / 1e9, "frac": alg / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                      "what": "the same launches without update rows and chain, graph replay between two HIP events"}}
-    r["resident_bits_per_genotype"] = bits
-    if bits != 8:
-        # both denominators (VERDICT r2 item 4): above, SURVEY §8 d's n x m bytes — genotypes per second priced at one byte each;
-        # here the bytes the resident layout really holds, i.e. what this kernel has to pull from HBM
-        res_b = alg * bits / 8.0
-        r["resident_bytes"] = {"bytes_per_launch": res_b, "achieved": res_b / (avg_ms * 1e-3) / 1e9, "frac": res_b / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                               "what": "HBM roofline of the bytes actually moved: the 2-bit kernel is VALU-issue-bound (v_dot4_i32_i8 issues once per "
-                                       "4 cycles per SIMD, 28 per 16 genotypes: DESIGN.md 2c), not HBM-bound"}
+         "isolated": {"avg_launch_ms": iso_ms, "achieved": res / (iso_ms * 1e-3) / 1e9, "frac": res / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "what": "the same launches without update rows and chain, graph replay between two HIP events"},
+         "genotypes_priced_at_one_byte": {"bytes_per_launch": one, "achieved": one / (avg_ms * 1e-3) / 1e9, "frac": one / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                          "what": "SURVEY 8d's n x m denominator: genotypes per second priced at one byte each, whatever "
+                                                  "the resident layout; equals `frac` for int8 columns, not a bandwidth for 2-bit ones"}}
+    if bound == "valu":
+        r["bound_note"] = ("the 2-bit v_dot4 kernel is bound by LDS return bandwidth and VALU issue (see `valu`), not by HBM: `frac` is the HBM "
+                           "roofline of the bytes it moves and is far below 1 by construction")
+        r["valu"] = valu_block(n, cols, avg_ms, kernel)
     if insitu:
         r["in_situ"] = {k: insitu[k] for k in ("min_ms", "max_ms", "sum_ms", "span_ms", "blocks_per_launch", "full_width_launches",
                                                "ms_per_step_of_the_stamped_sweeps")}
     return r
+
+
+def pmc_traffic(n, cols, kernel):
+    """HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE passes kept under profiles/ (counters cannot be read from
+    inside this process): reported only when a pass with the same kernel, n and launch width exists."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+        for e in table["passes"]:
+            if e["kernel"] == kernel and e["n"] == n and e["columns_per_launch"] == cols:
+                return e["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 PIPELINE = {  # (pipeline, look-ahead groups, panels per mat-vec launch): see DESIGN.md §2
@@ -210,8 +259,9 @@ def prior(model):
     return [0.95, 0.05], None
 
 
-def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, m_global, comm, torch, note, burn=0):
-    """burn set-up sweeps, W warm-up iterations, then exactly K iterations between barriers; returns the result dict pieces."""
+def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, m_global, comm, torch, note, burn=0, g_init=None):
+    """burn set-up sweeps, W warm-up iterations, then exactly K iterations between barriers; returns the result dict pieces.
+    g_init: effects the chain starts from (a leg that continues in the regime an earlier leg reached: no burn-in of its own)."""
     measure.insitu = None
     from hibayes_amd._lib import BayesArgs, RunInfo, check
     n, m = args.n, args.m
@@ -231,6 +281,10 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
     a.seed, a.device, a.precise, a.store_alpha = args.seed, local_rank, args.precise, 0
     a.ctx = ctx.h
     keep = []
+    if g_init is not None:
+        gi = np.ascontiguousarray(g_init, dtype=np.float64)
+        a.g_init = gi.ctypes.data
+        keep.append(gi)
     if comm is not None:
         a.rank, a.world, a.m_global, a.m_offset = rank, world, m_global, m_offset
         if getattr(comm, "rccl", None) is not None:
@@ -310,6 +364,7 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
         note("%s: %d stamped sweeps: k_dotq %.2f us per launch in situ (%d launches, stream span %.3f ms, sweep %.3f ms)"
              % (model, args.stamped, acc["avg_ms"] * 1e3, st["launches_all"], acc["span_ms"], wall / args.stamped * 1e3))
     measure.insitu = insitu
+    measure.replayed = info.sweeps_replayed
     L.hb_run_destroy(run)
     del keep
     ev = (info.mean_events * info.iter - info0.mean_events * info0.iter) / max(1, K)   # over the timed sweeps only
@@ -448,6 +503,7 @@ def main():
     K, W = args.steps, args.warmup
     elapsed, mean_events, nnz, misses = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
                                         m_global, comm, torch, note, burn=args.burnin)
+    replayed_main = getattr(measure, "replayed", 0)
     g_main = ctx.get_effects()[0]
     curve_main = list(getattr(measure, "curve", []))
     curve_main.append({"sweeps": "timed region", "moves_per_sweep": round(mean_events, 1), "sweeps_per_s": round(world * K / elapsed, 2)})
@@ -456,19 +512,8 @@ def main():
     # update rows and without the chain, back to back, HIP events on their stream
     ctx.time_matvec(reps=1)                                   # (untimed: clocks and TLBs as in the steady state of a run)
     iso_ms, launches, cols = ctx.time_matvec(reps=5)
-    alg_bytes = float(n) * cols  # one read of the launch's int8 genotypes (SURVEY.md §8 d: n*m per sweep)
-    avg_ms = insitu_main["avg_ms"] if insitu_main else iso_ms
-    ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-    # HBM bytes per launch: from the separate rocprofv3 --pmc FETCH_SIZE pass kept under profiles/ (counters cannot be read
-    # from inside this process); reported only when this run has the same n, panel and launch width as that pass
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", ("r03_pmc_k_dotq2.json" if bits == 2 else "r02_pmc_k_dotq.json") if args.precise == 2 else "r01_pmc_k_dot.json")))
-        if pm["n"] == n and pm["panel"] * pm["panels_per_launch"] == cols:
-            traffic = pm["traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
-    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, traffic, bits)
+    kernel_main = ("k_dotq2" if bits == 2 else "k_dotq") if args.precise == 2 else "k_dot"
+    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, pmc_traffic(n, cols, kernel_main), bits)
     note("mat-vec timing pass done")
 
     # one unit = one pass over m_ref markers (the metric's m = 500k); all ranks together pass over m_global markers per step
@@ -490,13 +535,71 @@ def main():
                    "collective": comm.rccl_note if comm is not None else "none",
                    "mcmc_burn_in_sweeps_before_warmup": args.burnin,
                    "mean_changed_markers_per_sweep": mean_events, "row_cache_misses_per_sweep": misses, "NumNZSnp_last": nnz,
+                   "sweeps_replayed_after_a_device_time_out": replayed_main,
+                   "matvec_kernel": roof["kernel"],
                    "resident_genotype_bits": bits, "setup_seconds": {"generate": gen_s, "gram": gram_s, "pack_2bit": pack_s}},
-        "achieved_GBps": (K / elapsed) * n * m_global / 1e9, "achieved_frac_of_hbm_peak": (K / elapsed) * n * m_global / 1e9 / (HBM_PEAK_GBPS * world),
+        # PHYSICAL bytes: the genotypes the resident layout holds are read once per sweep by the mat-vec (the Gram rows, digit planes and
+        # residual updates of a stationary BayesCpi sweep add < 2 %); the n x m-priced figure of earlier rounds is `genotype_rate`
+        "achieved_GBps": (K / elapsed) * n * m_global * bits / 8 / 1e9,
+        "achieved_frac_of_hbm_peak": (K / elapsed) * n * m_global * bits / 8 / 1e9 / (HBM_PEAK_GBPS * world),
+        "genotype_rate": {"value": (K / elapsed) * n * m_global / 1e9, "unit": "G genotypes/s",
+                          "what": "n x m genotypes per sweep (SURVEY 8d's unit; = GB/s at one byte per genotype)"},
         "roofline": roof,
         "regime_curve": curve_main,   # sweeps/s is set by the serial chain, i.e. by how many markers change per sweep
     }
-    sides = [(args.secondary, "secondary", args.burnin_secondary, max(10, K // 4), max(5, min(W, 30))),
-             (args.tertiary, "all_move", 20, max(10, K // 8), 5)]
+
+    def leg_block(model, el, Kx, Wx, ev, nnzx, missx, ins, iso, launches_x, cols_x, bits_x, kind, geo_x, burn_x, curve=None):
+        kern = roofline_block(args, n, cols_x, launches_x, ins, iso, None, bits_x, kind)
+        kern["traffic"] = pmc_traffic(n, cols_x, kern["kernel"])
+        b = {"model": model, "value": Kx / el, "unit": "sweeps/s", "steps": Kx, "warmup": Wx, "ms_per_step": el / Kx * 1e3,
+             "resident_genotype_bits": bits_x, "roofline": kern,
+             "achieved_GBps": Kx / el * n * m * bits_x / 8 / 1e9, "achieved_frac_of_hbm_peak": Kx / el * n * m * bits_x / 8 / 1e9 / HBM_PEAK_GBPS,
+             "mcmc_burn_in_sweeps_before_warmup": burn_x,
+             "mean_changed_markers_per_sweep": ev, "row_cache_misses_per_sweep": missx, "NumNZSnp_last": nnzx,
+             "sweeps_replayed_after_a_device_time_out": getattr(measure, "replayed", 0),
+             "pipeline": {"persistent_chain": geo_x[0], "lookahead_groups": geo_x[1], "panels_per_matvec": geo_x[2]}}
+        if curve is not None:
+            b["regime_curve"] = curve
+        return b
+
+    single = world == 1
+    # ---- A/B: the same sweep with the digit-plane product on the matrix cores (k_dotq2m; not the default) ----
+    if single and bits == 2 and args.precise == 2 and not args.no_ab:
+        try:
+            ctx.set_matvec_kernel(2)
+            Wm = max(5, min(W, 30))
+            elm, evm, nnzm, missm = measure(H, L, ctx, y, args.model, K, Wm, args, rank, local_rank, world, m_offset, m_global, comm, torch, note,
+                                            burn=0, g_init=g_main)
+            insm = measure.insitu
+            ctx.time_matvec(reps=1)
+            isom, lm, cm = ctx.time_matvec(reps=3)
+            res["mfma_ab"] = leg_block(args.model, elm, K, Wm, evm, nnzm, missm, insm, isom, lm, cm, 2, 2, geo, 0)
+            res["mfma_ab"]["note"] = ("A/B, not the headline: the seven digit planes as a skinny int8 GEMM on the matrix cores (v_mfma_i32_16x16x64_i8), "
+                                      "same exact integers and the same chain; warm-started from the headline run's effects")
+        except Exception as e:
+            res["mfma_ab"] = {"error": repr(e)}
+        ctx.set_matvec_kernel(0)
+    # ---- the int8-column layout of SURVEY 8 a1 (north_star's own layout, the library's default): HBM-bound k_dotq ----
+    if single and bits == 2 and args.precise == 2 and not args.no_ab:
+        try:
+            geo8 = (1, 2, 7) if geo == (1, 3, 7) else geo
+            ctx.set_layout(8)
+            ctx.set_pipeline(*geo8)
+            W8 = max(5, min(W, 30))
+            el8, ev8, nnz8, miss8 = measure(H, L, ctx, y, args.model, K, W8, args, rank, local_rank, world, m_offset, m_global, comm, torch, note,
+                                            burn=0, g_init=g_main)
+            ins8 = measure.insitu
+            ctx.time_matvec(reps=1)
+            iso8, l8, c8 = ctx.time_matvec(reps=3)
+            res["int8"] = leg_block(args.model, el8, K, W8, ev8, nnz8, miss8, ins8, iso8, l8, c8, 8, 0, geo8, 0)
+            res["int8"]["note"] = ("the same model on int8 columns (SURVEY 8 a1; hb_bayes_args.genotype_bits = 0, the library default), "
+                                   "warm-started from the headline run's effects: the mat-vec is HBM-bound here and `roofline.frac` is the fraction of "
+                                   "the 8 TB/s peak north_star's 40 % target refers to")
+        except Exception as e:
+            res["int8"] = {"error": repr(e)}
+    sides = [(args.secondary, "secondary", args.burnin_secondary, max(10, K // 4), max(5, min(W, 30)))]
+    for tm in [x for x in args.tertiary.split(",") if x]:
+        sides.append((tm, "all_move", 20, max(10, K // 8), 5))
     for side, key, burn_s, K2, W2 in sides:
         if not side or side == args.model or world != 1 or (key == "all_move" and side == args.secondary):
             continue
@@ -519,18 +622,20 @@ def main():
             iso2, launches2, cols2 = ctx.time_matvec(reps=2)
             curve2 = list(getattr(measure, "curve", []))
             curve2.append({"sweeps": "timed region", "moves_per_sweep": round(ev2, 1), "sweeps_per_s": round(K2 / el2, 2)})
-            res[key] = {"model": side, "value": K2 / el2, "unit": "sweeps/s", "steps": K2, "warmup": W2,
-                        "roofline": roofline_block(args, n, cols2, launches2, ins2, iso2, None, bits2), "resident_genotype_bits": bits2,
-                        "ms_per_step": el2 / K2 * 1e3, "achieved_frac_of_hbm_peak": K2 / el2 * n * m / 1e9 / HBM_PEAK_GBPS,
-                        "mcmc_burn_in_sweeps_before_warmup": burn_s,
-                        "mean_changed_markers_per_sweep": ev2, "row_cache_misses_per_sweep": miss2, "NumNZSnp_last": nnz2,
-                        "regime_curve": curve2,
-                        "pipeline": {"persistent_chain": geo2[0], "lookahead_groups": geo2[1], "panels_per_matvec": geo2[2]}}
+            blk = leg_block(side, el2, K2, W2, ev2, nnz2, miss2, ins2, iso2, launches2, cols2, bits2, 0, geo2, burn_s, curve2)
             if key == "all_move":
-                res[key]["note"] = ("every marker moves every sweep: a sweep reads the genotypes twice (mat-vec and residual update), "
-                                    "2 n m bytes; frac prices the n m of SURVEY 8d like the other lines")
+                blk["note"] = ("every marker moves every sweep: a sweep reads the genotypes twice (mat-vec and residual update), 2 n m bytes — "
+                               "`achieved_GBps` prices both passes, `roofline` the mat-vec launches (whose update rows ride in them)")
+                blk["achieved_GBps"] *= 2.0
+                blk["achieved_frac_of_hbm_peak"] *= 2.0
+                res.setdefault(key, []).append(blk)
+            else:
+                res[key] = blk
         except Exception as e:
-            res[key] = {"model": side, "error": repr(e)}
+            if key == "all_move":
+                res.setdefault(key, []).append({"model": side, "error": repr(e)})
+            else:
+                res[key] = {"model": side, "error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
             res["cpu_baseline"] = cpu_baseline(ctx, y, args, Pi, fold, g_main)

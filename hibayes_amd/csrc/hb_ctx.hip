@@ -128,7 +128,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char *e = getenv("HB_DOTQ2_CPL")) c->dotq2_cpl = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("HB_DOTQ2_TILES")) c->dotq2_tiles = std::max(1, atoi(e));
-    if (const char *e = getenv("HB_DOTQ2_KIND")) c->dotq2_kind = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("HB_DOTQ2_KIND")) c->dotq2_kind = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("HB_DOTQ2_NC")) c->dotq2_nc = std::max(4, atoi(e) / 4 * 4);
     if (const char *e = getenv("HB_DOTQ2_RS")) c->dotq2_rs = atoi(e) == 256 ? 256 : 512;
     if (const char *e = getenv("HB_CHAIN")) c->chain_kind = std::strcmp(e, "panel") == 0 ? 0 : std::strcmp(e, "all") == 0 ? 3 : (atoi(e) ? atoi(e) : 1);
@@ -561,12 +561,7 @@ int hb_ctx_build_gram(hb_ctx *c, double *seconds)
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_build_gram");
     if (rc) return rc;
-    if (!c->X) { // the int8 copy was dropped: unpack it for the build, drop it again afterwards
-        rc = hb_ctx_set_layout(c, 8, 1);
-        if (rc == HB_OK) rc = hb_ctx_build_gram(c, seconds);
-        if (rc == HB_OK) rc = hb_ctx_set_layout(c, 2, 0);
-        return rc;
-    }
+    // (a context that holds only the 2-bit layout: hb_build_gram_impl unpacks a window of panels at a time into a scratch buffer)
     c->Lg = c->L; // the band this build stores
     c->graph_model = -1; // the captured sweeps hold the old band's stride (and, after a re-allocation, its pointer)
     const size_t need = (size_t)c->m_pad * (size_t)c->P * (size_t)(c->Lg + 1);
@@ -876,6 +871,18 @@ int hb_ctx_restore(hb_ctx *c)
     if (rc) return rc;
     HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * 4096, c->stream));
     c->aborted = false;
+    return HB_OK;
+}
+
+int hb_ctx_set_matvec_kernel(hb_ctx *c, int32_t kind)
+{
+    if (!c) return hb_fail(HB_ERR_INVALID, "hb_ctx_set_matvec_kernel: null context");
+    if (kind < 0 || kind > 2) return hb_fail(HB_ERR_INVALID, "hb_ctx_set_matvec_kernel: kind must be 0 (lane = column, v_dot4), 1 (individuals across the lanes, v_dot4) or 2 (matrix cores)");
+    if (kind != c->dotq2_kind) {
+        HB_HIP(hipStreamSynchronize(c->stream));
+        c->dotq2_kind = kind;
+        c->graph_model = -1; // the captured sweeps hold the other kernel
+    }
     return HB_OK;
 }
 

@@ -153,6 +153,142 @@ __global__ __launch_bounds__(64) void k_dotq2(dq_view v, upd_view uq)
 static constexpr int q2_lds(int cpl, int rs) { return 2 * ((64 * cpl / (4096 / rs)) * HBQ_SLOT + ((HB_ND + 1024 / rs - 1) / (1024 / rs)) * 1024); }
 
 // ---------------------------------------------------------------------------------------------
+// k_dotq2m: the same product on the MATRIX CORES — an A/B kernel, not the default (hb_ctx_set_matvec_kernel(c, 2) /
+// HB_DOTQ2_KIND=2; BASELINE's north_star asks for coalesced loads and wavefront reductions for this mat-vec, "no MFMA").
+// Once the residual is seven int8 digit planes the panel product is a skinny integer GEMM, [columns x individuals] x
+// [individuals x 7], and k_dotq2 above is bound by what the VALU formulation costs per genotype: 35 vector instructions and
+// 7 KiB of broadcast LDS reads per 16 individuals of 64 columns (LDS return bandwidth 17 us, v_dot4 issue 12 us per
+// 3584-column launch at n = 50k, against 8 us for the launch's 44.8 MB at the HBM rate). Here one v_mfma_i32_16x16x64_i8 does
+// 16 columns x 64 individuals x 16 "planes" (7 real ones) — the same exact int8 x int8 -> int32 products, summed in another
+// order, so the results are the SAME INTEGERS (tests/test_gpu_kernels.py::test_two_bit_layout_*).
+//   * Operands. The instruction sums A[i][kk] B[kk][j] over 64 positions kk = (lane group kb, register r, byte b); which
+//     individual sits at a position is ours to choose as long as A and B agree. Lane (m, kb) of a column tile holds the 16
+//     bytes = four words w_0..w_3 of column m for individuals 64 kb .. 64 kb + 63 of the 256-individual stage; sub-position k
+//     of word w_r (bits [8 b + 2 k, +1]) is individual 64 kb + 16 r + 4 k + b. Masking WITHOUT shifting, w_r & (0x03030303 << 2 k),
+//     leaves the genotypes of sub-position k scaled by 4^k in the four bytes of register r (k = 3: (w_r >> 1) & 0x60606060, scaled
+//     by 32 — 0xC0 would be a negative int8): A_k. Its partner B_k holds the digits of the same individuals: register r =
+//     dword 4 r + k of the lane's 64 digit bytes of plane n — pure register selection. Four MFMAs per column tile and stage,
+//     one accumulator set per scale, combined exactly at the tile's end (sums of multiples of 4^k shift back without loss).
+//   * LDS. Tile and digit planes arrive by LDS-DMA exactly as in k_dotq2 (double-buffered, counted vmcnt); the DMA lane order
+//     is chosen so that every operand read is one conflict-free ds_read_b128: tile piece i (16 columns) is stored [kb][m] —
+//     lane l of the wave reads slot l —, digit piece j (planes 4 j .. 4 j + 3) is stored [16-byte chunk][plane], pieces 1088
+//     bytes apart so that planes 4..6 land 16 banks away from planes 0..3. 8 reads per stage against 116 in k_dotq2.
+//   * Cost per stage of 64 columns x 256 individuals: 16 MFMA + 80 mask operations + 8 LDS reads, against 448 v_dot4 + 112
+//     mask operations + 116 LDS reads: the launch becomes HBM-bound.
+// ---------------------------------------------------------------------------------------------
+#define Q2M_RS 256
+#define Q2M_DSTRIDE 1088
+#define Q2M_XB (4 * HBQ_SLOT)
+#define Q2M_BUF (Q2M_XB + 2 * Q2M_DSTRIDE)
+#define Q2M_PER 6
+static constexpr int q2m_lds() { return 2 * Q2M_BUF; }
+
+__device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
+{
+    const int lane = threadIdx.x;
+    const int cg = b % v.ncg, sp = b / v.ncg;
+    if (b == 0 && lane == 0) *v.gexp_out = *v.vexp_in;
+    const int st0 = sp * v.NS, st1 = min(v.nstages, st0 + v.NS);
+    if (st0 >= st1) return;
+    const int64_t ld2 = v.ld2, ld = v.ld;
+    const uint8_t *xg = v.X2 + (int64_t)cg * 64 * ld2;
+    const int m = lane & 15, kb = lane >> 4;
+    // DMA sources: tile piece i = columns 16 i + m, 16-byte chunk kb of the stage's 64 bytes; digit piece j = plane 4 j + (lane & 3)
+    // (clamped to the last plane), 16-byte chunk lane >> 2 of the stage's 256 digit bytes
+    const unsigned voff = (unsigned)(m * ld2 + kb * 16);
+    unsigned doff[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) doff[j] = (unsigned)(min(4 * j + (lane & 3), HB_ND - 1) * ld + (lane >> 2) * 16);
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    auto uni_p = [](const int8_t *p) {
+        const unsigned long long u = (unsigned long long)(uintptr_t)p;
+        return reinterpret_cast<const int8_t *>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                                            (unsigned)__builtin_amdgcn_readfirstlane((int)u)));
+    };
+    auto issue = [&](int st, int buf) {
+        const int8_t *xs = uni_p(reinterpret_cast<const int8_t *>(xg) + (int64_t)st * (Q2M_RS / 4));
+        const int8_t *ds = uni_p(v.rq + (int64_t)st * Q2M_RS);
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)buf * Q2M_BUF));
+#pragma unroll
+        for (int i = 0; i < 4; i++) hbq_dma16<true>(voff, xs + (int64_t)(16 * i) * ld2, dst + i * HBQ_SLOT);
+#pragma unroll
+        for (int j = 0; j < 2; j++) hbq_dma16<false>(doff[j], ds, dst + Q2M_XB + j * Q2M_DSTRIDE);
+    };
+    hb_v4i C[4][4]; // [column tile][scale 4^k, k = 3: 32]
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) C[ct][k] = hb_v4i{0, 0, 0, 0};
+    // this lane's digit reads: plane n = min(lane & 15, 6) (the output columns 7..15 of the instruction are never looked at)
+    const int n = min(m, HB_ND - 1);
+    const unsigned dlane = (unsigned)((n >> 2) * Q2M_DSTRIDE + (kb * 16 + (n & 3)) * 16); // + 64 r: chunk 4 kb + r
+    issue(st0, 0);
+    int buf = 0;
+    for (int st = st0; st < st1; ++st) {
+        if (st + 1 < st1) {
+            issue(st + 1, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_PER) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char *bp = smem + buf * Q2M_BUF;
+        hb_v4i D[4], X[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) D[r] = *reinterpret_cast<const hb_v4i *>(bp + Q2M_XB + dlane + r * 64);
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) X[ct] = *reinterpret_cast<const hb_v4i *>(bp + ct * HBQ_SLOT + lane * 16);
+        const hb_v4i B0 = hb_v4i{D[0].x, D[1].x, D[2].x, D[3].x}, B1 = hb_v4i{D[0].y, D[1].y, D[2].y, D[3].y},
+                     B2 = hb_v4i{D[0].z, D[1].z, D[2].z, D[3].z}, B3 = hb_v4i{D[0].w, D[1].w, D[2].w, D[3].w};
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) {
+            const hb_v4i w = X[ct];
+            const hb_v4i a0 = w & 0x03030303, a1 = w & 0x0c0c0c0c, a2 = w & 0x30303030;
+            const hb_v4i a3 = hb_v4i{(int)((unsigned)w.x >> 1), (int)((unsigned)w.y >> 1), (int)((unsigned)w.z >> 1), (int)((unsigned)w.w >> 1)} & 0x60606060;
+            C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, B0, C[ct][0], 0, 0, 0);
+            C[ct][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, B1, C[ct][1], 0, 0, 0);
+            C[ct][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, B2, C[ct][2], 0, 0, 0);
+            C[ct][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, B3, C[ct][3], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    // the instruction's result layout: lane l, register r = C[row 4 (l / 16) + r][column l % 16], i.e. genotype column
+    // 4 kb + r of the tile, plane m. The sums of scale 4^k are multiples of it: the shifts are exact.
+    if (m < HB_ND) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) {
+            const hb_v4i tot = C[ct][0] + (C[ct][1] >> 2) + (C[ct][2] >> 4) + (C[ct][3] >> 5);
+            long long *dst = v.accq + (int64_t)m * v.accstride + cg * 64 + ct * 16 + 4 * kb;
+            __hip_atomic_fetch_add(dst + 0, (long long)tot.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(dst + 1, (long long)tot.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(dst + 2, (long long)tot.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(dst + 3, (long long)tot.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_dotq2m(dq_view v, upd_view uq)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long t0 = 0;
+    if (v.stamp || v.ldiag) t0 = wall_clock64();
+    int b = blockIdx.x;
+    if (b < v.nfin) { // (finalize blocks first: see dotq_block)
+        const int col = b * 64 + threadIdx.x;
+        if (col < v.fin_ncols) hbq_finalize(v.fin_acc, v.accstride, col, *v.fin_exp, v.fin_out);
+    } else if (b < v.nfin + v.nupd) {
+        b -= v.nfin;
+        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096));
+    } else {
+        dotq2m_tile(v, smem, b - v.nupd - v.nfin);
+    }
+    if (v.stamp && threadIdx.x == 0) {
+        v.stamp[2 * (size_t)blockIdx.x] = t0;
+        v.stamp[2 * (size_t)blockIdx.x + 1] = wall_clock64();
+    }
+    if (v.ldiag) hb_ldiag_note(v.ldiag, t0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_dotq2r: the same product with the INDIVIDUALS across the lanes and no LDS at all.
 // The lane = column tile above spends its time parked: seven wave-uniform (broadcast) LDS reads per 16 individuals, each a
 // queue behind every other wave's, then 28 v_dot4 (4 cycles each on gfx950, measured: tools/dot4_rate.hip) — 78 % of the wave
@@ -287,8 +423,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // (the caller has checked min / max over X); individuals past n are zero in X already.
 __global__ __launch_bounds__(256) void k_pack2(const int8_t *__restrict__ X, int64_t ld, uint32_t *__restrict__ X2, int64_t ld2w, int ncols)
 {
-    const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
+    // (columns and word blocks share grid.x — nwb word blocks per column: grid.y stops at 65 535 and m does not)
+    const int nwb = (int)((ld2w + 255) / 256);
+    const int j = (int)(blockIdx.x / nwb);
+    const int64_t wi = (int64_t)(blockIdx.x % nwb) * blockDim.x + threadIdx.x;
     if (wi >= ld2w || j >= ncols) return;
     unsigned out = 0;
     if (wi * 16 < ld) {
@@ -303,8 +441,9 @@ __global__ __launch_bounds__(256) void k_pack2(const int8_t *__restrict__ X, int
 // ... and back (hb_ctx_download_genotype / a Gram rebuild once the int8 copy has been dropped)
 __global__ __launch_bounds__(256) void k_unpack2(const uint32_t *__restrict__ X2, int64_t ld2w, int8_t *__restrict__ X, int64_t ld, int ncols)
 {
-    const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
+    const int nwb = (int)((ld / 16 + 255) / 256);
+    const int j = (int)(blockIdx.x / nwb);
+    const int64_t wi = (int64_t)(blockIdx.x % nwb) * blockDim.x + threadIdx.x;
     if (wi * 16 >= ld || j >= ncols) return;
     const unsigned w = X2[(int64_t)j * ld2w + wi];
     hb_u4 q;

@@ -16,10 +16,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // (l = 0: the panel's own Gram; l >= 1: the panels the look-ahead pipeline has not yet folded into
 // the residual when panel p's mat-vec runs).
 __global__ __launch_bounds__(64) void k_gram(const int8_t *__restrict__ X, int64_t ld, int P, int L,
-                                             int32_t *__restrict__ gram)
+                                             int32_t *__restrict__ gram, int p_lo)
 {
     const int nb = P >> 6;                   // 64-blocks per panel side
-    const int pl = blockIdx.x / (nb * nb);
+    const int pl = blockIdx.x / (nb * nb) + p_lo * (L + 1); // (panels [p_lo, ...) of this launch: X may be a window, see hb_build_gram_impl)
     const int p = pl / (L + 1), l = pl % (L + 1);
     if (p - l < 0) return;
     const int rem = blockIdx.x % (nb * nb);
@@ -65,11 +65,11 @@ __global__ __launch_bounds__(64) void k_gram(const int8_t *__restrict__ X, int64
 #define HG_T 256
 #define HG_KS 64
 #define HG_CS 80 /* bytes per staged column: 64 + 16 */
-__global__ __launch_bounds__(1024) void k_gram_tiled(const int8_t *__restrict__ X, int64_t ld, int P, int L, int32_t *__restrict__ gram)
+__global__ __launch_bounds__(1024) void k_gram_tiled(const int8_t *__restrict__ X, int64_t ld, int P, int L, int32_t *__restrict__ gram, int p_lo)
 {
     __shared__ __attribute__((aligned(16))) char sa[HG_T * HG_CS], sb[HG_T * HG_CS];
     const int nt = P / HG_T;
-    const int pl = blockIdx.x / (nt * nt);
+    const int pl = blockIdx.x / (nt * nt) + p_lo * (L + 1);
     const int p = pl / (L + 1), l = pl % (L + 1);
     if (p - l < 0) return;
     const int rem = blockIdx.x % (nt * nt);
@@ -126,18 +126,44 @@ __global__ __launch_bounds__(1024) void k_gram_tiled(const int8_t *__restrict__ 
             }
 }
 
-int hb_build_gram_impl(hb_ctx *c)
+int hbk_unpack2(hb_ctx *c, int col0, int ncols, int8_t *dst);
+
+// panels [pa, pb) of the band; Xv = where column 0 WOULD be (a window of the matrix may be all that exists: only the columns of
+// panels pa - Lg .. pb - 1 are read)
+static int gram_launch(hb_ctx *c, const int8_t *Xv, int pa, int pb)
 {
     if (c->P >= HG_T && !getenv("HB_GRAM_UNTILED")) {
         const int nt = c->P / HG_T;
-        hipLaunchKernelGGL(k_gram_tiled, dim3((unsigned)(c->npanels * (c->Lg + 1) * nt * nt)), dim3(1024), 0, c->stream, c->X, c->ld,
-                           c->P, c->Lg, c->gram);
-        HB_HIP(hipGetLastError());
-        return HB_OK;
+        hipLaunchKernelGGL(k_gram_tiled, dim3((unsigned)((pb - pa) * (c->Lg + 1) * nt * nt)), dim3(1024), 0, c->stream, Xv, c->ld,
+                           c->P, c->Lg, c->gram, pa);
+    } else {
+        const int nb = c->P / 64;
+        hipLaunchKernelGGL(k_gram, dim3((unsigned)((pb - pa) * (c->Lg + 1) * nb * nb)), dim3(64), 0, c->stream, Xv, c->ld, c->P,
+                           c->Lg, c->gram, pa);
     }
-    const int nb = c->P / 64;
-    hipLaunchKernelGGL(k_gram, dim3((unsigned)(c->npanels * (c->Lg + 1) * nb * nb)), dim3(64), 0, c->stream, c->X, c->ld, c->P,
-                       c->Lg, c->gram);
     HB_HIP(hipGetLastError());
     return HB_OK;
+}
+
+int hb_build_gram_impl(hb_ctx *c)
+{
+    if (c->X) return gram_launch(c, c->X, 0, c->npanels);
+    // Only the 2-bit resident layout exists (the int8 copy was dropped, hb_ctx_set_layout(c, 2, 0)): the columns are unpacked a
+    // window at a time into a scratch buffer — the panels of one chunk plus the Lg panels before them that their band blocks reach
+    // back to —, never the whole matrix (25 GB at n = 50k, m = 500k: the capacity regime the 2-bit layout exists for).
+    if (!c->X2) return hb_fail(HB_ERR_INVALID, "hb_ctx_build_gram: no genotypes on the device");
+    const size_t colbytes = (size_t)c->ld * c->P;
+    int chunk = (int)std::max<size_t>(1, ((size_t)1 << 31) / colbytes); // ~2 GB of panels per window
+    chunk = std::min(chunk, c->npanels);
+    int8_t *win = nullptr;
+    HB_HIP(hipMalloc(reinterpret_cast<void **>(&win), colbytes * (size_t)(chunk + c->Lg)));
+    int rc = HB_OK;
+    for (int pa = 0; pa < c->npanels && rc == HB_OK; pa += chunk) {
+        const int pb = std::min(c->npanels, pa + chunk), first = std::max(0, pa - c->Lg);
+        rc = hbk_unpack2(c, first * c->P, (pb - first) * c->P, win);
+        if (rc == HB_OK) rc = gram_launch(c, win - (int64_t)first * (int64_t)colbytes, pa, pb);
+        if (rc == HB_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = hb_fail(HB_ERR_HIP, "hb_ctx_build_gram: window build failed");
+    }
+    (void)hipFree(win);
+    return rc;
 }

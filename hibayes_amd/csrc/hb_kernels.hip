@@ -2381,14 +2381,15 @@ __global__ __launch_bounds__(1024) void k_reduce_ru(const double *__restrict__ r
 // BayesL: vargL_j <- 1 / InvGauss(sqrt(vare) lambda / |g_j|, lambda^2), src/Bayes.cpp:729-730
 __global__ __launch_bounds__(256) void k_bayesl_post(const hb_sweep_in *__restrict__ pin, int m, int64_t m_offset,
                                                      uint64_t seed, const double *__restrict__ vx,
-                                                     const double *__restrict__ g, double *__restrict__ vargL)
+                                                     const double *__restrict__ g, double *__restrict__ vargL, int strict)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m || vx[j] == 0.0) return;
     const uint64_t sub = hb_sub(HB_PURPOSE_MARKER, (uint64_t)pin->iter);
     hb_stream st(seed, sub, (uint64_t)(m_offset + j) * HB_BLK_PER_MARKER + 2);
     const double vargi = 1.0 / st.invgauss(sqrt(pin->vare) * pin->lambda / fabs(g[j]), pin->lambda2);
-    if (vargi >= 0.0) vargL[j] = vargi;
+    // (src/Bayes.cpp:730 keeps vargi >= 0, src/SBayesD.cpp:377 only vargi > 0: `strict` is the summary-level rule)
+    if (strict ? vargi > 0.0 : vargi >= 0.0) vargL[j] = vargi;
 }
 
 __global__ __launch_bounds__(1024) void k_sum_vec(const double *__restrict__ x, int n, double *__restrict__ out)
@@ -2821,8 +2822,9 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
             return;
         }
     }
-    int cpl = (ncols % 128 == 0) ? c->dotq2_cpl : 1;
-    const int RS = c->dotq2_rs;
+    const bool mfma = c->dotq2_kind == 2; // (A/B: the digit-plane product on the matrix cores, k_dotq2m; 256-individual stages, 64 columns per wave)
+    int cpl = (ncols % 128 == 0 && !mfma) ? c->dotq2_cpl : 1;
+    const int RS = mfma ? Q2M_RS : c->dotq2_rs;
     const int nst = (int)((c->ld + RS - 1) / RS);
     const int ncg = ncols / (64 * cpl);
     // (a tile is at least four stages: its first stage's load latency and its closing atomics are paid per tile)
@@ -2859,7 +2861,8 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
         c->lstamp_cols[gidx] = ncols;
     }
     // (the update rows stage their lists in the tile buffers: 6152 bytes, below the smallest shape's 12416)
-    if (cpl == 2 && RS == 512) hipLaunchKernelGGL((k_dotq2<2, 512>), dim3(nblk), dim3(64), q2_lds(2, 512), st, v, uq);
+    if (mfma) hipLaunchKernelGGL(k_dotq2m, dim3(nblk), dim3(64), q2m_lds(), st, v, uq);
+    else if (cpl == 2 && RS == 512) hipLaunchKernelGGL((k_dotq2<2, 512>), dim3(nblk), dim3(64), q2_lds(2, 512), st, v, uq);
     else if (cpl == 2) hipLaunchKernelGGL((k_dotq2<2, 256>), dim3(nblk), dim3(64), q2_lds(2, 256), st, v, uq);
     else if (RS == 512) hipLaunchKernelGGL((k_dotq2<1, 512>), dim3(nblk), dim3(64), q2_lds(1, 512), st, v, uq);
     else hipLaunchKernelGGL((k_dotq2<1, 256>), dim3(nblk), dim3(64), q2_lds(1, 256), st, v, uq);
@@ -3102,7 +3105,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
         }
         if (model == 5) {
             hipLaunchKernelGGL(k_bayesl_post, dim3((c->m + 255) / 256), dim3(256), 0, sA, c->d_in, c->m,
-                               c->m_offset, c->seed, c->vx, c->g, c->vargL);
+                               c->m_offset, c->seed, c->vx, c->g, c->vargL, 0);
             hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(1024), 0, sA, c->vargL, c->m, c->acc + HB_ACC_SUMVARGL);
         }
         hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(1024), 0, sA, c->r, c->u, c->n, c->acc);
@@ -3359,7 +3362,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     }
     if (model == 5 && last) {
         hipLaunchKernelGGL(k_bayesl_post, dim3((c->m + 255) / 256), dim3(256), 0, sA, c->d_in, c->m, c->m_offset, c->seed,
-                           c->vx, c->g, c->vargL);
+                           c->vx, c->g, c->vargL, 0);
         hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(1024), 0, sA, c->vargL, c->m, c->acc + HB_ACC_SUMVARGL);
     }
     if (last) hipLaunchKernelGGL(k_reduce_ru, dim3(1), dim3(1024), 0, sA, c->r, c->u, c->n, c->acc);
@@ -3646,7 +3649,7 @@ int hbk_xalpha(hb_ctx *c, const double *dev_alpha, double *dev_out)
 int hbk_pack2(hb_ctx *c)
 {
     const int64_t ld2w = c->ld2 / 4;
-    hipLaunchKernelGGL(k_pack2, dim3((unsigned)((ld2w + 255) / 256), (unsigned)c->m_pad), dim3(256), 0, c->stream, c->X, c->ld, c->X2, ld2w, c->m_pad);
+    hipLaunchKernelGGL(k_pack2, dim3((unsigned)(((ld2w + 255) / 256) * c->m_pad)), dim3(256), 0, c->stream, c->X, c->ld, c->X2, ld2w, c->m_pad);
     HB_HIP(hipGetLastError());
     return HB_OK;
 }
@@ -3654,7 +3657,7 @@ int hbk_pack2(hb_ctx *c)
 int hbk_unpack2(hb_ctx *c, int col0, int ncols, int8_t *dst)
 {
     const int64_t ld2w = c->ld2 / 4;
-    hipLaunchKernelGGL(k_unpack2, dim3((unsigned)((c->ld / 16 + 255) / 256), (unsigned)ncols), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k_unpack2, dim3((unsigned)(((c->ld / 16 + 255) / 256) * (int64_t)ncols)), dim3(256), 0, c->stream,
                        c->X2 + (int64_t)col0 * ld2w, ld2w, dst, c->ld, ncols);
     HB_HIP(hipGetLastError());
     return HB_OK;

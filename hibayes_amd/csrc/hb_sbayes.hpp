@@ -297,7 +297,7 @@ int hbk_sb_enqueue_sweep(hb_sb_dev *d, int model, int n_fold)
         hipLaunchKernelGGL(k_sb_update, dim3(upd_blocks), dim3(64), 0, d->stream, v);
     }
     if (model == 5) // vargL_i <- 1 / InvGauss(sqrt(vare) lambda / |g_i|, lambda^2), :377-378 (the marker's own stream: order-free)
-        hipLaunchKernelGGL(k_bayesl_post, dim3((d->m + 255) / 256), dim3(256), 0, d->stream, d->d_in, d->m, (int64_t)0, d->seed, d->vx, d->g, d->vargL);
+        hipLaunchKernelGGL(k_bayesl_post, dim3((d->m + 255) / 256), dim3(256), 0, d->stream, d->d_in, d->m, (int64_t)0, d->seed, d->vx, d->g, d->vargL, 1);
     hipLaunchKernelGGL(k_sb_reduce, dim3(1), dim3(1024), 0, d->stream, v, d->vargL, model == 5 ? 1 : 0);
     HB_HIP(hipGetLastError());
     return HB_OK;

@@ -90,6 +90,10 @@ class Context:
     def set_pipeline(self, pipeline=1, lookahead=2, dotgroup=4):
         check(self.L.hb_ctx_set_pipeline(self.h, pipeline, lookahead, dotgroup))
 
+    def set_matvec_kernel(self, kind):
+        """2-bit resident genotypes: 0 = k_dotq2 (v_dot4, default), 1 = k_dotq2r, 2 = k_dotq2m (matrix cores; an A/B). Same integers."""
+        check(self.L.hb_ctx_set_matvec_kernel(self.h, kind))
+
     def debug_inject_abort(self, panel, times=1):
         """Debug hook: abort the next `times` pipeline sweeps once the chain has published `panel` panels (hb_run_step replays them)."""
         check(self.L.hb_ctx_debug_inject_abort(self.h, panel, times))

@@ -68,12 +68,45 @@ def SBayesD(sumstat, ldm, model, Pi, niter=50000, nburn=20000, thin=5, fold=None
     return res
 
 
-def sbrm(sumstat, ldm, method="BayesB", Pi=None, fold=None, niter=None, nburn=None, thin=5, windindx=None, vg=None, dfvg=None,
-         s2vg=None, ve=None, dfve=None, s2ve=None, printfreq=100, seed=666666, threads=4, verbose=True, **kw):
-    """The dense-LD slice of sbrm() (R/sbayes.r:101-239): defaults (:186-203), the column selection sumstat[, c(4, 5, 6, 8)] of an
-    8-column COJO table (:207), then SBayesD(). Sparse LD matrices (SBayesS) and method = "CG" are outside the GPU path."""
+def sbrm(sumstat, ldm, method="BayesB", map=None, Pi=None, fold=None, niter=None, nburn=None, thin=5, windsize=None, windnum=None,
+         windindx=None, vg=None, dfvg=None, s2vg=None, ve=None, dfve=None, s2ve=None, printfreq=100, seed=666666, threads=4, verbose=True, **kw):
+    """The dense-LD slice of sbrm() (R/sbayes.r:101-239): the ldm type check (:126-132), GWAS windows cut from `map` by windsize /
+    windnum (:135-187; res["gwas"] then carries WIND / CHR / NUM / START / END / WPPA like the reference's data frame, :231-234),
+    defaults (:189-203), the column selection sumstat[, c(4, 5, 6, 8)] of the 8-column COJO table (:207), then SBayesD().
+    Sparse LD matrices (dgCMatrix -> SBayesS) and method = "CG" are outside the GPU path and refused."""
+    try:
+        import scipy.sparse as sp
+        if sp.issparse(ldm):
+            raise NotImplementedError("a sparse ldm (dgCMatrix: SBayesS, src/SBayesS.cpp) is outside the GPU path; pass the dense LD matrix")
+    except ImportError:
+        pass
+    if not (isinstance(ldm, np.ndarray) or hasattr(ldm, "__array__")):
+        raise ValueError("Unrecognized type of ldm.")
     if method == "CG":
         raise NotImplementedError("method = 'CG' (conjgt_den / conjgt_spa) is outside the GPU path")
+    windinfo = None
+    if windsize is not None or windnum is not None:
+        if method in ("BayesA", "BayesRR", "BayesL"):
+            raise ValueError("can not implement GWAS analysis for the method: " + method)
+        if map is None:
+            raise ValueError("map information must be provided.")
+        from .bayes import _map_columns
+        from .windows import cutwind_by_bp, cutwind_by_num
+        chrom, bp = _map_columns(map)          # R/sbayes.r:140-172, the same checks as ibrm()
+        if windnum is not None:
+            if len(chrom) < windnum:
+                raise ValueError("Number of markers specified in a window is larger than the total number of markers.")
+            windindx = cutwind_by_num(chrom, bp, windnum)
+        else:
+            if bp.max() < windsize:
+                raise ValueError("Maximum of physical position is smaller than wind size.")
+            windindx = cutwind_by_bp(chrom, bp, windsize)
+        nwin = int(windindx.max())
+        windinfo = {"WIND": ["wind%d" % (w + 1) for w in range(nwin)],
+                    "CHR": [chrom[np.flatnonzero(windindx == w + 1)[0]] for w in range(nwin)],
+                    "NUM": [int((windindx == w + 1).sum()) for w in range(nwin)],
+                    "START": [float(bp[windindx == w + 1].min()) for w in range(nwin)],
+                    "END": [float(bp[windindx == w + 1].max()) for w in range(nwin)]}
     if niter is None:
         niter = 50000 if method == "BayesR" else 20000
     if nburn is None:
@@ -90,10 +123,12 @@ def sbrm(sumstat, ldm, method="BayesB", Pi=None, fold=None, niter=None, nburn=No
         else:
             Pi = [0.95, 0.05]
     ss = np.asarray(sumstat, dtype=np.float64)
-    if ss.shape[1] == 8:
+    if ss.ndim == 2 and ss.shape[1] >= 8:      # the COJO table (:207); a 4-column matrix is taken as MAF, BETA, SE, NMISS already
         ss = ss[:, [3, 4, 5, 7]]
     res = SBayesD(ss, ldm, method, Pi, niter=niter, nburn=nburn, thin=thin, fold=fold, windindx=windindx, vg=vg, dfvg=dfvg, s2vg=s2vg,
                   ve=ve, dfve=dfve, s2ve=s2ve, outfreq=printfreq, threads=threads, verbose=verbose, seed=seed, **kw)
+    if windinfo is not None:
+        res["gwas"] = dict(windinfo, WPPA=res["gwas"])
     res["call"] = "b ~ nD^{-1}V alpha + e"
     res["model"] = "Summary level Bayesian model fit by [%s]" % method
     return res

@@ -130,6 +130,29 @@ def test_two_bit_resident_layout_is_the_same_chain(big, model, Pi, fold, geo, pa
     _compare(rd, refd)
 
 
+@pytest.mark.parametrize("model,Pi,fold,geo", [CASES[0], CASES[2]])
+def test_matrix_core_matvec_is_the_same_chain_bit_for_bit(big, model, Pi, fold, geo):
+    """hb_ctx_set_matvec_kernel(c, 2): the 2-bit mat-vec with the seven digit planes as a skinny int8 GEMM on the matrix cores
+    (k_dotq2m, an A/B beside the default v_dot4 kernel). Integer sums in another order: the same integers, hence the same chain
+    bit for bit, and the oracle's draw for draw."""
+    X, y = big["X"], big["y"]
+    kw = dict(fold=fold, niter=6, nburn=0, thin=1, seed=8642)
+    ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, **kw)
+    out = []
+    for kind in (0, 2):
+        with H.Context(X.shape[0], X.shape[1], panel=512, seed=8642) as c:
+            c.upload(X)
+            c.set_pipeline(*geo)
+            c.build_gram()
+            c.set_layout(2, keep_int8=False)
+            c.set_matvec_kernel(kind)
+            out.append(H.Bayes(y, None, model, Pi, verbose=False, ctx=c, **kw))
+    _compare(out[1], ref)
+    for k in ("alpha", "pip", "g", "pi"):
+        assert np.array_equal(out[0][k], out[1][k]), k
+    assert np.array_equal(out[0]["MCMCsamples"]["alpha"], out[1]["MCMCsamples"]["alpha"])
+
+
 @pytest.mark.parametrize("panel,geo", [(64, (1, 2, 7)), (512, (1, 2, 7)), (128, (1, 2, 1)), (256, (1, 1, 8)), (64, (0, 3, 1))])
 def test_every_band_gram_block_exact(panel, geo):
     rng = np.random.default_rng(panel + geo[2])

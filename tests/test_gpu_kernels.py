@@ -272,7 +272,7 @@ def test_two_bit_layout_pack_unpack_dot_and_products():
     the fixed-point mat-vec and X * alpha must all give what the int8 layout gives — the dot products bit for bit: they are
     exact integers either way (checked against a Python big-integer dot product)."""
     rng = np.random.default_rng(22)
-    for n, m, panel in ((777, 300, 64), (1300, 1100, 128)):   # ld = 1024 (two stages of 512) and 1536 (an odd multiple of 256)
+    for n, m, panel in ((777, 300, 64), (1300, 1100, 128), (5000, 1024, 512)):   # ld = 1024 (two stages of 512), 1536 (an odd multiple of 256), 5120
         X = rand_geno(rng, n, m)
         r = rng.normal(0, 3.0, n)
         r[rng.integers(0, n, 5)] *= 1e6
@@ -288,6 +288,9 @@ def test_two_bit_layout_pack_unpack_dot_and_products():
             assert c.layout() == (2, False)
             d2 = c.dot()
             assert np.array_equal(d2, d8)
+            for kind in (1, 2, 0):                            # k_dotq2r (individuals across the lanes), k_dotq2m (the digit planes
+                c.set_matvec_kernel(kind)                     # as an int8 GEMM on the matrix cores: an A/B), back to k_dotq2:
+                assert np.array_equal(c.dot(), d8), kind      # integer sums in another order — the same integers
             assert np.array_equal(c.download(), X)            # unpacked on the device
             E = 53 - int(np.floor(np.log2(np.abs(r).max())))
             q = np.rint(np.ldexp(r, E))

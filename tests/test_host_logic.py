@@ -179,3 +179,26 @@ def test_bench_gpus_n_starts_n_ranks_by_itself():
     # and one rank stays one process: no launcher, no rendezvous
     p1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
     assert p1.returncode == 0 and json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_sbrm_host_checks_before_any_device_work():
+    """sbrm()'s own argument handling (reference R/sbayes.r:126-187): refused inputs say why without touching a device."""
+    import scipy.sparse as sp
+    from hibayes_amd.sbayes import sbrm
+    ss = np.zeros((5, 8))
+    ld = np.eye(5)
+    with pytest.raises(NotImplementedError, match="sparse ldm"):
+        sbrm(ss, sp.csc_matrix(ld), "BayesCpi")
+    with pytest.raises(NotImplementedError, match="CG"):
+        sbrm(ss, ld, "CG")
+    with pytest.raises(ValueError, match="can not implement GWAS analysis for the method: BayesRR"):
+        sbrm(ss, ld, "BayesRR", windsize=1e6)
+    with pytest.raises(ValueError, match="map information must be provided"):
+        sbrm(ss, ld, "BayesCpi", windnum=2)
+    mp = np.array([["s%d" % i, "1", str(100 * (i + 1))] for i in range(5)], dtype=object)
+    with pytest.raises(ValueError, match="larger than the total number of markers"):
+        sbrm(ss, ld, "BayesCpi", map=mp, windnum=9)
+    with pytest.raises(ValueError, match="smaller than wind size"):
+        sbrm(ss, ld, "BayesCpi", map=mp, windsize=1e6)
+    with pytest.raises(ValueError, match="bad setting for collecting frequency"):
+        sbrm(ss, ld, "BayesCpi", niter=10, nburn=8, thin=5)
