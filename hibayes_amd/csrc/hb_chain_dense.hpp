@@ -128,8 +128,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const unsigned long long t0 = wall_clock64();
                 unsigned looks = 0;
                 for (;;) {
-                    dj = ld_sc1(&v.dsum[j]);
-                    fc = ld_sc1(&fcp[j]);
+                    if (hb_fresh_look(looks)) { // (a lane still waiting reads at the memory side: ld_fresh, hb_kernels.hip)
+                        if (HBD_SENT(dj)) dj = ld_fresh(&v.dsum[j]);
+                        if (use_fc && HBD_SENT(fc)) fc = ld_fresh(&fcp[j]);
+                    } else {
+                        dj = ld_sc1(&v.dsum[j]);
+                        fc = ld_sc1(&fcp[j]);
+                    }
 #if HB_STAMPS
                     if (v.dbg && t == 0 && !HBD_SENT(dj) && c12 == 0) c12 = clock64();
 #endif
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         break;
                     }
                     hb_poll_pause(looks, 1);
+                    looks++;
                 }
             }
             rhs = dj - (use_fc ? fc : 0.0);
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const unsigned long long t0_ = wall_clock64();                                                                \
                     unsigned looks_ = 0;                                                                                          \
                     for (;;) {                                                                                                    \
-                        fc2 = ld_sc1(&fcorr2[j]);                                                                                 \
+                        fc2 = (hb_fresh_look(looks_) && HBD_SENT(fc2)) ? ld_fresh(&fcorr2[j]) : ld_sc1(&fcorr2[j]);               \
                         if (!__any(HBD_SENT(fc2))) break;                                                                         \
                         const bool own_ = wall_clock64() - t0_ > HB_TIMEOUT_TICKS;                                                \
                         if (ld_flag(pv.flags + HB_FLAG_ABORT) || own_) {                                                          \
@@ -198,6 +204,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             break;                                                                                                \
                         }                                                                                                         \
                         hb_poll_pause(looks_, 1);                                                                                 \
+                        looks_++;                                                                                                 \
                     }                                                                                                             \
                 }                                                                                                                 \
                 rhs -= fc2;                                                                                                       \
@@ -253,13 +260,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }                                                                                                                     \
             if (act) wacc += gn_f * gn_f;                                                                                         \
             if ((s) == 7) {                                                                                                       \
-                if (lane == 0) st_sc1(&v.ev_count[p], nev_);                                                                      \
+                if (lane == 0) st_sc1(&v.ev_count[(size_t)p * HB_EVS], nev_);                                                                      \
                 evacc += nev_;                                                                                                    \
                 absd_grp += ab_;                                                                                                  \
                 if (group_end) {                                                                                                  \
                     if (v.mb) {                                                                                                   \
                         mbr = fma(v.xabs, absd_grp, mbr);                                                                         \
-                        if (lane == 0) st_sc1(&v.mb[1 + gcount], mbr);                                                            \
+                        if (lane == 0) st_sc1(&v.mb[(size_t)(1 + gcount) * HB_MBS], mbr);                                                            \
                     }                                                                                                             \
                     absd_grp = 0.0;                                                                                               \
                 }                                                                                                                 \
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view p
                 const unsigned long long t0 = wall_clock64();
                 unsigned looks = 0;
                 for (;;) {
-                    d = ld_sc1(dp);
+                    d = (hb_fresh_look(looks) && HBD_SENT(d)) ? ld_fresh(dp) : ld_sc1(dp);
                     if (!__any(HBD_SENT(d))) break;
                     const bool own = wall_clock64() - t0 > HB_TIMEOUT_TICKS;
                     if (ld_flag(pv.flags + HB_FLAG_ABORT) || own) {
@@ -373,6 +380,7 @@ __global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view p
                         break;
                     }
                     hb_poll_pause(looks, 1);
+                    looks++;
                 }
                 if (st + 1 < nsteps) dn = ld_sc1(dptr(st + 1)); // (looked at before this step was there: likely stale)
             }

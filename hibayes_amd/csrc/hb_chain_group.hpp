@@ -108,13 +108,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             HBG_STAMP_VAL(11, bad ? 1 : 0);
             if (__any(bad)) { // the mat-vec (or k_fwd) has not delivered (all of) this group yet: look again
                 const unsigned long long t0 = wall_clock64();
-                for (;;) {
+                for (unsigned looks = 0;; looks++) {
                     bad = false;
+                    if (hb_fresh_look(looks)) { // (uniform; once in HB_FRESH_EVERY looks what is still missing is read at the memory side: ld_fresh, hb_kernels.hip)
+#pragma unroll
+                        for (int i = 0; i < HBG_DM; i++) {
+                            const size_t j = (size_t)(gp0 + min(i, Dg - 1)) * P + t;
+                            if (__double_as_longlong(dj[i]) == -1ll) dj[i] = ld_fresh(&v.dsum[j]);
+                            if (far_in && __double_as_longlong(fc[i]) == -1ll) fc[i] = ld_fresh(&fcp[j]);
+                        }
+                    } else {
 #pragma unroll
                     for (int i = 0; i < HBG_DM; i++) {
                         const size_t j = (size_t)(gp0 + min(i, Dg - 1)) * P + t;
                         dj[i] = ld_sc1(&v.dsum[j]);
                         fc[i] = ld_sc1(&fcp[j]);
+                    }
                     }
 #pragma unroll
                     for (int i = 0; i < HBG_DM; i++)
@@ -436,12 +445,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (wave == S - 1) {
             if (lane < Dg) {
                 const int c = misc[16 + lane];
-                if (c) st_sc1(&v.ev_count[gp0 + lane], c);
+                if (c) st_sc1(&v.ev_count[(size_t)(gp0 + lane) * HB_EVS], c);
                 misc[16 + lane] = 0;
             }
             if (v.mb) {
                 mbr = fma(v.xabs, absd_grp, mbr);
-                if (lane == 0) st_sc1(&v.mb[1 + gcount], mbr);
+                if (lane == 0) st_sc1(&v.mb[(size_t)(1 + gcount) * HB_MBS], mbr);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(gp0 + Dg));
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
         if (!s_ok) return;
         if (t <= HBF_D) { // exclusive scan of the panels' move counts
             int a = 0;
-            for (int i = 0; i < t && i < Dg; i++) a += ld_sc1(&v.ev_count[gp0 + i]);
+            for (int i = 0; i < t && i < Dg; i++) a += ld_sc1(&v.ev_count[(size_t)(gp0 + i) * HB_EVS]);
             s_cnt[t] = a;
         }
         __syncthreads();

@@ -196,7 +196,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->rq, (size_t)c->ld * 8 * HB_ND));
     TRY(dev_alloc(&c->vexp, 8));
     TRY(dev_alloc(&c->gexp, (size_t)c->npanels + 1));
-    TRY(dev_alloc(&c->mb, (size_t)c->npanels + 2));
+    TRY(dev_alloc(&c->mb, ((size_t)c->npanels + 2) * HB_MBS));
     TRY(dev_alloc(&c->accq, (size_t)HB_ND * mp));
     TRY(dev_alloc(&c->xinfo, 2));
     TRY(dev_alloc(&c->thr, mp * (HB_MAX_FOLD - 1)));
@@ -208,7 +208,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->ddense, mp));
     TRY(dev_alloc(&c->fcorr2, mp));
     TRY(dev_alloc(&c->dots, mp));
-    TRY(dev_alloc(&c->ev_count, (size_t)c->npanels));
+    TRY(dev_alloc(&c->ev_count, (size_t)c->npanels * HB_EVS));
     TRY(dev_alloc(&c->ev_idx, mp));
     TRY(dev_alloc(&c->ev_delta, mp));
     TRY(dev_alloc(&c->acc, HB_ACC_N));
@@ -628,7 +628,7 @@ int hb_ctx_get_events(hb_ctx *c, int32_t *ev_count, int32_t *ev_idx, double *ev_
     int rc = check_cols(c, 0, 0, "hb_ctx_get_events");
     if (rc) return rc;
     HB_HIP(hipStreamSynchronize(c->stream));
-    if (ev_count) HB_HIP(hipMemcpy(ev_count, c->ev_count, sizeof(int32_t) * (size_t)c->npanels, hipMemcpyDeviceToHost));
+    if (ev_count) HB_HIP(hipMemcpy2D(ev_count, sizeof(int32_t), c->ev_count, sizeof(int32_t) * HB_EVS, sizeof(int32_t), (size_t)c->npanels, hipMemcpyDeviceToHost));
     if (ev_idx) HB_HIP(hipMemcpy(ev_idx, c->ev_idx, sizeof(int32_t) * (size_t)c->m_pad, hipMemcpyDeviceToHost));
     if (ev_delta) HB_HIP(hipMemcpy(ev_delta, c->ev_delta, sizeof(double) * (size_t)c->m_pad, hipMemcpyDeviceToHost));
     return HB_OK;

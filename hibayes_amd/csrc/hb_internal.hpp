@@ -19,6 +19,12 @@ int hb_fail(int status, const std::string &msg);
 
 // layout of the per-sweep scalar block the kernels accumulate into / the host reads back
 #define HB_ND 7 /* int8 digits of the fixed-point residual: 55 bits + sign */
+// Words that one workgroup writes through and others read behind a flag — the panels' move counts, the groups' bounds on max |yadj| —
+// live ONE PER 128-BYTE LINE: a reader that touched the line for panel p while the chain was writing panel p + 1's word into it could
+// otherwise be left with a copy that shows the neighbour's old value (the stale-line hazard of DESIGN.md §9.0), and such a word is not
+// a sentinel a later look would recognise. ev_count[p] is at ev_count[p * HB_EVS], mb[i] at mb[i * HB_MBS].
+#define HB_EVS 32
+#define HB_MBS 16
 #define HB_LSTAMP_BLOCKS 4608
 
 enum {

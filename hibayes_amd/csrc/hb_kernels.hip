@@ -76,7 +76,6 @@ __device__ __forceinline__ void hb_abort_log(unsigned *flags, unsigned kind, boo
 __device__ __forceinline__ void hb_poll_pause(unsigned &looks, int base)
 {
 #if HB_BACKOFF
-    looks++;
     if (looks > 4096u) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
     else if (looks > 256u) __builtin_amdgcn_s_sleep(64);
     else if (base <= 1) __builtin_amdgcn_s_sleep(1);
@@ -88,14 +87,38 @@ __device__ __forceinline__ void hb_poll_pause(unsigned &looks, int base)
 #endif
 }
 
+// A poll that cannot be served a stale line. The hand-offs are polled with agent-scope (sc1) loads, which the XCD's L2 may serve;
+// round 4's abort log (profiles/r04_dense_stall_diagnostics.txt) shows what the dense stall of round 3 was: once in ~10^9 polled
+// words a reader's L2 keeps returning the sentinel a word was pre-filled with although the producer's write-through store reached
+// memory long ago (the reader asked for the line ahead of time, and its copy was never dropped) — every later look hits that copy,
+// and the pipeline waits until its 3 s time-out. A returning agent-scope atomic (fetch-or with 0) is performed at the memory side,
+// the one place all eight XCDs agree on: it returns what memory holds and leaves it unchanged. Every wait looks that way once in
+// HB_FRESH_EVERY looks — a wait that is served at once never pays for it.
+#define HB_FRESH_EVERY 8
+__device__ __forceinline__ double ld_fresh(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(const_cast<double *>(p)), 0ull,
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ unsigned ld_flag_fresh(const unsigned *p)
+{
+    return __hip_atomic_fetch_or(const_cast<unsigned *>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_fresh(const int *p)
+{
+    return (int)__hip_atomic_fetch_or(reinterpret_cast<unsigned *>(const_cast<int *>(p)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (uniform) is this look of a wait a memory-side one?
+__device__ __forceinline__ bool hb_fresh_look(unsigned looks) { return (looks % HB_FRESH_EVERY) == HB_FRESH_EVERY - 1; }
+
 // one lane waits until *word >= want; bounded; returns false when the run is being aborted
 template <int SLEEP = 8>
 __device__ __forceinline__ bool wait_ge(unsigned *flags, int word, unsigned want)
 {
     const unsigned long long t0 = wall_clock64();
-    for (;;) {
-        if (ld_flag(flags + word) >= want) return true;
-        if (ld_flag(flags + HB_FLAG_ABORT)) return false;
+    for (unsigned looks = 0;; looks++) {
+        if ((hb_fresh_look(looks) ? ld_flag_fresh(flags + word) : ld_flag(flags + word)) >= want) return true;
+        if (hb_fresh_look(looks) ? ld_flag_fresh(flags + HB_FLAG_ABORT) : ld_flag(flags + HB_FLAG_ABORT)) return false;
         if (wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
             st_flag(flags + HB_FLAG_ABORT, 1u);
             st_flag(flags + 8, want); // (diagnostics: who gave up, hb_ctx.hip fetch_acc)
@@ -283,12 +306,12 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
     int total = 0;
     int nevs[8]; // the group's event counts in one round trip (a group has at most 8 panels)
 #pragma unroll
-    for (int i = 0; i < 8; i++) nevs[i] = ld_sc1(q.ev_count + min(q.p0 + i, q.p1 - 1));
+    for (int i = 0; i < 8; i++) nevs[i] = ld_sc1(q.ev_count + (size_t)min(q.p0 + i, q.p1 - 1) * HB_EVS);
     for (int p = q.p0; p < q.p1; p++) {
         int nev = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) nev = (p - q.p0 == i) ? nevs[i] : nev;
-        if (p - q.p0 >= 8) nev = ld_sc1(q.ev_count + p);
+        if (p - q.p0 >= 8) nev = ld_sc1(q.ev_count + (size_t)p * HB_EVS);
         if (nev == 0) continue; // uniform
         total += nev;
         __syncthreads();
@@ -376,10 +399,18 @@ __device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q,
     double dv[16], mbv = 0.0;
     {
         const unsigned long long t0 = wall_clock64();
+        int relook = 0;
         for (;;) {
 #pragma unroll
             for (int i = 0; i < 16; i++) dv[i] = ld_sc1(q.dd + (size_t)q.p0 * q.P + min(64 * i + lane, ncol - 1));
             if (q.rq) mbv = ld_sc1(q.mbv); // (every lane the same word: one broadcast load)
+            if (relook > 1) { // (a word that is still missing although the group's last one was seen: read it at the memory side, see ld_fresh)
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    if (HBU_SENT(dv[i])) dv[i] = ld_fresh(q.dd + (size_t)q.p0 * q.P + min(64 * i + lane, ncol - 1));
+                if (q.rq && HBU_SENT(mbv)) mbv = ld_fresh(q.mbv);
+            }
+            relook++;
             bool bad = q.rq && HBU_SENT(mbv);
 #pragma unroll
             for (int i = 0; i < 16; i++) bad |= HBU_SENT(dv[i]);
@@ -389,9 +420,10 @@ __device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q,
             const double *last = q.rq ? q.mbv : q.dd + (size_t)q.p0 * q.P + (ncol - 1);
             bool dead = false;
             unsigned looks = 0;
-            while (HBU_SENT(ld_sc1(last))) {
-                if (ld_flag(q.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) { dead = true; break; }
+            while (HBU_SENT(hb_fresh_look(looks) ? ld_fresh(last) : ld_sc1(last))) {
+                if ((hb_fresh_look(looks) ? ld_flag_fresh(q.flags + HB_FLAG_ABORT) : ld_flag(q.flags + HB_FLAG_ABORT)) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) { dead = true; break; }
                 hb_poll_pause(looks, 8);
+                looks++;
             }
             // (the last word is there and an earlier one is not yet visible: look again, but never without the bound on the wait)
             if (!dead && (ld_flag(q.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS)) dead = true;
@@ -759,7 +791,7 @@ __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, un
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (acc && i < HB_ACC_N) acc[i] = 0.0; // (null: a later range of the same sweep keeps the sums)
     if (i < HB_NFLAGS && (acc || i != HB_FLAG_ABORT)) flags[i] = 0u; // (a later range keeps an abort raised by an earlier one)
-    for (int k = p_lo + i; k < np; k += stride) ev_count[k] = 0; // (panels of this range on: an earlier range's move lists stay readable)
+    for (int k = p_lo + i; k < np; k += stride) ev_count[(size_t)k * HB_EVS] = 0; // (panels of this range on: an earlier range's move lists stay readable)
     for (int k = i; k < m_pad; k += stride) dsum[k] = ~0ull;
     if (fcorr)
         for (int k = i; k < m_pad; k += stride) fcorr[k] = ~0ull;
@@ -768,7 +800,7 @@ __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, un
     if (fc2)
         for (int k = i; k < m_pad; k += stride) fc2[k] = ~0ull;
     if (mbs) // (the dense update rows poll the group's bound on max |yadj| together with its changes: "not written yet")
-        for (int k = mb_lo + i; k < mb_hi; k += stride) mbs[k] = ~0ull;
+        for (int k = mb_lo + i; k < mb_hi; k += stride) mbs[(size_t)k * HB_MBS] = ~0ull;
 }
 
 __global__ __launch_bounds__(1024) void k_quant0(const double *__restrict__ r, int64_t ld, int8_t *__restrict__ rq,
@@ -1089,7 +1121,7 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
     for (int l = 1; l <= v.L; l++) {
         const int bp = p - l;
         if (bp < 0) break;
-        const int nevp = v.ev_count[bp];
+        const int nevp = v.ev_count[(size_t)bp * HB_EVS];
         const int32_t *gx = gp + (size_t)l * P * P;
         const int32_t *eix = v.ev_idx + (size_t)bp * P;
         const double *edl = v.ev_delta + (size_t)bp * P;
@@ -1227,10 +1259,10 @@ __global__ __launch_bounds__(512) void k_chain(const hb_sweep_in *__restrict__ p
     }
     if (v.mb) { // (uniform)
         absd = block_sum(absd, red);
-        if (t == 0) v.mb[1 + p] = fma(v.xabs, absd, v.mb[p]);
+        if (t == 0) v.mb[(size_t)(1 + p) * HB_MBS] = fma(v.xabs, absd, v.mb[(size_t)p * HB_MBS]);
     }
     if (t == 0) {
-        v.ev_count[p] = nev;
+        v.ev_count[(size_t)p * HB_EVS] = nev;
         atomicAdd(&v.acc[HB_ACC_SUMG2], wsum);
         atomicAdd(&v.acc[HB_ACC_EVENTS], (double)nev);
     }
@@ -1440,6 +1472,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // opening ring (see below): HB_RD slots of [P reduced dots: 8 B][P filter words: 4 B][pad to 1 KiB][1 KiB packed hot-list]
     const int OSZ = ((12 * P + 1023) >> 10) << 10, OSLOT = OSZ + 1024, NPC = (OSZ >> 10) + 1; // NPC: DMA pieces per group
     char *oring = reinterpret_cast<char *>(corrL + (size_t)R * P);
+    // with k_fwd beside the chain (pv.fcorr; BayesR at panel 512, one panel per group): what the panels two and more before a
+    // panel owe it arrives through fcorr[] — brought into this two-slot LDS ring by LDS-DMA one panel ahead, see below — and the
+    // chain itself folds a panel's moves into the NEXT panel only (half of the band rows of a dense sweep leave its compute unit)
+    const bool fwd = pv.fcorr != nullptr;
+    double *fcring = reinterpret_cast<double *>(oring + (size_t)4 * (((((size_t)12 * P + 1023) >> 10) << 10) + 1024));
     int pslot = -1; // p mod R
     double wacc = 0.0;
     int cacc[K1 + 1];
@@ -1558,6 +1595,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the barrier below hands it to everybody before the next panel's take
         if (wave < RW) {
             if (S == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a 64-marker panel: the same wave also fills the row cache)
+            else if (fwd && p + HB_RD - 2 >= np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (no group was issued behind this panel's fcorr piece: it is the youngest)
             else if (my_pieces == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else if (my_pieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -1566,31 +1604,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- take over the panel: LDS only ----
         double dj = reinterpret_cast<const double *>(oslotp)[t];
         const float fthr = reinterpret_cast<const float *>(oslotp + 8 * P)[t];
+        const bool use_fc = fwd && p >= pv.p0 + 2; // (the first two panels of a range have nobody two panels before them)
+        double fcv = use_fc ? fcring[(size_t)(p & 1) * P + t] : 0.0;
         bool aborted = false;
         {
-            bool bad = __double_as_longlong(dj) == HB_SENT;
+            bool bad = __double_as_longlong(dj) == HB_SENT, badf = use_fc && __double_as_longlong(fcv) == HB_SENT;
             HB_STAMP_VAL(11, bad ? 1 : 0);
-            if (__any(bad)) { // this wave's dots had not been written when the ring slot was filled: re-read until they are
+            if (__any(bad || badf)) { // this wave's dots (or k_fwd's sums) had not been written when the ring slot was filled: re-read until they are
                 const unsigned long long t0 = wall_clock64();
+                unsigned looks = 0;
                 for (;;) {
+                    const bool fresh = hb_fresh_look(looks);
                     if (bad) {
-                        dj = ld_sc1(&v.dsum[j]);
+                        dj = fresh ? ld_fresh(&v.dsum[j]) : ld_sc1(&v.dsum[j]);
                         bad = __double_as_longlong(dj) == HB_SENT;
                     }
-                    if (!__any(bad)) break;
-                    if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
+                    if (badf) {
+                        fcv = fresh ? ld_fresh(&pv.fcorr[j]) : ld_sc1(&pv.fcorr[j]);
+                        badf = __double_as_longlong(fcv) == HB_SENT;
+                    }
+                    if (!__any(bad || badf)) break;
+                    const bool own = wall_clock64() - t0 > HB_TIMEOUT_TICKS;
+                    if (ld_flag(pv.flags + HB_FLAG_ABORT) || own) {
                         if (lane == 0) st_flag(pv.flags + HB_FLAG_ABORT, 1u);
+                        const unsigned long long bm = __ballot(bad || badf);
+                        if (bm && lane == __ffsll((long long)bm) - 1) hb_abort_log(pv.flags, HB_LOG_GROUP, own, bad ? 1u : 2u, (unsigned)p, ~0ull);
                         aborted = true;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(4);
+                    hb_poll_pause(looks, 1);
+                    looks++;
                 }
             }
         }
         double corrv;
         {
             double *cp = corrL + (size_t)pslot * P + t;
-            corrv = *cp;
+            corrv = *cp + fcv;
             *cp = 0.0; // the slot is panel p + R's from now on
         }
         const bool active = fthr == fthr;                          // not NaN: a polymorphic marker
@@ -2086,7 +2136,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     st_sc1(&v.ev_delta[(size_t)p * P + e], ev_del[e]);
                     absd += fabs(ev_del[e]);
                 }
-                if (lane == 0) st_sc1(&v.ev_count[p], nev);
+                if (lane == 0) st_sc1(&v.ev_count[(size_t)p * HB_EVS], nev);
                 if (v.mb) mbr = fma(v.xabs, wave_sum(absd), mbr);
             }
             HB_STAMP(4);
@@ -2108,7 +2158,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             evacc = nev + evacc;
             HB_STAMP(5);
             // ---- fold the moves forward into the corrections of the next Lb panels ----
-            const int lcount = min(min(pv.Lb, (pv.Lv + 1) * pv.D - 1 - pmodD), np - 1 - p); // panels that need the correction
+            const int lcount = min(min(fwd ? 1 : pv.Lb, (pv.Lv + 1) * pv.D - 1 - pmodD), np - 1 - p); // panels that need the correction FROM HERE (k_fwd: the others)
             bool from_pre = NPL > 0 && nev > 0 && nev <= HB_NPF;
             int w0 = 0, w1 = 0;
             if (from_pre) { // did exactly (a subset of) the first two candidates move? Their rows are already here
@@ -2148,7 +2198,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (wave == S - 1 && group_end) {
             // last panel of its mat-vec group: the update of this group is waiting for exactly these moves, and the
             // next panel's take may itself have to wait for a later launch — publish now rather than at that take
-            if (lane == 0 && v.mb) st_sc1(&v.mb[1 + gcount], mbr);
+            if (lane == 0 && v.mb) st_sc1(&v.mb[(size_t)(1 + gcount) * HB_MBS], mbr);
             gcount++;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(p + 1));
@@ -2158,6 +2208,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // so any of them placed after a DMA piece would drain that piece as well (the queue is in-order); issued here, the
         // pieces have the whole next panel — which, when quiet, contains no vector-memory wait at all — to land ----
         // (0) ring group of panel p + HB_RD - 1, into the slot panel p - 1 has just left
+        // (k_fwd's sums for the NEXT panel first — one 1-KiB piece per ring wave, P = 512 — so that the counted wait at the top of the
+        // next panel, which lets the youngest ring group stay in flight, covers them; a word k_fwd has not written yet shows the
+        // sentinel the sweep filled fcorr[] with and is polled at the take)
+        if (fwd && wave < RW && have_next && p + 1 >= pv.p0 + 2)
+            dma_piece_s(reinterpret_cast<const char *>(pv.fcorr + (size_t)(p + 1) * P) + (__builtin_amdgcn_readfirstlane(wave) << 10),
+                        (unsigned)(uintptr_t)fcring + (unsigned)(((p + 1) & 1) * P * 8) + ((unsigned)__builtin_amdgcn_readfirstlane(wave) << 10), true);
         if (wave < RW && p + HB_RD - 1 < np) issue_group(p + HB_RD - 1, (oslot + HB_RD - 1) % HB_RD);
         // (1) Gram rows of the next panel's hot markers, straight into the other half of the LDS row cache by LDS-DMA; the
         // first reader of that half — the first round of the next panel that has candidates — drains vmcnt before its
@@ -2197,7 +2253,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- the last panel's moves: drain and publish ----
     if (wave == S - 1 && ok) {
-        if (lane == 0 && v.mb) st_sc1(&v.mb[1 + gcount], mbr);
+        if (lane == 0 && v.mb) st_sc1(&v.mb[(size_t)(1 + gcount) * HB_MBS], mbr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)np);
     }
@@ -2733,7 +2789,7 @@ static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128
 #define HB_PERSIST_RING(P) ((size_t)4 * ((((size_t)12 * (P) + 1023) >> 10 << 10) + 1024)) /* HB_RD slots of the opening ring */
 // move lists (12 B per marker) + reduction / counter words + one round's candidate staging (sized by the model's K1 non-null classes)
 // + the 64 x 64 block of mutual Gram entries + the correction ring + the opening ring; the rest is the double-buffered row cache
-#define HB_PERSIST_FIXED(P, LB, K1) ((size_t)(P) * 12 + 128 + 512 + 64 * (8 * (3 + 3 * (K1)) + 12) + 64 * 64 * 4 + (size_t)((LB) + 1) * (P) * 8 + HB_PERSIST_RING(P))
+#define HB_PERSIST_FIXED(P, LB, K1) ((size_t)(P) * 12 + 128 + 512 + 64 * (8 * (3 + 3 * (K1)) + 12) + 64 * 64 * 4 + (size_t)((LB) + 1) * (P) * 8 + HB_PERSIST_RING(P) + (size_t)2 * (P) * 8 /* k_fwd's sums, two panels */)
 static int persist_nslot(int P, int Lb, int K1) { return std::min(P, std::min(250, (int)((160 * 1024 - HB_PERSIST_FIXED(P, Lb, K1)) / ((size_t)P * 4)))); }
 // the whole 160 KiB: nothing that needs LDS (mat-vec, update) can then be co-scheduled on the chain's CU
 static size_t persist_smem(int) { return (size_t)160 * 1024; }
@@ -2905,6 +2961,7 @@ static void launch_dotq(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st
         c->lstamp_nblk[gidx] = nblk;
         c->lstamp_cols[gidx] = ncols;
     }
+    if (gidx == 1 && getenv("HB_DEBUG_LDIAG")) fprintf(stderr, "launch_dotq: gidx 1 nblk %d ldiag %p -> %p (nblk vector %zu)\n", nblk, (void *)c->ldiag, (void *)v.ldiag, c->ldiag_nblk.size());
     hipLaunchKernelGGL(k_dotq, dim3(nblk), dim3(64), uq.dense ? HBU_LDS : HBQ_LDS, st, v, uq);
 }
 
@@ -2991,7 +3048,7 @@ static upd_view make_upd(hb_ctx *c, int p0, int p1, int sin, int sout, unsigned 
     const bool fx = c->precise == 2;
     return upd_view{c->X, c->P, p0, p1, c->ev_count, c->ev_idx, c->ev_delta, c->r + (size_t)sin * c->ld,
                     c->r + (size_t)sout * c->ld, c->u, c->r32 + (size_t)sout * c->ld, flags,
-                    fx ? c->rq + (size_t)sout * HB_ND * c->ld : nullptr, c->mb + 1 + mbi, c->vexp + sout,
+                    fx ? c->rq + (size_t)sout * HB_ND * c->ld : nullptr, c->mb + (size_t)(1 + mbi) * HB_MBS, c->vexp + sout,
                     c->layout == 2 ? c->X2 : nullptr, c->ld2 / 4, 0, c->ddense};
 }
 
@@ -3236,6 +3293,11 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     if (c->L > HB_LBMAX && !fwd)
         return hb_fail(HB_ERR_UNSUPPORTED, "three groups of seven panels of look-ahead need the group chain with k_fwd (BayesB / BayesC, panel 512)");
     if (dense) pv.fcorr = c->fcorr;
+    // BayesR on the per-panel chain (round 4): k_fwd folds a panel's moves into the panels two (and, at Lv = 3, three) ahead, the chain
+    // itself only into the next one — half (two thirds) of the band rows of a dense sweep leave the chain's compute unit (HB_FWD=0: off)
+    const bool fwd_persist = !dense && !group_chain && kp == 3 && c->P == 512 && D == 1 && (Lv == 2 || Lv == 3) && c->fwd_group && !alone &&
+                             np - pb > 2 && getenv("HB_FWD_R") == nullptr;
+    if (fwd_persist) pv.fcorr = c->fcorr;
     auto launch_the_chain = [&](hipStream_t st) -> int {
         if (dense) {
             if (model == 5) hipLaunchKernelGGL((k_chain_dense<true>), dim3(1), dim3(512), persist_smem(c->P), st, c->d_in, cv, pv, c->ddense, c->fcorr2);
@@ -3273,7 +3335,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // the L2 warmers (k_warm): a third branch of the graph, 4 workgroups per XCD of which only the chain's XCD's stay
     int warm = 4;
     if (const char *e = getenv("HB_WARM")) warm = std::max(0, std::min(16, atoi(e)));
-    if (alone || (group_chain && !c->warm_group) || fwd || dense) warm = 0;
+    if (alone || (group_chain && !c->warm_group) || fwd || dense || fwd_persist) warm = 0; // (k_fwd has the third stream)
     if (dense) { // (Lb + 1 target panels are open at any time: Lb ahead for their band, the chain's own for its far sub-blocks)
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         hipLaunchKernelGGL(k_fold_dense, dim3(8 * (c->L + 1)), dim3(256), 0, c->s_upd, cv, pv, c->ddense, c->fcorr2, c->L + 1);
@@ -3295,6 +3357,12 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         if (Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else hipLaunchKernelGGL((k_fwd<7, 2, 4>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+        HB_HIP(hipGetLastError());
+    }
+    if (fwd_persist) {
+        HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
+        if (Lv == 2) hipLaunchKernelGGL((k_fwd<1, 1, 16>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+        else hipLaunchKernelGGL((k_fwd<1, 2, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         HB_HIP(hipGetLastError());
     }
     if (warm) {
@@ -3347,7 +3415,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     }
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
-    if (warm || fwd || dense || warm_dense) {
+    if (warm || fwd || dense || warm_dense || fwd_persist) {
         HB_HIP(hipEventRecord(c->ev_upd[0], c->s_upd));
         HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[0], 0));
     }

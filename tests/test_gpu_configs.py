@@ -99,17 +99,44 @@ def test_config4_shard_shape_bayescpi_n50k_m250k_pipeline_vs_serial():
         same_chain(a, b, 1e-9, "config 4 shard: pipeline vs serial")
 
 
-def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=2, dense=0.0):
-    """dense > 0: the chain starts from an installed state with that fraction of the markers in the model (g_init on both
-    sides): crowded rounds, row-cache misses and band folds of hundreds of moves per mat-vec group from the first panel on."""
+@pytest.fixture(scope="module")
+def c3():
+    """Config 3's genotypes (n = 50k, m = 500k, generated on the device) in ONE context shared by the full-size oracle cases, with
+    the int8 matrix downloaded once for the live oracle (25 GB): generating, downloading and re-checking them per case was most of
+    the suite's run time."""
+    n, m = 50000, 500000
     need = n * m / 1e9 + 8
     if host_free_gb() < need:
         pytest.skip("host has %.0f GB available, the live oracle needs %.0f GB for the int8 genotypes" % (host_free_gb(), need))
+    c = H.Context(n, m, seed=20240901, m_offset=0, precise=2)
+    c.generate(20240901, mono_every=1000)
+    y = synth_y(c, n, m, 17)
+    X = c.download()
+    yield c, y, X
+    c.close()
+
+
+def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=2, dense=0.0, shared=None, bits=8):
+    """dense > 0: the chain starts from an installed state with that fraction of the markers in the model (g_init on both
+    sides): crowded rounds, row-cache misses and band folds of hundreds of moves per mat-vec group from the first panel on.
+    bits = 2: the sweep runs on the 2-bit resident layout with the int8 copy dropped after the Gram build, as bench.py's headline does."""
     kw = dict(fold=fold, niter=niter, nburn=0, thin=1, seed=20240901)
-    with H.Context(n, m, seed=20240901, m_offset=m_offset, precise=precise) as c:
+    if shared is None:
+        need = n * m / 1e9 + 8
+        if host_free_gb() < need:
+            pytest.skip("host has %.0f GB available, the live oracle needs %.0f GB for the int8 genotypes" % (host_free_gb(), need))
+        c = H.Context(n, m, seed=20240901, m_offset=m_offset, precise=precise)
         c.generate(20240901, mono_every=1000)
         y = synth_y(c, n, m, 17)
+        X = None
+    else:
+        c, y, X = shared
+    try:
         c.set_pipeline(*geo)
+        if bits == 2:
+            c.build_gram()
+            c.set_layout(2, keep_int8=False)
+            assert c.layout() == (2, False)
         if dense > 0:
             rs = np.random.default_rng(23)
             g0 = np.zeros(m)
@@ -117,9 +144,16 @@ def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=
             g0[on] = rs.normal(0, 0.01, on.size)
             kw["g_init"] = g0
         r = H.Bayes(y, None, model, Pi, verbose=False, precise=precise, ctx=c, store_alpha=False, **kw)
+        assert c.pipeline()[:3] == geo and c.layout()[0] == bits
         invariants(c, y, r)
         g_gpu, trk, _ = c.get_effects()
-        X = c.download()
+        if X is None:
+            X = c.download()
+    finally:
+        if shared is None:
+            c.close()
+        elif bits == 2:
+            c.set_layout(8)          # (the next case finds the int8 columns again)
     ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, marker_offset=m_offset, **kw)
     g_ref = ref["s_alpha"][:, -1]
     assert np.array_equal(g_gpu != 0, g_ref != 0), "%d of %d inclusion decisions differ" % (((g_gpu != 0) != (g_ref != 0)).sum(), m)
@@ -131,22 +165,24 @@ def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=
     assert (g_ref != 0).sum() > 0
 
 
-@pytest.mark.parametrize("geo", [(1, 3, 7), (1, 2, 7)])   # the default (k_fwd beside the group chain, a 28-block band) and round 3's first
-def test_config3_bayescpi_n50k_m500k_draw_for_draw_against_live_oracle(geo):
-    _full_size_vs_oracle(50000, 500000, "BayesCpi", [0.95, 0.05], None, geo, 0)
+# (1, 3, 7) on 2-bit genotypes with the int8 copy dropped is THE shape bench.py's `value` is measured on (ld2 = 98 x 128 bytes, a ragged
+# last stage); (1, 3, 7) / (1, 2, 7) on int8 columns: the library's default layout under the default and round 3's first geometry
+@pytest.mark.parametrize("geo,bits", [((1, 3, 7), 2), ((1, 3, 7), 8), ((1, 2, 7), 8)])
+def test_config3_bayescpi_n50k_m500k_draw_for_draw_against_live_oracle(c3, geo, bits):
+    _full_size_vs_oracle(50000, 500000, "BayesCpi", [0.95, 0.05], None, geo, 0, shared=c3, bits=bits)
 
 
-def test_config3_bayesr_n50k_m500k_draw_for_draw_against_live_oracle():
+def test_config3_bayesr_n50k_m500k_draw_for_draw_against_live_oracle(c3):
     """BASELINE.json configs[2] is BayesR at n=50k, m=500k: its own model, at its own size and default geometry, against the
     live oracle (reference src/Bayes.cpp:743-815) — 2 sweeps from cold, ~47 moves per panel."""
-    _full_size_vs_oracle(50000, 500000, "BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 0)
+    _full_size_vs_oracle(50000, 500000, "BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 0, shared=c3)
 
 
 @pytest.mark.parametrize("model,Pi,fold,geo", [("BayesCpi", [0.95, 0.05], None, (1, 3, 7)),
                                                 ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1))])
-def test_config3_dense_installed_state_against_live_oracle(model, Pi, fold, geo):
+def test_config3_dense_installed_state_against_live_oracle(c3, model, Pi, fold, geo):
     """The same size from an installed state with 5 % of the markers in the model (25 000 certain movers in the first sweep)."""
-    _full_size_vs_oracle(50000, 500000, model, Pi, fold, geo, 0, niter=2, dense=0.05)
+    _full_size_vs_oracle(50000, 500000, model, Pi, fold, geo, 0, niter=2, dense=0.05, shared=c3)
 
 
 def test_config5_shard_shape_bayesb_n200k_m125k_draw_for_draw_against_live_oracle():

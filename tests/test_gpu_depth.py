@@ -64,6 +64,8 @@ def _compare(r, ref, tol=1e-9):
 @pytest.mark.parametrize("start", ["cold", "dense"])
 @pytest.mark.parametrize("precise", [2, 1])   # 2: exact fixed-point mat-vec (library default); 1: fp64 FMA mat-vec
 def test_default_geometry_draw_for_draw_at_pipeline_depth(big, model, Pi, fold, geo, panel, mcols, start, precise):
+    if precise == 1 and panel == 64:
+        pytest.skip("the fp64-FMA mat-vec is covered at panel 512 (and by the goldens at panel 64): not repeated here, to keep the suite's run time")
     X, y = big["X"][:, :mcols], big["y"]
     if model == "BayesRR":
         if panel == 512:

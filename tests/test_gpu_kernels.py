@@ -324,3 +324,28 @@ def test_two_bit_layout_refuses_what_it_cannot_hold():
         c.upload(np.abs(X))
         with pytest.raises(H.HibayesError, match="precise = 2"):
             c.set_layout(2)
+
+
+def test_gram_rebuild_from_the_two_bit_layout_alone():
+    """A context that dropped its int8 copy (hb_ctx_set_layout(c, 2, 0)) and is then asked for a wider band rebuilds the Gram blocks
+    from the packed genotypes: a window of panels at a time is unpacked into a scratch buffer (never the whole matrix), and every
+    block is the exact int32 product."""
+    rng = np.random.default_rng(31)
+    n, panel, m = 900, 64, 64 * 9 + 5
+    X = rand_geno(rng, n, m)
+    with H.Context(n, m, panel=panel, precise=2) as c:
+        c.upload(X)
+        c.set_pipeline(1, 1, 1)
+        c.build_gram()
+        c.set_layout(2, keep_int8=False)
+        assert c.layout() == (2, False)
+        c.set_pipeline(1, 2, 2)                                  # band 5 > the stored band 1: the next build must come from X2
+        c.build_gram()
+        assert c.layout() == (2, False)                          # (no int8 copy was materialised behind the caller's back)
+        band = c.pipeline()[3]
+        Xi = np.zeros((n, (m + panel - 1) // panel * panel), dtype=np.int64)
+        Xi[:, :m] = X
+        for p in range((m + panel - 1) // panel):
+            for l in range(0, min(band, p) + 1):
+                a, b = Xi[:, (p - l) * panel:(p - l + 1) * panel], Xi[:, p * panel:(p + 1) * panel]
+                assert np.array_equal(c.gram_band(p, l), a.T @ b), (p, l)
