@@ -178,17 +178,18 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
 # v_and, v_lshrrev) issues once per this many cycles per SIMD, at this sustained clock; LDS returns 128 bytes per clock per CU
 VALU_CYCLES_PER_WAVE_INSTR = 4.5
 SUSTAINED_GHZ = 2.25
-N_CU, SIMD_PER_CU, LDS_BYTES_PER_CLK_CU = 256, 4, 128.0
+N_CU, SIMD_PER_CU, LDS_BYTES_PER_CLK_CU = 256, 4, 256.0   # (ds_read_b128: 4 cycles per wave-instruction, MI355X_MICROARCH.md LDS table)
 
 
 def valu_block(n, cols, avg_ms, kernel):
-    """What bounds the 2-bit v_dot4 kernel (it is not HBM): per 16 genotypes of a column one lane issues 28 v_dot4 + 7 mask
-    operations and receives 7 broadcast digit reads + a quarter of a 16-byte column read through LDS."""
+    """What bounds the 2-bit v_dot4 kernel (it is not HBM): per 16 genotypes of a column one lane issues 28 v_dot4 + 5 mask
+    operations (round 4: shift-free masks, hb_dotq2.hpp Q2_SCALED) and receives 7 broadcast digit reads + a quarter of a 16-byte
+    column read through LDS."""
     if kernel != "k_dotq2":
         return None
     lane_steps = float(n) * cols / 16.0          # (lane, 16-genotype chunk) pairs per launch
     wave_steps = lane_steps / 64.0
-    dot4, mask, lds_reads = 28.0 * wave_steps, 7.0 * wave_steps, 7.25 * wave_steps
+    dot4, mask, lds_reads = 28.0 * wave_steps, 5.0 * wave_steps, 7.25 * wave_steps
     t_valu = (dot4 + mask) * VALU_CYCLES_PER_WAVE_INSTR / (N_CU * SIMD_PER_CU) / (SUSTAINED_GHZ * 1e9)
     t_lds = lds_reads * 1024.0 / (N_CU * LDS_BYTES_PER_CLK_CU) / (SUSTAINED_GHZ * 1e9)
     dur = avg_ms * 1e-3
@@ -197,7 +198,8 @@ def valu_block(n, cols, avg_ms, kernel):
             "valu_issue_floor_us": t_valu * 1e6, "lds_return_floor_us": t_lds * 1e6, "measured_us": dur * 1e6,
             "frac_of_valu_issue_bound": t_valu / dur, "frac_of_lds_return_bound": t_lds / dur,
             "what": "floors of one launch if nothing else existed: VALU issue of the dot4 + mask stream over 1024 SIMDs, and the LDS->VGPR "
-                    "return path (1 KiB per ds_read_b128, 128 B/clk/CU) of the broadcast digit reads; the larger one bounds the kernel "
+                    "return path (1 KiB per ds_read_b128 at 256 B/clk/CU) of the broadcast digit reads; one wave issues both, so where they "
+                    "do not overlap the bound is their sum "
                     "(profiles/r04_dot4_rate.txt, profiles/r04_pmc_sq_k_dotq2.txt)"}
 
 
@@ -251,6 +253,11 @@ PIPELINE = {  # (pipeline, look-ahead groups, panels per mat-vec launch): see DE
     "BayesCpi": (1, 3, 7), "BayesC": (1, 3, 7), "BayesB": (1, 3, 7), "BayesBpi": (1, 3, 7),
     "BayesR": (1, 2, 1), "BayesRR": (1, 2, 2), "BayesA": (1, 2, 2), "BayesL": (1, 2, 2),   # (RR / A / L at panel 512: k_chain_dense, hb_run's own choice)
 }
+
+
+for _k in list(PIPELINE):  # (tuning runs: HB_BENCH_GEO_BayesR="1,3,1" overrides a model's geometry)
+    if os.environ.get("HB_BENCH_GEO_" + _k):
+        PIPELINE[_k] = tuple(int(x) for x in os.environ["HB_BENCH_GEO_" + _k].split(","))
 
 
 def prior(model):

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         break;
                     }
                     hb_poll_pause(looks, 1);
+                    hb_long_wait(looks); // (what this workgroup stored write-through may be what the data it waits for depends on: hb_kernels.hip)
                     looks++;
                 }
             }
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             break;                                                                                                \
                         }                                                                                                         \
                         hb_poll_pause(looks_, 1);                                                                                 \
+                        hb_long_wait(looks_);                                                                                     \
                         looks_++;                                                                                                 \
                     }                                                                                                             \
                 }                                                                                                                 \
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view p
                         break;
                     }
                     hb_poll_pause(looks, 1);
+                    hb_long_wait(looks);
                     looks++;
                 }
                 if (st + 1 < nsteps) dn = ld_sc1(dptr(st + 1)); // (looked at before this step was there: likely stale)

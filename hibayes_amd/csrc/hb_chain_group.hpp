@@ -134,6 +134,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         break;
                     }
                     __builtin_amdgcn_s_sleep(2);
+                    hb_long_wait(looks);
                 }
             }
 #pragma unroll

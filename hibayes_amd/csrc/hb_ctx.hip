@@ -808,6 +808,14 @@ static int fetch_acc(hb_ctx *c)
     if (c->blk_n) HB_HIP(hipMemcpyAsync(c->h_blk, c->blk, sizeof(double) * c->blk_n, hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
     c->aborted = false;
+    if (c->ldiag) { // (HB_DEBUG_ABORT) a long wait that flushed its L2 and went on leaves no other trace
+        static unsigned seen = 0;
+        const unsigned now = hbk_long_wait_flushes();
+        if (now != seen) {
+            fprintf(stderr, "hibayes_gpu: %u long waits flushed their L2 so far (+%u in this sweep)%s\n", now, now - seen, c->h_flags[1] ? " — and the sweep was aborted" : "");
+            seen = now;
+        }
+    }
     // (a sharded sweep: the rank whose pipeline gave up poisons the sums it contributes, so every rank sees a NaN here — hb_run.hip)
     if (c->h_flags[1] || c->h_acc[HB_ACC_EVENTS] != c->h_acc[HB_ACC_EVENTS]) {
         c->aborted = true;

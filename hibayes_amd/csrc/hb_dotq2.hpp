@@ -22,6 +22,14 @@
 #define Q2_DIAG 0 /* timing diagnostics only (wrong results): 1 = no atomics at the tile's end, 2 = no dot4 (loads + reduction only) */
 #endif
 #define Q2_RS 512   /* individuals per stage of the default shape (the padded column length is a multiple of it) */
+// Q2_SCALED (round 4): the four genotypes of a byte are masked WITHOUT shifting them down — w & 0x03030303, w & 0x0c0c0c0c,
+// w & 0x30303030 leave them scaled by 1, 4, 16, and (w >> 1) & 0x60606060 by 32 (0xc0 would be a negative int8) — and each scale
+// sums into its own accumulator; the four are combined exactly at the tile's end (a sum of multiples of 4^k shifts back without
+// loss). Five mask operations per 16 genotypes instead of seven, and four independent dot4 chains per plane instead of one.
+// The scale-32 sums bound a tile: rows x 96 x 128 < 2^31, i.e. at most 174 000 individuals per tile (the host splits taller columns).
+#ifndef Q2_SCALED
+#define Q2_SCALED 1
+#endif
 
 // RS: individuals per stage (512 or 256). A 1-KiB DMA piece holds 4096 / RS columns x RS individuals of the tile, or 1024 / RS
 // digit planes x RS individuals.
@@ -45,11 +53,14 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
 #pragma unroll
     for (int j = 0; j < NDP; j++) doff[j] = (unsigned)(min(j * PPP + lane / LPP, HB_ND - 1) * ld + (lane % LPP) * 16);
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
-    int acc[CPL][HB_ND];
+    constexpr int NSC = Q2_SCALED ? 4 : 1;
+    int acc[CPL][HB_ND][NSC];
 #pragma unroll
     for (int c = 0; c < CPL; c++)
 #pragma unroll
-        for (int k = 0; k < HB_ND; k++) acc[c][k] = 0;
+        for (int k = 0; k < HB_ND; k++)
+#pragma unroll
+            for (int q = 0; q < NSC; q++) acc[c][k][q] = 0;
     // (values that ARE wave-uniform, but that hipcc may keep on the vector unit when scalar registers run short)
     auto uni_p = [](const int8_t *p) {
         const unsigned long long u = (unsigned long long)(uintptr_t)p;
@@ -107,15 +118,27 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
                 const unsigned xw = (unsigned)(w == 0 ? xq[c].x : w == 1 ? xq[c].y : w == 2 ? xq[c].z : xq[c].w);
+#if Q2_SCALED
+                const int m0 = (int)(xw & 0x03030303u), m1 = (int)(xw & 0x0c0c0c0cu), m2 = (int)(xw & 0x30303030u),
+                          m3 = (int)((xw >> 1) & 0x60606060u);
+#pragma unroll
+                for (int k = 0; k < HB_ND; k++) {
+                    acc[c][k][0] = __builtin_amdgcn_sdot4(m0, d[k].x, acc[c][k][0], false);
+                    acc[c][k][1] = __builtin_amdgcn_sdot4(m1, d[k].y, acc[c][k][1], false);
+                    acc[c][k][2] = __builtin_amdgcn_sdot4(m2, d[k].z, acc[c][k][2], false);
+                    acc[c][k][3] = __builtin_amdgcn_sdot4(m3, d[k].w, acc[c][k][3], false);
+                }
+#else
                 const int m0 = (int)(xw & 0x03030303u), m1 = (int)((xw >> 2) & 0x03030303u), m2 = (int)((xw >> 4) & 0x03030303u),
                           m3 = (int)((xw >> 6) & 0x03030303u);
 #pragma unroll
                 for (int k = 0; k < HB_ND; k++) {
-                    acc[c][k] = __builtin_amdgcn_sdot4(m0, d[k].x, acc[c][k], false);
-                    acc[c][k] = __builtin_amdgcn_sdot4(m1, d[k].y, acc[c][k], false);
-                    acc[c][k] = __builtin_amdgcn_sdot4(m2, d[k].z, acc[c][k], false);
-                    acc[c][k] = __builtin_amdgcn_sdot4(m3, d[k].w, acc[c][k], false);
+                    acc[c][k][0] = __builtin_amdgcn_sdot4(m0, d[k].x, acc[c][k][0], false);
+                    acc[c][k][0] = __builtin_amdgcn_sdot4(m1, d[k].y, acc[c][k][0], false);
+                    acc[c][k][0] = __builtin_amdgcn_sdot4(m2, d[k].z, acc[c][k][0], false);
+                    acc[c][k][0] = __builtin_amdgcn_sdot4(m3, d[k].w, acc[c][k][0], false);
                 }
+#endif
             }
         }
         buf ^= 1;
@@ -123,9 +146,11 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
 #pragma unroll
     for (int c = 0; c < CPL; c++)
 #pragma unroll
-        for (int k = 0; k < HB_ND; k++)
-            __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * (64 * CPL) + c * 64 + lane, (long long)acc[c][k], __ATOMIC_RELAXED,
+        for (int k = 0; k < HB_ND; k++) {
+            const int tot = Q2_SCALED ? acc[c][k][0] + (acc[c][k][NSC > 1 ? 1 : 0] >> 2) + (acc[c][k][NSC > 2 ? 2 : 0] >> 4) + (acc[c][k][NSC > 3 ? 3 : 0] >> 5) : acc[c][k][0];
+            __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * (64 * CPL) + c * 64 + lane, (long long)tot, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+        }
 }
 
 template <int CPL, int RS>
@@ -181,7 +206,10 @@ static constexpr int q2_lds(int cpl, int rs) { return 2 * ((64 * cpl / (4096 / r
 #define Q2M_XB (4 * HBQ_SLOT)
 #define Q2M_BUF (Q2M_XB + 2 * Q2M_DSTRIDE)
 #define Q2M_PER 6
-static constexpr int q2m_lds() { return 2 * Q2M_BUF; }
+#ifndef Q2M_NBUF
+#define Q2M_NBUF 3 /* stage buffers: NBUF - 1 stages in flight ahead of the one being multiplied (a stage computes in ~0.3 us, a loaded round trip takes ~2) */
+#endif
+static constexpr int q2m_lds() { return Q2M_NBUF * Q2M_BUF; }
 
 __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
 {
@@ -222,15 +250,18 @@ __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
     // this lane's digit reads: plane n = min(lane & 15, 6) (the output columns 7..15 of the instruction are never looked at)
     const int n = min(m, HB_ND - 1);
     const unsigned dlane = (unsigned)((n >> 2) * Q2M_DSTRIDE + (kb * 16 + (n & 3)) * 16); // + 64 r: chunk 4 kb + r
-    issue(st0, 0);
+#pragma unroll
+    for (int a = 0; a < Q2M_NBUF - 1; a++)
+        if (st0 + a < st1) issue(st0 + a, a);
     int buf = 0;
     for (int st = st0; st < st1; ++st) {
-        if (st + 1 < st1) {
-            issue(st + 1, buf ^ 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_PER) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (st + Q2M_NBUF - 1 < st1) issue(st + Q2M_NBUF - 1, (buf + Q2M_NBUF - 1) % Q2M_NBUF);
+        // stages still in flight behind this one: the counted wait lets exactly those stay outstanding
+        const int ahead = min(Q2M_NBUF - 1, st1 - 1 - st);
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * Q2M_PER) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * Q2M_PER) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const char *bp = smem + buf * Q2M_BUF;
         hb_v4i D[4], X[4];
 #pragma unroll
@@ -249,21 +280,27 @@ __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
             C[ct][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, B2, C[ct][2], 0, 0, 0);
             C[ct][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, B3, C[ct][3], 0, 0, 0);
         }
-        buf ^= 1;
+        // (the next iteration's DMA overwrites the buffer read here: every LDS read of it has returned — the MFMAs consumed them)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        buf = (buf + 1 == Q2M_NBUF) ? 0 : buf + 1;
     }
     // the instruction's result layout: lane l, register r = C[row 4 (l / 16) + r][column l % 16], i.e. genotype column
     // 4 kb + r of the tile, plane m. The sums of scale 4^k are multiples of it: the shifts are exact.
+    // Turned through LDS (the tile buffers are free now; one wave: no barrier) so that a lane ends up with ONE column and the seven
+    // closing atomics of the wave each cover 64 consecutive columns — straight from the result layout an atomic instruction
+    // would touch 28 separate lines (7 planes x 4 lane groups): measured 44 us per launch against 22 with a quarter of the tiles.
+    int *tr = reinterpret_cast<int *>(smem); // [plane][64 columns]
     if (m < HB_ND) {
 #pragma unroll
         for (int ct = 0; ct < 4; ct++) {
             const hb_v4i tot = C[ct][0] + (C[ct][1] >> 2) + (C[ct][2] >> 4) + (C[ct][3] >> 5);
-            long long *dst = v.accq + (int64_t)m * v.accstride + cg * 64 + ct * 16 + 4 * kb;
-            __hip_atomic_fetch_add(dst + 0, (long long)tot.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(dst + 1, (long long)tot.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(dst + 2, (long long)tot.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(dst + 3, (long long)tot.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<hb_v4i *>(tr + m * 64 + ct * 16 + 4 * kb) = tot;
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < HB_ND; k++)
+        __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * 64 + lane, (long long)tr[k * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(64) void k_dotq2m(dq_view v, upd_view uq)

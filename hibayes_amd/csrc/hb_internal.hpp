@@ -184,6 +184,7 @@ struct hb_ctx {
 
 extern "C" int hb_ctx_snapshot(hb_ctx *c, int model_index, bool store, bool count_pip);
 extern "C" int hb_ctx_restore(hb_ctx *c);
+unsigned hbk_long_wait_flushes();
 int hbk_copy_segs(hb_ctx *c, const std::vector<hb_ctx::snap_seg> &segs, bool restore);
 
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed);

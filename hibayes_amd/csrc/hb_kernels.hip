@@ -44,11 +44,28 @@
 #define HB_LOG_GROUP 7        /* k_chain_group / k_fwd / k_chain_persist: a = code, b = panel or group */
 
 __device__ __forceinline__ unsigned ld_flag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_flag(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_flag(unsigned *p, unsigned v)
+{
+#if defined(HB_PUBLISH_ATOMIC) && HB_PUBLISH_ATOMIC
+    (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 __device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_sc1(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// HB_PUBLISH_ATOMIC (an A/B for the dense stall): publish with a no-return atomic exchange — performed at the memory side,
+// the point all XCDs share — instead of a write-through store that the writer's L2 forwards
+#ifndef HB_PUBLISH_ATOMIC
+#define HB_PUBLISH_ATOMIC 0
+#endif
+#if HB_PUBLISH_ATOMIC
+__device__ __forceinline__ void st_sc1(double *p, double v) { (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(int *p, int v) { (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
 __device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 
 __device__ __forceinline__ void hb_abort_log(unsigned *flags, unsigned kind, bool own, unsigned a, unsigned b, unsigned long long seen)
 {
@@ -94,7 +111,9 @@ __device__ __forceinline__ void hb_poll_pause(unsigned &looks, int base)
 // and the pipeline waits until its 3 s time-out. A returning agent-scope atomic (fetch-or with 0) is performed at the memory side,
 // the one place all eight XCDs agree on: it returns what memory holds and leaves it unchanged. Every wait looks that way once in
 // HB_FRESH_EVERY looks — a wait that is served at once never pays for it.
-#define HB_FRESH_EVERY 8
+#ifndef HB_FRESH_EVERY
+#define HB_FRESH_EVERY 0 /* 0: never (the default since the stall turned out to be on the WRITER's side, see hb_long_wait) */
+#endif
 __device__ __forceinline__ double ld_fresh(const double *p)
 {
     return __longlong_as_double((long long)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(const_cast<double *>(p)), 0ull,
@@ -109,7 +128,41 @@ __device__ __forceinline__ int ld_fresh(const int *p)
     return (int)__hip_atomic_fetch_or(reinterpret_cast<unsigned *>(const_cast<int *>(p)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // (uniform) is this look of a wait a memory-side one?
-__device__ __forceinline__ bool hb_fresh_look(unsigned looks) { return (looks % HB_FRESH_EVERY) == HB_FRESH_EVERY - 1; }
+__device__ __forceinline__ bool hb_fresh_look(unsigned looks)
+{
+#if HB_FRESH_EVERY > 0
+    return (looks % HB_FRESH_EVERY) == HB_FRESH_EVERY - 1;
+#else
+    (void)looks;
+    return false;
+#endif
+}
+
+// A wait that has lasted a few hundred looks writes back the dirty lines of ITS OWN XCD's L2 (buffer_wbl2 sc1). What the launch
+// stamps and the memory-side looks of round 4 showed about the dense stall (profiles/r04_dense_stall_diagnostics.txt): once in a few
+// thousand sweeps the device pauses for ~1 ms (a launch starts 0.85 ms after its predecessor ended; `max_ms` of the in-situ stamps shows
+// the same pauses in runs that do not stall), and afterwards ONE write-through store instruction of the chain workgroup — a sub-block's
+// 64 changes of effect — is in nobody's view: every reader on every other XCD, memory-side atomics included, sees the pre-filled sentinel
+// for 3 s, while the value appears in memory the moment the kernels end (their end-of-kernel release writes the L2 back). The line sits
+// dirty in the WRITER's L2. The writer is by then waiting itself — for the sums that depend on that very store — so the remedy lives in
+// the waits: whoever has published write-through data and then waits longer than any healthy hand-off takes flushes its L2. A healthy
+// wait never gets here (hand-offs take microseconds); a stalled one is released within a fraction of a millisecond instead of 3 s.
+#ifndef HB_FLUSH_LOOKS
+#define HB_FLUSH_LOOKS 256
+#endif
+__device__ unsigned hb_long_wait_flushes; // (diagnostics: how often a wait got that far; read by fetch_acc with HB_DEBUG_ABORT)
+__device__ __forceinline__ void hb_long_wait(unsigned looks)
+{
+#if HB_FLUSH_LOOKS > 0
+    if ((looks % HB_FLUSH_LOOKS) == HB_FLUSH_LOOKS - 1) { // (uniform)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0) atomicAdd(&hb_long_wait_flushes, 1u);
+    }
+#else
+    (void)looks;
+#endif
+}
 
 // one lane waits until *word >= want; bounded; returns false when the run is being aborted
 template <int SLEEP = 8>
@@ -119,6 +172,7 @@ __device__ __forceinline__ bool wait_ge(unsigned *flags, int word, unsigned want
     for (unsigned looks = 0;; looks++) {
         if ((hb_fresh_look(looks) ? ld_flag_fresh(flags + word) : ld_flag(flags + word)) >= want) return true;
         if (hb_fresh_look(looks) ? ld_flag_fresh(flags + HB_FLAG_ABORT) : ld_flag(flags + HB_FLAG_ABORT)) return false;
+        hb_long_wait(looks);
         if (wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
             st_flag(flags + HB_FLAG_ABORT, 1u);
             st_flag(flags + 8, want); // (diagnostics: who gave up, hb_ctx.hip fetch_acc)
@@ -422,7 +476,12 @@ __device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q,
             unsigned looks = 0;
             while (HBU_SENT(hb_fresh_look(looks) ? ld_fresh(last) : ld_sc1(last))) {
                 if ((hb_fresh_look(looks) ? ld_flag_fresh(q.flags + HB_FLAG_ABORT) : ld_flag(q.flags + HB_FLAG_ABORT)) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) { dead = true; break; }
+#ifdef HB_UPD_SLEEP
+                __builtin_amdgcn_s_sleep(HB_UPD_SLEEP);
+                __builtin_amdgcn_s_sleep(HB_UPD_SLEEP);
+#else
                 hb_poll_pause(looks, 8);
+#endif
                 looks++;
             }
             // (the last word is there and an earlier one is not yet visible: look again, but never without the bound on the wait)
@@ -1605,6 +1664,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         double dj = reinterpret_cast<const double *>(oslotp)[t];
         const float fthr = reinterpret_cast<const float *>(oslotp + 8 * P)[t];
         const bool use_fc = fwd && p >= pv.p0 + 2; // (the first two panels of a range have nobody two panels before them)
+        // (k_fwd's sums were brought in by the ring waves only one panel ahead — their producer needs the panel before — so unlike the
+        // ring groups no earlier barrier has handed them to the other waves yet: one extra barrier per panel, a few hundred cycles)
+        if (use_fc) __syncthreads();
         double fcv = use_fc ? fcring[(size_t)(p & 1) * P + t] : 0.0;
         bool aborted = false;
         {
@@ -1633,6 +1695,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         break;
                     }
                     hb_poll_pause(looks, 1);
+                    hb_long_wait(looks);
                     looks++;
                 }
             }
@@ -2184,7 +2247,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             } else if (nev > 0) { // batch shape by band width: as many loads in flight as the registers allow
                 // (a kernel specialised for one band width — NPL == Lb — carries only that width's fold: the others would
                 // be dead code that still costs registers in the loop every panel runs)
-                if (NPL > 12) fold_forward<HB_LBMAX, 2>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
+                if (fwd) fold_forward<1, 32>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p); // (the next panel only: 32 moves per trip)
+                else if (NPL > 12) fold_forward<HB_LBMAX, 2>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
                 else if (NPL > 0 && NPL <= 2) fold_forward<2, 16>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
                 else if (pv.Lb <= 2) fold_forward<2, 16>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
                 else if (pv.Lb <= 5) fold_forward<5, 8>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev, ev_ix, ev_del, p);
@@ -2884,7 +2948,11 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     const int nst = (int)((c->ld + RS - 1) / RS);
     const int ncg = ncols / (64 * cpl);
     // (a tile is at least four stages: its first stage's load latency and its closing atomics are paid per tile)
-    const int ns = std::max(1, std::min(std::max(1, nst / 4), (int)((double)c->dotq2_tiles / ncg + 0.5)));
+    // (the matrix-core kernel streams best with few, long tiles — its per-stage work is an eighth of the v_dot4 kernel's, so a tile's fixed
+    // costs weigh more: ~800 tiles per 3584-column launch)
+    int ns = std::max(1, std::min(std::max(1, nst / 4), (int)((double)(mfma && !getenv("HB_DOTQ2_TILES") ? 800 : c->dotq2_tiles) / ncg + 0.5)));
+    // (int32 accumulators of genotypes scaled by up to 32 — Q2_SCALED, k_dotq2m: rows x 96 x 128 < 2^31 bounds a tile at 174 000 individuals)
+    ns = std::max(ns, (int)(((int64_t)nst * RS + 131071) / 131072));
     const int NS = (nst + ns - 1) / ns, nsplit = (nst + NS - 1) / NS;
     upd_view uq{};
     if (upd) uq = *upd;
@@ -3659,6 +3727,13 @@ int hbk_abort_poison(hb_ctx *c, double *sums)
     hipLaunchKernelGGL(k_abort_poison, dim3(1), dim3(1), 0, c->stream, c->flags, sums);
     HB_HIP(hipGetLastError());
     return HB_OK;
+}
+
+unsigned hbk_long_wait_flushes()
+{
+    unsigned v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(hb_long_wait_flushes), sizeof v);
+    return v;
 }
 
 int hbk_windows(hb_ctx *c)

@@ -15,6 +15,8 @@ def run(n, m, model, niter, nburn, seed=20240901):
     pv = np.array(Pi); a.Pi, a.n_pi = pv.ctypes.data, pv.size
     if fold is not None: fv = np.array(fold, dtype=float); a.fold, a.n_fold = fv.ctypes.data, fv.size
     a.niter, a.nburn, a.thin = niter, nburn, 5; a.seed = 1; a.ctx = c.h
+    a.precise = int(os.environ.get("HB_SOAK_PRECISE", "2"))  # (the library default: the exact fixed-point mat-vec, update rows riding in the launches;
+    #  until round 4 this script left the field at 0 and so soaked the fp32 path, whose dense update is a kernel of its own)
     run = ct.c_void_p(); check(c.L.hb_run_create(ct.byref(a), ct.byref(run)))
     fin = ct.c_int32(); info = RunInfo()
     t0 = time.time(); done = 0
