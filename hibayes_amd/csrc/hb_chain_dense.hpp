@@ -126,15 +126,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
             if (__any(bad)) {
                 const unsigned long long t0 = wall_clock64();
-                unsigned looks = 0;
                 for (;;) {
-                    if (hb_fresh_look(looks)) { // (a lane still waiting reads at the memory side: ld_fresh, hb_kernels.hip)
-                        if (HBD_SENT(dj)) dj = ld_fresh(&v.dsum[j]);
-                        if (use_fc && HBD_SENT(fc)) fc = ld_fresh(&fcp[j]);
-                    } else {
-                        dj = ld_sc1(&v.dsum[j]);
-                        fc = ld_sc1(&fcp[j]);
-                    }
+                    dj = ld_sc1(&v.dsum[j]);
+                    fc = ld_sc1(&fcp[j]);
 #if HB_STAMPS
                     if (v.dbg && t == 0 && !HBD_SENT(dj) && c12 == 0) c12 = clock64();
 #endif
@@ -144,17 +138,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (ld_flag(pv.flags + HB_FLAG_ABORT) || own) {
                         if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); misc[2] = 1; }
                         if (bad) { st_flag(pv.flags + 9, (unsigned)p + 1u); st_flag(pv.flags + 10, (HBD_SENT(dj) ? 1u : 2u) + (own ? 0x100u : 0u)); }
-                        { // (diagnostics: the first lane of the wave that is still waiting says for what)
-                            const unsigned long long bm = __ballot(bad);
-                            if (bm && lane == __ffsll((long long)bm) - 1)
-                                hb_abort_log(pv.flags, HBD_SENT(dj) ? HB_LOG_CHAIN_DOT : HB_LOG_CHAIN_FCORR, own, (unsigned)j, (unsigned)p,
-                                             (unsigned long long)__double_as_longlong(HBD_SENT(dj) ? dj : fc));
-                        }
                         break;
                     }
-                    hb_poll_pause(looks, 1);
-                    hb_long_wait(looks); // (what this workgroup stored write-through may be what the data it waits for depends on: hb_kernels.hip)
-                    looks++;
+                    __builtin_amdgcn_s_sleep(1);
                 }
             }
             rhs = dj - (use_fc ? fc : 0.0);
@@ -191,22 +177,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if ((s) > HBD_NEAR) { /* the far sub-blocks' share, summed by k_fold_dense while the near ones were being applied */     \
                 if (__any(HBD_SENT(fc2))) {                                                                                       \
                     const unsigned long long t0_ = wall_clock64();                                                                \
-                    unsigned looks_ = 0;                                                                                          \
                     for (;;) {                                                                                                    \
-                        fc2 = (hb_fresh_look(looks_) && HBD_SENT(fc2)) ? ld_fresh(&fcorr2[j]) : ld_sc1(&fcorr2[j]);               \
+                        fc2 = ld_sc1(&fcorr2[j]);                                                                                 \
                         if (!__any(HBD_SENT(fc2))) break;                                                                         \
                         const bool own_ = wall_clock64() - t0_ > HB_TIMEOUT_TICKS;                                                \
                         if (ld_flag(pv.flags + HB_FLAG_ABORT) || own_) {                                                          \
                             if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); st_flag(pv.flags + 9, (unsigned)p + 1u); st_flag(pv.flags + 10, 3u); misc[2] = 1; } \
-                            const unsigned long long bm_ = __ballot(HBD_SENT(fc2));                                               \
-                            if (bm_ && lane == __ffsll((long long)bm_) - 1)                                                       \
-                                hb_abort_log(pv.flags, HB_LOG_CHAIN_FC2, own_, (unsigned)j, (unsigned)p, ~0ull);                  \
                             fc2 = 0.0;                                                                                            \
                             break;                                                                                                \
                         }                                                                                                         \
-                        hb_poll_pause(looks_, 1);                                                                                 \
-                        hb_long_wait(looks_);                                                                                     \
-                        looks_++;                                                                                                 \
+                        __builtin_amdgcn_s_sleep(1);                                                                              \
                     }                                                                                                             \
                 }                                                                                                                 \
                 rhs -= fc2;                                                                                                       \

@@ -130,11 +130,12 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_DOTQ2_TILES")) c->dotq2_tiles = std::max(1, atoi(e));
     if (const char *e = getenv("HB_DOTQ2_KIND")) c->dotq2_kind = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("HB_DOTQ2_NC")) c->dotq2_nc = std::max(4, atoi(e) / 4 * 4);
-    if (const char *e = getenv("HB_DOTQ2_RS")) c->dotq2_rs = atoi(e) == 256 ? 256 : 512;
+    if (const char *e = getenv("HB_DOTQ2_RS")) c->dotq2_rs = atoi(e) == 256 ? 256 : atoi(e) == 128 ? 128 : 512;
     if (const char *e = getenv("HB_CHAIN")) c->chain_kind = std::strcmp(e, "panel") == 0 ? 0 : std::strcmp(e, "all") == 0 ? 3 : (atoi(e) ? atoi(e) : 1);
     if (const char *e = getenv("HB_WARM_GROUP")) c->warm_group = atoi(e) != 0;
     if (const char *e = getenv("HB_FWD")) c->fwd_group = atoi(e) != 0;
     if (const char *e = getenv("HB_DENSE")) c->dense_chain = atoi(e) != 0;
+    if (const char *e = getenv("HB_TIMEOUT_MS")) c->timeout_ms = std::max(1, std::min(60000, atoi(e)));
     if (const char *e = getenv("HB_KAPPA")) c->kappa = atof(e);
     if (const char *e = getenv("HB_DOT_LDS")) c->dot_lds = std::min(65536, std::max(0, atoi(e)));
     if (const char *e = getenv("HB_CANDF")) c->candf = std::min(1.0, std::max(0.0, atof(e)));

@@ -174,6 +174,7 @@ struct hb_ctx {
     size_t snap_cap = 0;
     std::vector<snap_seg> snap_segs; // what the last snapshot holds
     bool aborted = false;            // the last fetch found the abort flag raised
+    int timeout_ms = 100;            // a device-side wait gives up after this long (HB_TIMEOUT_MS; hb_run_step raises it for a replay)
     int inject_abort_panel = -1;     // debug hook (hb_ctx_debug_inject_abort): the next sweeps are aborted once chain_done reaches this panel
     int inject_abort_times = 0;
     hipStream_t s_dbg = nullptr;
@@ -185,6 +186,7 @@ struct hb_ctx {
 extern "C" int hb_ctx_snapshot(hb_ctx *c, int model_index, bool store, bool count_pip);
 extern "C" int hb_ctx_restore(hb_ctx *c);
 unsigned hbk_long_wait_flushes();
+int hbk_set_timeout(hb_ctx *c);
 int hbk_copy_segs(hb_ctx *c, const std::vector<hb_ctx::snap_seg> &segs, bool restore);
 
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed);

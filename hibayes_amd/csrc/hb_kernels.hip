@@ -28,7 +28,12 @@
 #define HB_FLAG_ABORT 1
 #define HB_FLAG_XCC 2               /* 1 + the XCD the chain workgroup runs on (k_warm) */
 #define HB_NFLAGS 72                /* words in the flag block that every sweep clears */
-#define HB_TIMEOUT_TICKS 300000000ull /* wall_clock64() runs at 100 MHz: 3 s */
+// How long a wait inside the pipeline may last before it gives up and aborts the sweep, in ticks of wall_clock64() (100 MHz). A device
+// global, set per sweep from hb_ctx.timeout_ms (hbk_set_timeout): 100 ms by default — a healthy hand-off takes microseconds, the
+// device's own occasional pauses ~1 ms (§9.0), and an aborted sweep is replayed by hb_run_step, so giving up early is cheap; the
+// replay of a sweep runs with 3 s, and a run that aborts repeatedly (a shared or profiled GPU) raises its own default.
+__device__ unsigned long long hb_timeout_ticks = 10000000ull;
+#define HB_TIMEOUT_TICKS hb_timeout_ticks
 // Abort log (diagnostics of a pipeline time-out, read by fetch_acc in hb_ctx.hip): whoever leaves a wait because the sweep is
 // being aborted appends one record of 8 words — what it was waiting for, whether the time-out was its own, the clock, the value
 // it last saw. flags[HB_FLAG_LOGN] counts the records, they start at flags + HB_LOG_BASE (the flag block has 4096 words).
@@ -67,7 +72,7 @@ __device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store
 __device__ __forceinline__ void st_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
-__device__ __forceinline__ void hb_abort_log(unsigned *flags, unsigned kind, bool own, unsigned a, unsigned b, unsigned long long seen)
+__device__ __attribute__((noinline)) void hb_abort_log(unsigned *flags, unsigned kind, bool own, unsigned a, unsigned b, unsigned long long seen)
 {
     const unsigned i = atomicAdd(flags + HB_FLAG_LOGN, 1u);
     if (i >= HB_LOG_CAP) return;
@@ -148,7 +153,7 @@ __device__ __forceinline__ bool hb_fresh_look(unsigned looks)
 // the waits: whoever has published write-through data and then waits longer than any healthy hand-off takes flushes its L2. A healthy
 // wait never gets here (hand-offs take microseconds); a stalled one is released within a fraction of a millisecond instead of 3 s.
 #ifndef HB_FLUSH_LOOKS
-#define HB_FLUSH_LOOKS 256
+#define HB_FLUSH_LOOKS 0 /* off: measured, it does not release a stall (§9.0) — 11 sweeps in 16 000 still timed out with it */
 #endif
 __device__ unsigned hb_long_wait_flushes; // (diagnostics: how often a wait got that far; read by fetch_acc with HB_DEBUG_ABORT)
 __device__ __forceinline__ void hb_long_wait(unsigned looks)
@@ -2943,7 +2948,7 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
         }
     }
     const bool mfma = c->dotq2_kind == 2; // (A/B: the digit-plane product on the matrix cores, k_dotq2m; 256-individual stages, 64 columns per wave)
-    int cpl = (ncols % 128 == 0 && !mfma) ? c->dotq2_cpl : 1;
+    int cpl = (ncols % 128 == 0 && !mfma && c->dotq2_rs != 128) ? c->dotq2_cpl : 1;
     const int RS = mfma ? Q2M_RS : c->dotq2_rs;
     const int nst = (int)((c->ld + RS - 1) / RS);
     const int ncg = ncols / (64 * cpl);
@@ -2989,6 +2994,7 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     else if (cpl == 2 && RS == 512) hipLaunchKernelGGL((k_dotq2<2, 512>), dim3(nblk), dim3(64), q2_lds(2, 512), st, v, uq);
     else if (cpl == 2) hipLaunchKernelGGL((k_dotq2<2, 256>), dim3(nblk), dim3(64), q2_lds(2, 256), st, v, uq);
     else if (RS == 512) hipLaunchKernelGGL((k_dotq2<1, 512>), dim3(nblk), dim3(64), q2_lds(1, 512), st, v, uq);
+    else if (RS == 128) hipLaunchKernelGGL((k_dotq2<1, 128>), dim3(nblk), dim3(64), q2_lds(1, 128), st, v, uq); // (6208 bytes of LDS per wave: twice the waves per compute unit)
     else hipLaunchKernelGGL((k_dotq2<1, 256>), dim3(nblk), dim3(64), q2_lds(1, 256), st, v, uq);
 }
 
@@ -3029,7 +3035,6 @@ static void launch_dotq(hb_ctx *c, int col0, int ncols, int slot, hipStream_t st
         c->lstamp_nblk[gidx] = nblk;
         c->lstamp_cols[gidx] = ncols;
     }
-    if (gidx == 1 && getenv("HB_DEBUG_LDIAG")) fprintf(stderr, "launch_dotq: gidx 1 nblk %d ldiag %p -> %p (nblk vector %zu)\n", nblk, (void *)c->ldiag, (void *)v.ldiag, c->ldiag_nblk.size());
     hipLaunchKernelGGL(k_dotq, dim3(nblk), dim3(64), uq.dense ? HBU_LDS : HBQ_LDS, st, v, uq);
 }
 
@@ -3508,6 +3513,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
 
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
 {
+    if (int rc = hbk_set_timeout(c)) return rc;
     *c->h_in = *in;
     HB_HIP(hipMemcpyAsync(c->d_in, c->h_in, sizeof(hb_sweep_in), hipMemcpyHostToDevice, c->stream));
     if (timed || c->row_reduce) return enqueue_sweep_kernels(c, in->model_index, in->n_fold, true); // (row-sharded mode: host round trips inside the sweep)
@@ -3726,6 +3732,18 @@ int hbk_abort_poison(hb_ctx *c, double *sums)
 {
     hipLaunchKernelGGL(k_abort_poison, dim3(1), dim3(1), 0, c->stream, c->flags, sums);
     HB_HIP(hipGetLastError());
+    return HB_OK;
+}
+
+int hbk_set_timeout(hb_ctx *c)
+{
+    static int uploaded_ms[64];
+    const int dev = c->device & 63, ms = std::max(1, c->timeout_ms);
+    if (uploaded_ms[dev] == ms) return HB_OK;
+    const unsigned long long ticks = (unsigned long long)ms * 100000ull;
+    HB_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(hb_timeout_ticks), &ticks, sizeof ticks, 0, hipMemcpyHostToDevice, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream)); // (the source is a stack word; this happens once per change of the value)
+    uploaded_ms[dev] = ms;
     return HB_OK;
 }
 

@@ -91,6 +91,7 @@ struct hb_run {
     int sync_blocks = 1;       // runs of mat-vec groups per sweep, an exchange after each (hb_bayes_args.sync_blocks)
     bool recover_on = true;    // replay a sweep whose pipeline timed out (HB_RECOVER=0: fail the run, as before round 4)
     int aborts = 0;            // sweeps replayed so far
+    int abort_win_start = 0, abort_win_count = 0, slow_timeout = 0; // three aborts within 64 iterations: a slow device, the run's time-out is raised
     bool adaptive_geo = false; // choose (Lv, D) per sweep from the previous sweep's moves (BayesB/C)
     int geo_wide_lv = 2;       // look-ahead groups of the wide geometry (3 with k_fwd beside the chain, else 2)
     int geo_cur = 0;           // 0: (2, 7), 1: (2, 2)
@@ -749,6 +750,7 @@ int hb_run::step()
     const bool recover = recover_on && c->pipeline && !rowmode;
     int saved_geo[4] = {0, 0, 0, 0};
     bool fell_back = false;
+    const int base_timeout = c->timeout_ms;
     if (recover) {
         rc = hb_ctx_snapshot(c, model_index, in.store != 0, in.count_pip != 0);
         if (rc) return rc;
@@ -787,6 +789,11 @@ int hb_run::step()
                 attempt >= 1 ? " on the per-panel kernels" : "");
         rc = hb_ctx_restore(c);
         if (rc) return rc;
+        // (the replay waits as long as round 3's pipeline did: a wait that was merely slow — a shared or profiled GPU — then gets through)
+        c->timeout_ms = std::max(base_timeout, 3000);
+        // a run that keeps aborting is on a slow device, not in a stall (those come once in a few thousand sweeps): wait longer from now on
+        if (iter - abort_win_start > 64) { abort_win_start = iter; abort_win_count = 0; }
+        if (++abort_win_count >= 3) slow_timeout = std::min(3000, std::max(base_timeout, slow_timeout) * 4);
         if (attempt >= 1 && !fell_back) {
             (void)hb_ctx_get_pipeline(c, &saved_geo[0], &saved_geo[1], &saved_geo[2], &saved_geo[3]);
             rc = hb_ctx_set_pipeline(c, 0, 0, 1);
@@ -794,6 +801,7 @@ int hb_run::step()
             fell_back = true;
         }
     }
+    c->timeout_ms = std::max(base_timeout, slow_timeout);
     if (fell_back) {
         const int rc2 = hb_ctx_set_pipeline(c, saved_geo[0], saved_geo[1], saved_geo[2]);
         if (rc2) return rc2;
