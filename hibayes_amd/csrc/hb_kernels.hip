@@ -353,42 +353,55 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
         __syncthreads();
         if (!*s_ok) return;
     }
+    // Round 4: the whole group in FOUR dependent memory round trips — the flag above; the bound and the panels' move counts together;
+    // the move lists of all panels of the group at once; the genotype columns of up to 16 moves at a time — instead of two per panel with
+    // moves (list, then columns: ~10 trips for a group of seven panels with a move each, ~2 us apiece beside the streaming tiles; the
+    // update blocks lived 20 us and, on the matrix-core mat-vec, ended 8 us after the launch's last tile — profiles/r04_launch_roles_*).
+    // The moves are applied in the same order (panel, then position in its list): the same sums bit for bit.
     int fixE = 0;
-    if (q.rq) { // (uniform) exponent of the new version, the same number in every workgroup
-        __syncthreads();
-        if (threadIdx.x == 0) s_ok[1] = hb_fix_exp(ld_sc1(q.mbv));
-        __syncthreads();
-        fixE = s_ok[1];
-        if (blk == 0 && threadIdx.x == 0) *q.vexp_out = fixE;
-    }
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int total = 0;
-    int nevs[8]; // the group's event counts in one round trip (a group has at most 8 panels)
+    int nevs[8]; // a group has at most 8 panels
+    {
+        const double mbv = q.rq ? ld_sc1(q.mbv) : 0.0; // (every thread the same word: one broadcast load per wave, in flight with the counts)
 #pragma unroll
-    for (int i = 0; i < 8; i++) nevs[i] = ld_sc1(q.ev_count + (size_t)min(q.p0 + i, q.p1 - 1) * HB_EVS);
-    for (int p = q.p0; p < q.p1; p++) {
-        int nev = 0;
+        for (int i = 0; i < 8; i++) nevs[i] = ld_sc1(q.ev_count + (size_t)min(q.p0 + i, q.p1 - 1) * HB_EVS);
+        if (q.rq) { // (uniform) exponent of the new version, the same number in every workgroup
+            fixE = hb_fix_exp(mbv);
+            if (blk == 0 && threadIdx.x == 0) *q.vexp_out = fixE;
+        }
+    }
+    int off[9];
+    off[0] = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) nev = (p - q.p0 == i) ? nevs[i] : nev;
-        if (p - q.p0 >= 8) nev = ld_sc1(q.ev_count + (size_t)p * HB_EVS);
-        if (nev == 0) continue; // uniform
-        total += nev;
+    for (int i = 0; i < 8; i++) off[i + 1] = off[i] + (q.p0 + i < q.p1 ? nevs[i] : 0);
+    total = off[8];
+    constexpr int CH = 512; // moves staged per pass (s_ix: 512 ints, s_dl: 512 doubles)
+    for (int base = 0; base < total; base += CH) {
+        const int cnt = min(CH, total - base);
         __syncthreads();
-        for (int e = threadIdx.x; e < nev; e += blockDim.x) {
-            s_ix[e] = ld_sc1(q.ev_idx + (size_t)p * q.P + e);
-            s_dl[e] = ld_sc1(q.ev_delta + (size_t)p * q.P + e);
+        for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+            const int ge = base + e;
+            int i = 0;
+#pragma unroll
+            for (int k = 1; k < 8; k++) i += (ge >= off[k]) ? 1 : 0; // panel of move ge (off[] is non-decreasing; panels past the group add nothing)
+            int oi = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) oi = (i == k) ? off[k] : oi;
+            const size_t src = (size_t)(q.p0 + i) * q.P + (size_t)(ge - oi);
+            s_ix[e] = (q.p0 + i) * q.P + ld_sc1(q.ev_idx + src); // the move's COLUMN
+            s_dl[e] = ld_sc1(q.ev_delta + src);
         }
         __syncthreads();
         if (!mine) continue;
-        const int64_t col0 = (int64_t)p * q.P;
-        int e = 0;
-        for (; e < nev; e += 8) {
-            int w[8];
+        constexpr int UB = 16; // columns in flight per thread: a panel of BayesR's ~47 moves is three trips
+        for (int e = 0; e < cnt; e += UB) {
+            int w[UB];
 #pragma unroll
-            for (int k = 0; k < 8; k++) w[k] = hb_ld4(q.X, ld, q.X2, q.ld2w, col0 + s_ix[min(e + k, nev - 1)], row0);
+            for (int k = 0; k < UB; k++) w[k] = hb_ld4(q.X, ld, q.X2, q.ld2w, (int64_t)s_ix[min(e + k, cnt - 1)], row0);
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const double d = (e + k < nev) ? s_dl[e + k] : 0.0;
+            for (int k = 0; k < UB; k++) {
+                const double d = (e + k < cnt) ? s_dl[e + k] : 0.0;
                 a0 = fma((double)(int8_t)(w[k]), d, a0);
                 a1 = fma((double)(int8_t)(w[k] >> 8), d, a1);
                 a2 = fma((double)(int8_t)(w[k] >> 16), d, a2);
