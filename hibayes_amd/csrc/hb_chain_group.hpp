@@ -446,14 +446,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (wave == S - 1) {
             if (lane < Dg) {
                 const int c = misc[16 + lane];
-                if (c) st_sc1(&v.ev_count[(size_t)(gp0 + lane) * HB_EVS], c);
+                st_sc1(&v.ev_count[(size_t)(gp0 + lane) * HB_EVS], c); // (zero included: the update rows poll the counts themselves)
                 misc[16 + lane] = 0;
             }
             if (v.mb) {
                 mbr = fma(v.xabs, absd_grp, mbr);
                 if (lane == 0) st_sc1(&v.mb[(size_t)(1 + gcount) * HB_MBS], mbr);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (no drain before the flag any more: every consumer of the counts, the bound and the move lists validates the words
+            // themselves — waiting for the acknowledgement of stores to lines that 196 update blocks poll cost this wave, and through
+            // the next group's first barrier the whole workgroup, ~25 000 cycles per group: profiles/r04_group_timeline_*.txt)
             if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(gp0 + Dg));
         }
         HBG_STAMP(9);
@@ -522,18 +524,40 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
         if (t == 0) s_ok = wait_ge(pv.flags, HB_FLAG_CHAIN_DONE, (unsigned)(gp0 + Dg)) ? 1 : 0;
         __syncthreads();
         if (!s_ok) return;
+        // (round 4: chain_done only paces this workgroup — the chain no longer drains its stores before raising it. Counts and list entries
+        // are pre-filled by the sweep with a pattern no value has and validated here, like the update rows do: the data is the flag)
         if (t <= HBF_D) { // exclusive scan of the panels' move counts
             int a = 0;
-            for (int i = 0; i < t && i < Dg; i++) a += ld_sc1(&v.ev_count[(size_t)(gp0 + i) * HB_EVS]);
+            for (int i = 0; i < t && i < Dg; i++) {
+                int c = ld_sc1(&v.ev_count[(size_t)(gp0 + i) * HB_EVS]);
+                const unsigned long long t0 = wall_clock64();
+                while (c < 0 && !ld_flag(pv.flags + HB_FLAG_ABORT) && wall_clock64() - t0 < HB_TIMEOUT_TICKS) {
+                    __builtin_amdgcn_s_sleep(2);
+                    c = ld_sc1(&v.ev_count[(size_t)(gp0 + i) * HB_EVS]);
+                }
+                if (c < 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); c = 0; s_ok = 0; }
+                a += c;
+            }
             s_cnt[t] = a;
         }
         __syncthreads();
+        if (!s_ok) return;
         const int nev = s_cnt[min(Dg, HBF_D)];
         for (int i = 0; i < Dg; i++) {
             const int b = s_cnt[i], c = s_cnt[i + 1] - b;
             for (int k = t; k < c; k += P) {
-                s_pos[b + k] = i * P + ld_sc1(&v.ev_idx[(size_t)(gp0 + i) * P + k]);
-                s_del[b + k] = ld_sc1(&v.ev_delta[(size_t)(gp0 + i) * P + k]);
+                const size_t src = (size_t)(gp0 + i) * P + k;
+                int ix = ld_sc1(&v.ev_idx[src]);
+                double dl = ld_sc1(&v.ev_delta[src]);
+                const unsigned long long t0 = wall_clock64();
+                while ((ix < 0 || __double_as_longlong(dl) == -1ll) && !ld_flag(pv.flags + HB_FLAG_ABORT) && wall_clock64() - t0 < HB_TIMEOUT_TICKS) {
+                    __builtin_amdgcn_s_sleep(2);
+                    ix = ld_sc1(&v.ev_idx[src]);
+                    dl = ld_sc1(&v.ev_delta[src]);
+                }
+                if (ix < 0 || __double_as_longlong(dl) == -1ll) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); ix = 0; dl = 0.0; }
+                s_pos[b + k] = i * P + ix;
+                s_del[b + k] = dl;
             }
         }
         __syncthreads();

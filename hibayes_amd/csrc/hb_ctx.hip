@@ -796,7 +796,7 @@ static void print_abort_diagnostics(hb_ctx *c)
         const int gs = stall_panel >= 0 ? stall_panel / c->D : 0;
         fprintf(stderr, "mat-vec launches around group %d (first own time-out at clock %llu; 100 MHz):\n", gs, first_clock);
         for (int g = std::max(0, gs - 3); g <= std::min(G, gs + 4); g++)
-            fprintf(stderr, "  launch %4d: start %llu (%+.1f us vs the time-out)  last block end %llu (%+.1f us)  blocks finished %llu of %d\n", g, ld[4 * (size_t)g],
+            fprintf(stderr, "  launch %4d: start %llu (%+.1f us vs the time-out)  last block end %llu (%+.1f us)  sampled blocks (every 32nd) finished %llu, launch has %d\n", g, ld[4 * (size_t)g],
                     ((double)ld[4 * (size_t)g] - (double)first_clock) / 100.0, ld[4 * (size_t)g + 1], ((double)ld[4 * (size_t)g + 1] - (double)first_clock) / 100.0,
                     ld[4 * (size_t)g + 2], g < (int)c->ldiag_nblk.size() ? c->ldiag_nblk[g] : -1);
     }
@@ -1341,6 +1341,15 @@ int hb_ctx_debug_launch_stamps(hb_ctx *c, int g, unsigned long long *out, int ca
     const int nb = std::min(cap, c->lstamp_nblk[g]);
     *nblocks = nb;
     if (nb > 0) HB_HIP(hipMemcpy(out, c->lstamp + (size_t)g * HB_LSTAMP_BLOCKS * 2, sizeof(unsigned long long) * 2 * nb, hipMemcpyDeviceToHost));
+    return HB_OK;
+}
+
+// development aid (not in the header): the per-launch diagnostics of the last sweep (HB_DEBUG_ABORT=1), 4 words per launch
+int hb_ctx_debug_ldiag(hb_ctx *c, unsigned long long *out)
+{
+    if (!c || !c->ldiag || !out) return hb_fail(HB_ERR_INVALID, "hb_ctx_debug_ldiag: start the process with HB_DEBUG_ABORT=1");
+    HB_HIP(hipStreamSynchronize(c->stream));
+    HB_HIP(hipMemcpy(out, c->ldiag, sizeof(unsigned long long) * 4 * ((size_t)c->npanels + 2), hipMemcpyDeviceToHost));
     return HB_OK;
 }
 

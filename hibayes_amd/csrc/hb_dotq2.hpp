@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void k_dotq2(dq_view v, upd_view uq)
         if (col < v.fin_ncols) hbq_finalize(v.fin_acc, v.accstride, col, *v.fin_exp, v.fin_out);
     } else if (b < v.nfin + v.nupd) { // residual update of an earlier group (2-bit columns: upd_view.X2), lists staged in the tile buffers
         b -= v.nfin;
-        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096));
+        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096), v.ldiag ? v.ldiag + 3 : nullptr);
     } else {
         dotq2_tile<CPL, RS>(v, smem, b - v.nupd - v.nfin);
     }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64) void k_dotq2m(dq_view v, upd_view uq)
         if (col < v.fin_ncols) hbq_finalize(v.fin_acc, v.accstride, col, *v.fin_exp, v.fin_out);
     } else if (b < v.nfin + v.nupd) {
         b -= v.nfin;
-        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096));
+        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096), v.ldiag ? v.ldiag + 3 : nullptr);
     } else {
         dotq2m_tile(v, smem, b - v.nupd - v.nfin);
     }
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (col < v.fin_ncols) hbq_finalize(v.fin_acc, v.accstride, col, *v.fin_exp, v.fin_out);
     } else if (b < v.nfin + v.nupd) {
         b -= v.nfin;
-        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096));
+        update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096), v.ldiag ? v.ldiag + 3 : nullptr);
     } else {
         dotq2r_tile(v, b - v.nupd - v.nfin);
     }

@@ -152,6 +152,9 @@ __device__ __forceinline__ bool hb_fresh_look(unsigned looks)
 // dirty in the WRITER's L2. The writer is by then waiting itself — for the sums that depend on that very store — so the remedy lives in
 // the waits: whoever has published write-through data and then waits longer than any healthy hand-off takes flushes its L2. A healthy
 // wait never gets here (hand-offs take microseconds); a stalled one is released within a fraction of a millisecond instead of 3 s.
+#ifndef HB_UPD_FLAG_FIRST
+#define HB_UPD_FLAG_FIRST 0
+#endif
 #ifndef HB_FLUSH_LOOKS
 #define HB_FLUSH_LOOKS 0 /* off: measured, it does not release a stall (§9.0) — 11 sweeps in 16 000 still timed out with it */
 #endif
@@ -336,8 +339,12 @@ __device__ __forceinline__ void hb_store_digits(int8_t *rq, int64_t ld, int64_t 
 
 // rows [row0, row0 + 4) of the residual: yadj -= sum_e x_e D_e, u += the same, r32 = (float)yadj
 __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int blk, int *s_ix,
-                                            double *s_dl, int *s_ok)
+                                            double *s_dl, int *s_ok, unsigned long long *ust = nullptr)
 {
+    // (ust: HB_DEBUG_ABORT diagnostics — block 64 of the launch leaves the lengths of its phases, four 16-bit counts of 100 MHz ticks:
+    // poll of counts and bound | move lists | columns and sums | stores; tools/launch_roles.py prints their means)
+    const unsigned long long tA = ust ? wall_clock64() : 0ull;
+    unsigned long long tB = tA, tC = tA, tD = tA;
     const int64_t row0 = ((int64_t)blk * blockDim.x + threadIdx.x) * 4;
     const bool mine = row0 < ld;
     // the residual rows do not depend on the chain: fetch them before waiting for it
@@ -348,29 +355,55 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
         u01 = *reinterpret_cast<const double2 *>(q.u + row0);
         u23 = *reinterpret_cast<const double2 *>(q.u + row0 + 2);
     }
-    if (q.flags) { // the chain workgroup publishes a panel's moves and then chain_done = panel + 1
-        if (threadIdx.x == 0) *s_ok = wait_ge(q.flags, HB_FLAG_CHAIN_DONE, (unsigned)q.p1) ? 1 : 0;
-        __syncthreads();
-        if (!*s_ok) return;
-    }
-    // Round 4: the whole group in FOUR dependent memory round trips — the flag above; the bound and the panels' move counts together;
-    // the move lists of all panels of the group at once; the genotype columns of up to 16 moves at a time — instead of two per panel with
-    // moves (list, then columns: ~10 trips for a group of seven panels with a move each, ~2 us apiece beside the streaming tiles; the
-    // update blocks lived 20 us and, on the matrix-core mat-vec, ended 8 us after the launch's last tile — profiles/r04_launch_roles_*).
+    // Round 4: THE DATA IS THE FLAG, and the whole group takes three dependent memory round trips — (1) the panels' move counts and the
+    // bound, polled directly: the sweep pre-fills both with a pattern no value has (count -1, bound ffff...), every word lands whole, so
+    // a word is either that pattern (look again) or final; (2) the move lists of all panels of the group at once, their entries
+    // pre-filled and validated the same way; (3) the genotype columns of up to 32 moves at a time — instead of chain_done first, then the
+    // bound, then the counts, then per panel with moves its list and its columns (~10 trips of 2-3 us each beside the streaming tiles:
+    // the update blocks of a BayesR launch lived 19 us against 7 for its tiles, profiles/r04_launch_roles_*).
     // The moves are applied in the same order (panel, then position in its list): the same sums bit for bit.
     int fixE = 0;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     int total = 0;
     int nevs[8]; // a group has at most 8 panels
     {
-        const double mbv = q.rq ? ld_sc1(q.mbv) : 0.0; // (every thread the same word: one broadcast load per wave, in flight with the counts)
+        double mbv = 0.0;
+        const bool poll = q.flags != nullptr;
+#if HB_UPD_FLAG_FIRST
+        // (A/B: one lane waits for chain_done first — ONE polled word for all update blocks — and the counts and the bound are then read
+        // once, validated like below: a trip more, but the lines the chain stores its counts and bounds to are not polled)
+        if (poll) {
+            if (threadIdx.x == 0) *s_ok = wait_ge(q.flags, HB_FLAG_CHAIN_DONE, (unsigned)q.p1) ? 1 : 0;
+            __syncthreads();
+            if (!*s_ok) return;
+        }
+#endif
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned looks = 0;; looks++) {
+            if (q.rq) mbv = ld_sc1(q.mbv); // (every thread the same word: one broadcast load per wave, in flight with the counts)
 #pragma unroll
-        for (int i = 0; i < 8; i++) nevs[i] = ld_sc1(q.ev_count + (size_t)min(q.p0 + i, q.p1 - 1) * HB_EVS);
+            for (int i = 0; i < 8; i++) nevs[i] = ld_sc1(q.ev_count + (size_t)min(q.p0 + i, q.p1 - 1) * HB_EVS);
+            if (!poll) break; // (the per-panel kernels: a kernel boundary separates this from the chain)
+            bool bad = q.rq && __double_as_longlong(mbv) == -1ll;
+#pragma unroll
+            for (int i = 0; i < 8; i++) bad |= nevs[i] < 0;
+            if (!bad) break; // (wave-uniform: every lane read the same words)
+            if (ld_flag(q.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
+                if (threadIdx.x == 0) {
+                    st_flag(q.flags + HB_FLAG_ABORT, 1u);
+                    st_flag(q.flags + 8, (unsigned)q.p1); // (diagnostics: who gave up, hb_ctx.hip fetch_acc)
+                    if ((blk & 31) == 0) hb_abort_log(q.flags, HB_LOG_WAIT_GE, wall_clock64() - t0 > HB_TIMEOUT_TICKS, (unsigned)q.p0, (unsigned)q.p1, 0ull);
+                }
+                return;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
         if (q.rq) { // (uniform) exponent of the new version, the same number in every workgroup
             fixE = hb_fix_exp(mbv);
             if (blk == 0 && threadIdx.x == 0) *q.vexp_out = fixE;
         }
     }
+    if (ust) tB = tC = tD = wall_clock64();
     int off[9];
     off[0] = 0;
 #pragma unroll
@@ -389,13 +422,28 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
 #pragma unroll
             for (int k = 0; k < 8; k++) oi = (i == k) ? off[k] : oi;
             const size_t src = (size_t)(q.p0 + i) * q.P + (size_t)(ge - oi);
-            s_ix[e] = (q.p0 + i) * q.P + ld_sc1(q.ev_idx + src); // the move's COLUMN
-            s_dl[e] = ld_sc1(q.ev_delta + src);
+            int ix = ld_sc1(q.ev_idx + src);
+            double dl = ld_sc1(q.ev_delta + src);
+            if (q.flags) { // (an entry whose count is already visible may itself still be on its way: pre-filled like the counts)
+                const unsigned long long t1 = wall_clock64();
+                while (ix < 0 || __double_as_longlong(dl) == -1ll) {
+                    if (ld_flag(q.flags + HB_FLAG_ABORT) || wall_clock64() - t1 > HB_TIMEOUT_TICKS) { st_flag(q.flags + HB_FLAG_ABORT, 1u); ix = 0; dl = 0.0; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    ix = ld_sc1(q.ev_idx + src);
+                    dl = ld_sc1(q.ev_delta + src);
+                }
+            }
+            s_ix[e] = (q.p0 + i) * q.P + ix; // the move's COLUMN
+            s_dl[e] = dl;
         }
         __syncthreads();
+        if (ust && base == 0) tC = tD = wall_clock64();
         if (!mine) continue;
-        constexpr int UB = 16; // columns in flight per thread: a panel of BayesR's ~47 moves is three trips
-        for (int e = 0; e < cnt; e += UB) {
+        // columns in flight per thread: 32 where a panel has many moves (BayesR's ~50: two trips), 8 where a group has a handful (the
+        // point-mass models in the stationary regime: padding a batch of 32 with repeats of the last column cost 100 conversions and
+        // fp64 multiply-adds per row for nothing, beside tiles that keep the vector unit busy — 11 us of a block's 18, r04_launch_roles_*)
+        auto batch = [&](auto UBC, int e) {
+            constexpr int UB = decltype(UBC)::value;
             int w[UB];
 #pragma unroll
             for (int k = 0; k < UB; k++) w[k] = hb_ld4(q.X, ld, q.X2, q.ld2w, (int64_t)s_ix[min(e + k, cnt - 1)], row0);
@@ -407,8 +455,12 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
                 a2 = fma((double)(int8_t)(w[k] >> 16), d, a2);
                 a3 = fma((double)(int8_t)(w[k] >> 24), d, a3);
             }
-        }
+        };
+        int e = 0;
+        for (; cnt - e > 8; e += 32) batch(std::integral_constant<int, 32>(), e);
+        if (e < cnt) batch(std::integral_constant<int, 8>(), e);
     }
+    if (ust) { asm volatile("" : "+v"(a0), "+v"(a1)); tD = wall_clock64(); }
     if (!mine || (total == 0 && q.r_in == q.r)) return;
     r01.x -= a0; r01.y -= a1; r23.x -= a2; r23.y -= a3;
     *reinterpret_cast<double2 *>(q.r + row0) = r01;
@@ -419,6 +471,11 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
         u01.x += a0; u01.y += a1; u23.x += a2; u23.y += a3;
         *reinterpret_cast<double2 *>(q.u + row0) = u01;
         *reinterpret_cast<double2 *>(q.u + row0 + 2) = u23;
+    }
+    if (ust && blk == 64 && threadIdx.x == 0) {
+        const unsigned long long tE = wall_clock64();
+        auto c16 = [](unsigned long long d) { return d > 65535ull ? 65535ull : d; };
+        *ust = c16(tB - tA) | (c16(tC - tB) << 16) | (c16(tD - tC) << 32) | (c16(tE - tD) << 48);
     }
 }
 
@@ -731,7 +788,7 @@ struct dq_view {
 // (diagnostics of a pipeline time-out: when did each mat-vec launch start and end — fetch_acc prints the launches around the stall)
 __device__ __forceinline__ void hb_ldiag_note(unsigned long long *ld, unsigned long long t0)
 {
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0 || (blockIdx.x & 31) != 0) return; // (every 32nd block: ~50 atomics per launch on two words perturb nothing)
     if (blockIdx.x == 0) __hip_atomic_store(&ld[0], t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_max(&ld[1], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&ld[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -784,7 +841,7 @@ __device__ __forceinline__ void dotq_block(const dq_view &v, const upd_view &uq,
     if (b < v.nupd) { // residual update of an earlier group: 256 rows per block (64 where every marker moves), lists staged in the (unused) tile buffers
         if (uq.dense) update_rows_dense(v.ld, uq, b, v.nupd, smem); // (launched with HBU_LDS bytes of dynamic LDS)
         else update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048),
-                         reinterpret_cast<int *>(smem + 2048 + 4096));
+                         reinterpret_cast<int *>(smem + 2048 + 4096), v.ldiag ? v.ldiag + 3 : nullptr);
         return;
     }
     b -= v.nupd;
@@ -863,12 +920,19 @@ __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, un
                                                     int np, unsigned long long *__restrict__ dsum, int m_pad, int p_lo,
                                                     unsigned long long *__restrict__ fcorr, unsigned long long *__restrict__ dd,
                                                     unsigned long long *__restrict__ mbs, int mb_lo, int mb_hi,
-                                                    unsigned long long *__restrict__ fc2)
+                                                    unsigned long long *__restrict__ fc2, int32_t *__restrict__ ev_idx,
+                                                    unsigned long long *__restrict__ ev_delta, int P)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (acc && i < HB_ACC_N) acc[i] = 0.0; // (null: a later range of the same sweep keeps the sums)
     if (i < HB_NFLAGS && (acc || i != HB_FLAG_ABORT)) flags[i] = 0u; // (a later range keeps an abort raised by an earlier one)
-    for (int k = p_lo + i; k < np; k += stride) ev_count[(size_t)k * HB_EVS] = 0; // (panels of this range on: an earlier range's move lists stay readable)
+    // move counts and list entries of the panels of this range on: "not written yet" (the update rows poll them directly; an earlier
+    // range's move lists stay readable)
+    for (int k = p_lo + i; k < np; k += stride) ev_count[(size_t)k * HB_EVS] = -1;
+    for (size_t k = (size_t)p_lo * P + i; k < (size_t)np * P; k += stride) {
+        ev_idx[k] = -1;
+        ev_delta[k] = ~0ull;
+    }
     for (int k = i; k < m_pad; k += stride) dsum[k] = ~0ull;
     if (fcorr)
         for (int k = i; k < m_pad; k += stride) fcorr[k] = ~0ull;
@@ -2276,6 +2340,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         } else {
             cacc[0] += active ? 1 : 0; // a quiet panel: nothing moved, nothing to write
         }
+        if (wave == S - 1 && lane == 0 && nev == 0) st_sc1(&v.ev_count[(size_t)p * HB_EVS], 0); // (the update rows poll the count itself: a panel without moves says so)
         HB_STAMP(8);
         if (wave == S - 1 && group_end) {
             // last panel of its mat-vec group: the update of this group is waiting for exactly these moves, and the
@@ -3335,8 +3400,9 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
                        reinterpret_cast<unsigned long long *>(c->dsum), c->m_pad, pb,
                        (c->fwd_group || dense) ? reinterpret_cast<unsigned long long *>(c->fcorr) : nullptr,
                        dense ? reinterpret_cast<unsigned long long *>(c->ddense) : nullptr,
-                       (dense && c->precise == 2) ? reinterpret_cast<unsigned long long *>(c->mb) : nullptr, 1 + pb / c->D, c->npanels + 2,
-                       dense ? reinterpret_cast<unsigned long long *>(c->fcorr2) : nullptr);
+                       c->precise == 2 ? reinterpret_cast<unsigned long long *>(c->mb) : nullptr, 1 + pb / c->D, c->npanels + 2,
+                       dense ? reinterpret_cast<unsigned long long *>(c->fcorr2) : nullptr, c->ev_idx,
+                       reinterpret_cast<unsigned long long *>(c->ev_delta), c->P);
     const bool fx = c->precise == 2;
     if (fx) {
         HB_HIP(hipEventRecord(c->ev_dot[0], sA));
@@ -3409,7 +3475,11 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_persist launch: ") + hipGetErrorString(e));
         return HB_OK;
     };
-    if (alone) HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->flags + HB_FLAG_CHAIN_DONE), 0x7ffffff0, 1, sA));
+    if (alone) { // (the update rows poll the move counts themselves: "no moves" for every panel)
+        HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->flags + HB_FLAG_CHAIN_DONE), 0x7ffffff0, 1, sA));
+        HB_HIP(hipMemsetAsync(c->ev_count, 0, sizeof(int32_t) * (size_t)c->npanels * HB_EVS, sA));
+        if (fx) HB_HIP(hipMemsetAsync(c->mb + HB_MBS, 0, sizeof(double) * ((size_t)c->npanels + 1) * HB_MBS, sA));
+    }
     else {
         if (int rc = launch_the_chain(sB)) return rc;
         // (the first mat-vec launch starts when the chain is resident; HB_GATE=0 / 1 overrides: by default only where a launch's

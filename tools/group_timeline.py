@@ -1,7 +1,7 @@
 """Where k_chain_group's time goes: cycle stamps per mat-vec group for one sweep in the stationary regime.
    tools/build_variant.sh stamps "-DHB_STAMPS=1"; python tools/group_timeline.py [model] [burn] [n m]"""
 import os, sys, ctypes as ct
-_v = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hibayes_amd", "variants", "stamps.so")
+_v = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "variants", "stamps.so")
 if "HIBAYES_GPU_LIB" not in os.environ and os.path.exists(_v):
     os.environ["HIBAYES_GPU_LIB"] = _v
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -9,14 +9,16 @@ import bench as B
 
 bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 Lv = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+MODEL = os.environ.get("HB_ROLES_MODEL", "BayesCpi")   # BayesR: one panel per launch, int8 columns (python tools/launch_roles.py 8 2)
+D = 1 if MODEL == "BayesR" else 7
 n, m = 50000, 500000
 L = H.lib()
 L.hb_ctx_debug_launch_stamps.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]
 from hibayes_amd._lib import BayesArgs, check
 with H.Context(n, m, seed=20240901) as c:
     c.generate(20240901, 1000)
-    y = B.synth_phenotype(c, n, m, 0, m, 20240901, None, "BayesCpi")
-    c.set_pipeline(1, Lv, 7)
+    y = B.synth_phenotype(c, n, m, 0, m, 20240901, None, MODEL)
+    c.set_pipeline(1, Lv, D)
     c.build_gram()
     c.set_adaptive(True)
     if bits == 2:
@@ -24,8 +26,11 @@ with H.Context(n, m, seed=20240901) as c:
     a = BayesArgs()
     a.n, a.m = n, m
     yv = np.ascontiguousarray(y); a.y = yv.ctypes.data
-    a.model = b"BayesCpi"
-    pv = np.array([0.95, 0.05]); a.Pi, a.n_pi = pv.ctypes.data, pv.size
+    a.model = MODEL.encode()
+    Pi_, fold_ = B.prior(MODEL)
+    pv = np.array(Pi_); a.Pi, a.n_pi = pv.ctypes.data, pv.size
+    if fold_ is not None:
+        fv = np.array(fold_, dtype=float); a.fold, a.n_fold = fv.ctypes.data, fv.size
     a.niter, a.nburn, a.thin = 340, 0, 5
     a.seed, a.precise, a.ctx = 20240901, 2, c.h
     run = ct.c_void_p(); check(L.hb_run_create(ct.byref(a), ct.byref(run)))
@@ -36,16 +41,16 @@ with H.Context(n, m, seed=20240901) as c:
     s = {"n_events": -1}
     st = c.matvec_stamps()
     npan = (m + c.panel - 1) // c.panel
-    ng = (npan + 6) // 7
+    ng = (npan + D - 1) // D
     nupd = (n + 255) // 256
-    nfin = 7 * c.panel // 64
+    nfin = D * c.panel // 64
     buf = np.zeros(2 * 4608, dtype=np.uint64)
     nb = ct.c_int()
     rows = []
     for g in range(ng):
         H._lib.check(L.hb_ctx_debug_launch_stamps(c.h, g, buf.ctypes.data, 4608, ct.byref(nb)))
         k = nb.value
-        if k < nupd + nfin + 100:
+        if k < nupd + nfin + 100 or g < 4:
             continue
         a = buf[:2 * k].reshape(k, 2).astype(np.int64)
         ok = a[:, 0] > 0
@@ -56,7 +61,7 @@ with H.Context(n, m, seed=20240901) as c:
     r = np.array(rows, dtype=np.float64)
     gap = r[1:, 0] - r[:-1, 7]
     us = 1e-2  # 100 MHz ticks -> us
-    print("bits %d, (Lv, D) = (%d, 7): %d full launches, %.2f us each in situ, moves per sweep %d" % (bits, Lv, len(r), st["avg_ms"] * 1e3, s["n_events"]))
+    print("%s, " % MODEL + "bits %d, (Lv, D) = (%d, %d): %d full launches, %.2f us each in situ, moves per sweep %d" % (bits, Lv, D, len(r), st["avg_ms"] * 1e3, s["n_events"]))
     print("  update rows: last one ends %.2f us after the launch's first block starts (a block lives %.2f us)" % (r[:, 1].mean() * us, r[:, 2].mean() * us))
     print("  finalize blocks: last one ends at %.2f us" % (r[:, 3].mean() * us))
     print("  tiles: last one STARTS at %.2f us, half of them have ended at %.2f us, last one ends at %.2f us (a tile lives %.2f us)" % (
@@ -64,3 +69,12 @@ with H.Context(n, m, seed=20240901) as c:
     print("  launch ends at %.2f us; gap to the next launch's first block %.2f us (p90 %.2f)" % ((r[:, 7] - r[:, 0]).mean() * us, gap.mean() * us, np.percentile(gap, 90) * us))
     late = r[:, 1] > r[:, 4]
     print("  launches whose update rows end after their last tile: %d of %d (by %.2f us on average)" % (late.sum(), len(r), ((r[late, 1] - r[late, 4]).mean() * us) if late.any() else 0))
+    if os.environ.get("HB_DEBUG_ABORT"):
+        L.hb_ctx_debug_ldiag.argtypes = [ct.c_void_p, ct.c_void_p]
+        ld = np.zeros((npan + 2) * 4, dtype=np.uint64)
+        H._lib.check(L.hb_ctx_debug_ldiag(c.h, ld.ctypes.data))
+        w = ld.reshape(-1, 4)[4:ng - 2, 3]
+        w = w[w != 0]
+        ph = np.stack([(w >> np.uint64(16 * k)) & np.uint64(0xffff) for k in range(4)], axis=1).astype(np.float64) * us
+        print("  update block 64 of each launch, phases in us (mean / p90): poll counts+bound %.2f / %.2f | move lists %.2f / %.2f | columns+sums %.2f / %.2f | stores %.2f / %.2f" % (
+            ph[:, 0].mean(), np.percentile(ph[:, 0], 90), ph[:, 1].mean(), np.percentile(ph[:, 1], 90), ph[:, 2].mean(), np.percentile(ph[:, 2], 90), ph[:, 3].mean(), np.percentile(ph[:, 3], 90)))
