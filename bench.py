@@ -437,7 +437,7 @@ def main():
             dist.init_process_group(backend=args.backend)
         from hibayes_amd.dist import TorchComm, RcclComm
         comm = TorchComm(device=torch.device("cuda", local_rank))
-        comm.rccl, comm.rccl_note = None, "torch.distributed all_reduce through the library's callback"
+        comm.rccl, comm.rccl_note = None, "torch.distributed all_reduce (%s) over %d ranks through the library's callback" % (args.backend, world)
         if args.collective == "rccl" and args.backend == "nccl":
             # the library's own communicator; torch.distributed only ships rank 0's RCCL id. ncclCommInitRank is a blocking
             # collective: it runs in a helper thread with a deadline, so that a bootstrap that never completes on this node

@@ -2282,7 +2282,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     absd += fabs(ev_del[e]);
                 }
                 if (lane == 0) st_sc1(&v.ev_count[(size_t)p * HB_EVS], nev);
-                if (v.mb) mbr = fma(v.xabs, wave_sum(absd), mbr);
+                if (v.mb) {
+                    mbr = fma(v.xabs, wave_sum(absd), mbr);
+                    // (the group's bound goes out WITH its last panel's moves — the update rows poll it — not after the results and the
+                    // forward fold at the panel's end: ~11 000 cycles earlier, profiles/r04_bayesr_chain_phases.txt)
+                    if (group_end && lane == 0) st_sc1(&v.mb[(size_t)(1 + gcount) * HB_MBS], mbr);
+                }
             }
             HB_STAMP(4);
             if (!active) { cls_f = 0; g_f = 0.0; }
@@ -2340,13 +2345,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         } else {
             cacc[0] += active ? 1 : 0; // a quiet panel: nothing moved, nothing to write
         }
-        if (wave == S - 1 && lane == 0 && nev == 0) st_sc1(&v.ev_count[(size_t)p * HB_EVS], 0); // (the update rows poll the count itself: a panel without moves says so)
+        if (wave == S - 1 && lane == 0 && nev == 0) { // (the update rows poll the count itself: a panel without moves says so — and the bound, unchanged)
+            st_sc1(&v.ev_count[(size_t)p * HB_EVS], 0);
+            if (group_end && v.mb) st_sc1(&v.mb[(size_t)(1 + gcount) * HB_MBS], mbr);
+        }
         HB_STAMP(8);
         if (wave == S - 1 && group_end) {
             // last panel of its mat-vec group: the update of this group is waiting for exactly these moves, and the
             // next panel's take may itself have to wait for a later launch — publish now rather than at that take
-            if (lane == 0 && v.mb) st_sc1(&v.mb[(size_t)(1 + gcount) * HB_MBS], mbr);
-            gcount++;
+            gcount++; // (its bound went out with the moves of its last panel)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(p + 1));
         }
