@@ -30,6 +30,9 @@
 #ifndef Q2_SCALED
 #define Q2_SCALED 1
 #endif
+#ifndef Q2_AHEAD
+#define Q2_AHEAD 2 /* chunks the digit reads run ahead of the dot4 that use them: two since round 4 (a ring of three register sets, the stage fully unrolled: 24.2 against 25.7 us per launch isolated, 22.6 against 23.2 in situ); 1 = the round-3 loop */
+#endif
 
 // RS: individuals per stage (512 or 256). A 1-KiB DMA piece holds 4096 / RS columns x RS individuals of the tile, or 1024 / RS
 // digit planes x RS individuals.
@@ -93,6 +96,34 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
         // software-pipelined by hand: the seven digit reads of chunk ch + 1 (and the column's next 16 bytes) are issued BEFORE
         // the 28 dot4 of chunk ch — a wave parks 78 % of its cycles otherwise (rocprofv3 SQ_WAIT_ANY), every chunk waiting out
         // its own LDS round trip behind the other waves' reads
+#if Q2_AHEAD == 2
+        // (the digit reads TWO chunks ahead of the dot4 that use them, a ring of three register sets, the stage fully unrolled)
+        hb_v4i dr[3][HB_ND], xq[CPL], xqn[CPL];
+#pragma unroll
+        for (int k = 0; k < HB_ND; k++) dr[0][k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS);
+#pragma unroll
+        for (int k = 0; k < HB_ND; k++) dr[1][k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS + 16);
+#pragma unroll
+        for (int c = 0; c < CPL; c++) xqn[c] = px[c][0];
+#pragma unroll
+        for (int ch = 0; ch < RS / 16; ch++) {
+            const int w = ch & 3;
+            if (w == 0) {
+#pragma unroll
+                for (int c = 0; c < CPL; c++) xq[c] = xqn[c];
+            }
+            const int chn = min(ch + 2, RS / 16 - 1);
+#pragma unroll
+            for (int k = 0; k < HB_ND; k++) dr[(ch + 2) % 3][k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS + chn * 16);
+            if (w == 2) {
+#pragma unroll
+                for (int c = 0; c < CPL; c++) xqn[c] = px[c][min((ch >> 2) + 1, RS / 64 - 1)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            hb_v4i d[HB_ND];
+#pragma unroll
+            for (int k = 0; k < HB_ND; k++) d[k] = dr[ch % 3][k];
+#else
         hb_v4i dn[HB_ND], xq[CPL], xqn[CPL];
 #pragma unroll
         for (int k = 0; k < HB_ND; k++) dn[k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS);
@@ -115,6 +146,7 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
 #pragma unroll
                 for (int c = 0; c < CPL; c++) xqn[c] = px[c][min((ch >> 2) + 1, RS / 64 - 1)];
             }
+#endif
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
                 const unsigned xw = (unsigned)(w == 0 ? xq[c].x : w == 1 ? xq[c].y : w == 2 ? xq[c].z : xq[c].w);
