@@ -41,6 +41,7 @@ if os.environ.get("STAMPS"):
     a = st[5:-2]
     print("fine: 0->1 take %d, 1->7 issue+barrier %d, 7->2 rounds %d, 2->3 ticket %d, 3->6 results+fwd+landing %d; moves/panel %.2f; waited-for-matvec frac %.3f" % (
         (a[:, 1] - a[:, 0]).mean(), (a[:, 7] - a[:, 1]).mean(), (a[:, 2] - a[:, 7]).mean(), (a[:, 3] - a[:, 2]).mean(), (a[:, 6] - a[:, 3]).mean(), a[:, 10].mean(), a[:, 11].mean()))
+    print("  candidates at the opening %.1f per panel, rounds %.2f, repeats of a speculated block %.2f per panel" % (a[:, 15].mean(), a[:, 16].mean(), a[:, 17].mean()))
     nm = a[:, 10]
     for label, one in (("1-move", nm == 1), ("16+-move", nm >= 16)):
       if one.sum():
