@@ -164,6 +164,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
         auto mk = [&](hipStream_t *st) { return prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, phi) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
         if (mk(&c->s_chain) != hipSuccess ||
             mk(&c->s_upd) != hipSuccess ||
+            mk(&c->s_warm) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) {
             hb_ctx_destroy(c);
             return hb_fail(HB_ERR_HIP, "hipStreamCreate failed");
@@ -281,6 +282,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
+    if (c->s_warm) (void)hipStreamDestroy(c->s_warm);
     if (c->s_dbg) (void)hipStreamDestroy(c->s_dbg);
     void *ptrs[] = {c->X, c->X2, c->xpx, c->vx, c->s1, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->fcorr, c->ddense, c->fcorr2, c->dots, c->ev_count, c->ev_idx,

@@ -65,6 +65,7 @@ struct hb_ctx {
     hipStream_t stream = nullptr;      // mat-vec stream (and everything outside the sweep)
     hipStream_t s_chain = nullptr;     // serial chain kernels
     hipStream_t s_upd = nullptr;       // residual updates
+    hipStream_t s_warm = nullptr;      // k_warm where k_fwd has s_upd (BayesR)
     std::vector<hipEvent_t> ev_dot, ev_chain, ev_upd; // cross-stream dependencies of one sweep
     hipEvent_t ev_fork = nullptr;
 

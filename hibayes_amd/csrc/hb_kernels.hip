@@ -1448,6 +1448,24 @@ struct persist_view {
 #define HB_NPF 1 /* candidates per panel whose band rows are requested ahead (1 or 2) */
 #endif
 #define HB_CROWD 8 /* candidates in a round from which their Gram entries are gathered up front */
+#ifndef HB_R_EARLY
+#define HB_R_EARLY 1 /* with k_fwd beside the chain: the next panel's dots and k_fwd's sums are (re-)requested right after a panel's rounds */
+#endif
+#ifndef HB_R_FOLDPRE
+#define HB_R_FOLDPRE 1 /* ... and the band rows of its first 32 moves before the publish, used after the results */
+#endif
+#ifndef HB_ROW_TRI
+#define HB_ROW_TRI 1 /* panel 512: the row cache keeps a row of the panel's second half as its second 1-KiB piece alone (k_hotlist) */
+#endif
+#ifndef HB_APPLY_LEAN
+#define HB_APPLY_LEAN 1 /* a crowded round's moves are applied from 16-byte records read with one broadcast LDS load (0: the round-3 loop) */
+#endif
+#ifndef HB_SPEC_B
+#define HB_SPEC_B 16 /* steps per speculated block */
+#endif
+#ifndef HB_R_SPEC
+#define HB_R_SPEC 1 /* crowded rounds of a mixture model: the serial pass in blocks of eight steps on speculated classes */
+#endif
 #ifndef HB_SERIAL_BRANCHLESS
 #define HB_SERIAL_BRANCHLESS 1
 #endif
@@ -1497,10 +1515,38 @@ __global__ __launch_bounds__(512) void k_hotlist(const hb_sweep_in *__restrict__
         tot += c;
     }
     const int raw = sbase + __popcll(hmask & ((1ull << lane) - 1ull));
-    const int slot = (hot && raw < nslot) ? raw : -1;
+    // Where a listed row sits in the chain's row cache, in units of 64 ints: base64 * 64 + column. Row k is only ever used at
+    // columns > k (a move touches later markers), so at panel 512 — two 1-KiB pieces per row — a row of the panel's second half is
+    // kept as its second piece alone: the cache holds a third more rows in the same LDS (HB_ROW_TRI). The list is in marker order,
+    // so the whole rows (n2 of them) come first; a half row's base points 256 columns before its piece (shifted by one piece when
+    // there is no whole row before it, so that no base is negative). [0] = rows that fit, [1] = rows listed, [2] = whole rows among
+    // those that fit, [3] = that shift, in pieces.
+    const bool tri = HB_ROW_TRI && P == 512;
+    int n2 = tot;
+    if (tri) {
+        n2 = 0;
+        for (int w = 0; w < S / 2; w++) n2 += wcnt[w];
+    }
+    const int U = max(P >> 6, 1), Uh = U >> 1, cap64 = nslot * U;
+    const int shift = (tri && n2 == 0) ? Uh : 0;
+    const int off64 = raw < n2 ? raw * U : n2 * U + (raw - n2) * Uh + shift;
+    const int len64 = raw < n2 ? U : Uh;
+    const bool fits = hot && off64 + len64 <= cap64;
+    const int slot = fits ? (raw < n2 ? off64 : off64 - Uh) : -1;
     slot_of[j] = active ? slot : -2; // -2: monomorphic marker, skipped by the chain
-    if (slot >= 0) hotpack[(size_t)p * HB_HS + 4 + slot] = t;
-    if (t == 0) hotpack[(size_t)p * HB_HS] = min(tot, nslot);
+    // (the list goes on past the rows that got a slot, up to the 252 entries a piece holds: k_warm pulls those rows into the chain's
+    // L2 as well — a candidate without a slot then costs the chain an L2 hit instead of a trip to memory)
+    if (hot && raw < HB_HS - 4) hotpack[(size_t)p * HB_HS + 4 + raw] = t;
+    if (t == 0) {
+        int count;
+        if (n2 * U >= cap64) count = cap64 / U;
+        else count = n2 + (tri ? min(tot - n2, max(0, (cap64 - n2 * U - shift) / Uh)) : 0);
+        count = min(count, HB_HS - 4);
+        hotpack[(size_t)p * HB_HS] = count;
+        hotpack[(size_t)p * HB_HS + 1] = min(tot, HB_HS - 4);
+        hotpack[(size_t)p * HB_HS + 2] = min(n2, count);
+        hotpack[(size_t)p * HB_HS + 3] = shift ? 1 : 0;
+    }
 }
 
 // Forward corrections of one batch shape: FW moves x up to LB band blocks, all loads in flight together.
@@ -1618,6 +1664,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // chain itself folds a panel's moves into the NEXT panel only (half of the band rows of a dense sweep leave its compute unit)
     const bool fwd = pv.fcorr != nullptr;
     double *fcring = reinterpret_cast<double *>(oring + (size_t)4 * (((((size_t)12 * P + 1023) >> 10) << 10) + 1024));
+    // one crowded round's moves as the apply reads them (HB_APPLY_LEAN): {byte offset of the row in the row cache, marker, change}
+    // for the moves whose row is cached — 64 + 8 records, the list is padded with changes of zero — and {-, marker, change} for the others
+    int4 *ap_rec = reinterpret_cast<int4 *>(fcring + (size_t)2 * P);
+    int4 *ms_rec = ap_rec + 72;
     int pslot = -1; // p mod R
     double wacc = 0.0;
     int cacc[K1 + 1];
@@ -1707,12 +1757,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {   // the row cache for the first panel
         const int *hl0 = pv.hotpack + (size_t)pv.p0 * HB_HS;
         n_nhot = hl0[0];
-        const int total = n_nhot << lgP, items = (total + 255) >> 8;
         const int32_t *gp0 = v.gram + (size_t)pv.p0 * (pv.Lg + 1) * P * P;
-        for (int it = wave; it < items; it += S) {
-            const int lin = min((it << 8) + lane * 4, total - 4);
-            const int k = hl0[4 + (lin >> lgP)];
-            *reinterpret_cast<int4 *>(rowc0 + lin) = *reinterpret_cast<const int4 *>(gp0 + ((size_t)k << lgP) + (lin & (P - 1)));
+        if (HB_ROW_TRI && P == 512) { // (the layout k_hotlist describes: whole rows first, then second pieces alone)
+            const int n2s = hl0[2], sh = hl0[3], items = n_nhot + n2s;
+            for (int it = wave; it < items; it += S) {
+                const int r = it < 2 * n2s ? it >> 1 : it - n2s, pc = it < 2 * n2s ? (it & 1) << 8 : 256;
+                const int k = hl0[4 + r];
+                *reinterpret_cast<int4 *>(rowc0 + ((it + sh) << 8) + lane * 4) = *reinterpret_cast<const int4 *>(gp0 + ((size_t)k << lgP) + pc + lane * 4);
+            }
+        } else {
+            const int total = n_nhot << lgP, items = (total + 255) >> 8;
+            for (int it = wave; it < items; it += S) {
+                const int lin = min((it << 8) + lane * 4, total - 4);
+                const int k = hl0[4 + (lin >> lgP)];
+                *reinterpret_cast<int4 *>(rowc0 + lin) = *reinterpret_cast<const int4 *>(gp0 + ((size_t)k << lgP) + (lin & (P - 1)));
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1743,12 +1802,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         }
         // ---- take over the panel: LDS only ----
+        const bool use_fc = fwd && p >= pv.p0 + 2; // (the first two panels of a range have nobody two panels before them)
+        // (k_fwd's sums — and, HB_R_EARLY, a second copy of the panel's dots — were brought in by the ring waves during the previous
+        // panel, after its barrier — their producers need the panels before — so unlike the ring groups no earlier barrier has handed
+        // them to the other waves yet: one extra barrier per panel, a few hundred cycles)
+        if (HB_R_EARLY ? fwd : use_fc) __syncthreads();
         double dj = reinterpret_cast<const double *>(oslotp)[t];
         const float fthr = reinterpret_cast<const float *>(oslotp + 8 * P)[t];
-        const bool use_fc = fwd && p >= pv.p0 + 2; // (the first two panels of a range have nobody two panels before them)
-        // (k_fwd's sums were brought in by the ring waves only one panel ahead — their producer needs the panel before — so unlike the
-        // ring groups no earlier barrier has handed them to the other waves yet: one extra barrier per panel, a few hundred cycles)
-        if (use_fc) __syncthreads();
         double fcv = use_fc ? fcring[(size_t)(p & 1) * P + t] : 0.0;
         bool aborted = false;
         {
@@ -1843,6 +1903,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int cls_f = 0;
         double g_f = 0.0;
         int nev = 0;
+#if HB_STAMPS
+        int nrerun = 0, nround = 0;
+        HB_STAMP_VAL(15, tot0);
+#endif
         int pre[2][NPL > 0 ? NPL : 1];
         if (tot0 > 0) {
             // the exact per-marker data, for the candidates only (one CU pulls ~18 bytes per clock from memory — measured,
@@ -1930,7 +1994,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const double dk = rg - cgold;
                 double rhs_new = rhs;
                 if (dk != 0.0) { // uniform
-                    int gv = rowc[max(cslot, 0) * P + t];
+                    int gv = rowc[(max(cslot, 0) << 6) + t];
                     if (cslot < 0) gv = gp[(size_t)c1 * P + t];
                     if (t > c1) rhs_new = fma(-(double)gv, dk, rhs);
                     if (t == c1) { ev_ix[0] = (cslot << 16) | c1; ev_del[0] = dk; }
@@ -1990,6 +2054,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
                 if (tot == 0) break; // nobody left can move
+#if HB_STAMPS
+                nround++;
+#endif
                 const int rank = basec + __popcll(cm & ((1ull << lane) - 1ull));
                 const bool inr = isc && rank < 64;
                 const int ncr = min(tot, 64);
@@ -2024,7 +2091,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         gval[u8] = 0;
                         if (idx < ncr * 64 && k < c && c < ncr) {
                             const int sk = cs_slot[k];
-                            gval[u8] = rowc[max(sk, 0) * P + cs_t[c]];
+                            gval[u8] = rowc[(max(sk, 0) << 6) + cs_t[c]];
                             if (sk < 0) gval[u8] = gp[(size_t)cs_t[k] * P + cs_t[c]];
                         }
                     }
@@ -2035,6 +2102,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
                 if (crowded) __syncthreads(); // (uniform)
+                if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(18);
                 if (wave == 0) {
                     // The exact serial chain over the round's candidates, one per lane in marker order: step k asks whether
                     // lane k moves given everything before it (certain movers always do), broadcasts its change and applies
@@ -2106,6 +2174,60 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                 gnx = (double)r1;
                                 r1 = r2;
                             }
+                        } else if (HB_R_SPEC && K1 > 1) {
+                            // A mixture model (BayesR: ~60 candidates in a panel, half of them certain movers): a step of the exact
+                            // loop below is ~25 dependent instructions, because the class of lane k has to be decided from the rhs
+                            // the step before it left. But within a class the new effect is LINEAR in rhs, and a lane's class
+                            // rarely changes over the few steps before its own. So: HB_SPEC_B steps at a time on the classes every lane
+                            // has NOW (a step is then: one fused multiply-add, the change, its broadcast, one fused multiply-add
+                            // per lane), then the classes of the block's lanes are read off their final rhs — nobody touches a
+                            // lane's rhs after its own step — and compared with what was assumed. All equal: every step computed
+                            // exactly what the exact loop computes (same operands, same operations). One differs: back to the rhs
+                            // saved at the block's start and again with the classes just read — the lanes before the first
+                            // mismatch were exact and stay so, the mismatching lane now has its exact class, so every repeat
+                            // fixes at least one more lane (at most HB_SPEC_B repeats; 0.01 per panel measured).
+                            auto classify = [&](double rhsv, int &cls, double &a, double &b) {
+                                const double q = rhsv * rhsv;
+                                cls = 0; a = 0.0; b = 0.0;
+#pragma unroll
+                                for (int c = 0; c < K1; c++) {
+                                    const bool ge = q >= cthr[c];
+                                    cls += ge ? 1 : 0;
+                                    a = ge ? cinvv[c] : a;
+                                    b = ge ? csdz[c] : b;
+                                }
+                            };
+                            int cls_s;
+                            double a_s, b_s;
+                            classify(crhs, cls_s, a_s, b_s);
+                            constexpr int SB = K1 > 3 ? 8 : HB_SPEC_B; // (steps per block)
+                            for (int k0 = 0; k0 < ncr; k0 += SB) {
+                                double grow[SB];
+#pragma unroll
+                                for (int u = 0; u < SB; u++) grow[u] = (double)cg[min(k0 + u, ncr - 1) * 64 + lane];
+                                const double save = crhs;
+                                const bool inblk = lv && lane >= k0 && lane < k0 + SB;
+                                for (;;) {
+#pragma unroll
+                                    for (int u = 0; u < SB; u++) {
+                                        if (k0 + u < ncr) { // uniform
+                                            const double gn = fma(crhs, a_s, b_s); // (class 0: +0, the exact loop's 0.0)
+                                            const double dk = readlane_f64(gn - cgold, k0 + u);
+                                            crhs = fma(-grow[u], dk, crhs);
+                                        }
+                                    }
+                                    int cls2;
+                                    double a2, b2;
+                                    classify(crhs, cls2, a2, b2);
+                                    const bool mis = inblk && cls2 != cls_s;
+                                    cls_s = cls2; a_s = a2; b_s = b2; // (the block's lanes become exact from the front; the later lanes get a fresher guess)
+                                    if (!__any(mis)) break;
+#if HB_STAMPS
+                                    nrerun++;
+#endif
+                                    crhs = save;
+                                }
+                            }
                         } else
                         for (int k = 0; k < ncr; k++) {
                             const double gcur = gnx;
@@ -2155,7 +2277,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                 asm volatile("" : "+v"(gv)); // (keeps the three loads apart)
                             } else {
                                 const int sk = __builtin_amdgcn_readlane(cslot, k);
-                                gv = rowc[max(sk, 0) * P + ct];                                                // always: LDS
+                                gv = rowc[(max(sk, 0) << 6) + ct];                                                // always: LDS
                                 asm volatile("" : "+v"(gv));
                                 if (sk < 0) {
                                     gv = gp[(size_t)__builtin_amdgcn_readlane(ct, k) * P + ct];               // a miss: global
@@ -2185,6 +2307,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         res_c[lane] = rc;
                         res_g[lane] = rg;
                         if (lane == 0) cnts[0] = nev0 + __popcll(moved);
+                        if (HB_APPLY_LEAN && crowded) { // (the same moves once more, as the other waves' apply wants them)
+                            const unsigned long long mvs = moved & ~noslot, mvm = moved & noslot, below = (1ull << lane) - 1ull;
+                            const long long db = __double_as_longlong(dmine);
+                            if (lv && dmine != 0.0) {
+                                if (cslot >= 0) ap_rec[__popcll(mvs & below)] = make_int4(cslot << 8, ct, (int)db, (int)(db >> 32));
+                                else ms_rec[__popcll(mvm & below)] = make_int4(0, ct, (int)db, (int)(db >> 32));
+                            }
+                            const int nsr = __popcll(mvs);
+                            if (lane < 8) ap_rec[nsr + lane] = make_int4(0, 0x7fffffff, 0, 0);
+                            if (lane == 0) { cnts[2] = nsr; cnts[3] = __popcll(mvm); }
+                        }
                     }
                 }
                 if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(13);
@@ -2202,7 +2335,64 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     nap = nev0 + __popcll(__ballot(kl < ((t | 63))));
                 }
 #endif
-                if (undec && !inr) {
+                const bool doap = undec && !inr;
+                if (HB_APPLY_LEAN && crowded) {
+                    // A crowded round (BayesR: ~50 moves): the apply used to be the longest phase of the panel — eight waves, two
+                    // per SIMD, each issuing ~15 instructions per move (the move's record handed round by v_readlane, a scalar row
+                    // address, the test for a row outside the cache, the select for "this marker comes later") at ~13 cycles an
+                    // instruction: 10 600 cycles of 52 000 (profiles/r04_bayesr_chain_phases.txt). Here the serial pass leaves
+                    // the round's moves as 16-byte records {row's byte offset in the cache, marker, change} that every lane reads
+                    // with ONE broadcast LDS load; a move of a marker before the wave's first needs no select at all, so a move
+                    // costs five instructions (record, address, Gram entry, conversion, fused multiply-add). The few moves whose
+                    // row is not cached come afterwards, their global loads in flight together. (The moves are summed in a
+                    // different order than the per-panel kernel sums them: the same chain up to the rounding of rhs, which
+                    // every comparison in tests/ already allows for.)
+                    const int nsr = cnts[2], nmr = cnts[3];
+                    if (__any(doap)) {
+                        const int kl = lane < nsr ? ap_rec[lane].y : 0x7fffffff;
+                        const int nap_s = __popcll(__ballot(kl < (t | 63)));
+                        const int nfull = __popcll(__ballot(kl < (t & ~63))) & ~7;
+                        double acc = rhs;
+                        for (int e0 = 0; e0 < nfull; e0 += 8) {
+                            int4 rc[8];
+                            int gv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) rc[q] = ap_rec[e0 + q];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) gv[q] = reinterpret_cast<const int *>(smem + rc[q].x)[t];
+#pragma unroll
+                            for (int q = 0; q < 8; q++)
+                                acc = fma(-(double)gv[q], __longlong_as_double(((long long)rc[q].w << 32) | (unsigned)rc[q].z), acc);
+                        }
+                        for (int e0 = nfull; e0 < nap_s; e0 += 8) { // (the wave's own stretch of the panel; the list is padded with eight changes of zero)
+                            int4 rc[8];
+                            int gv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) rc[q] = ap_rec[e0 + q];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) gv[q] = reinterpret_cast<const int *>(smem + rc[q].x)[t];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                const double nw = fma(-(double)gv[q], __longlong_as_double(((long long)rc[q].w << 32) | (unsigned)rc[q].z), acc);
+                                acc = rc[q].y < t ? nw : acc;
+                            }
+                        }
+                        for (int e0 = 0; e0 < nmr; e0 += 8) { // moves whose row is not in the cache
+                            int4 rc[8];
+                            int gv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) rc[q] = ms_rec[min(e0 + q, nmr - 1)];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) gv[q] = gp[(size_t)__builtin_amdgcn_readfirstlane(rc[q].y) * P + t];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                const double nw = fma(-(double)gv[q], __longlong_as_double(((long long)rc[q].w << 32) | (unsigned)rc[q].z), acc);
+                                acc = (e0 + q < nmr && rc[q].y < t) ? nw : acc;
+                            }
+                        }
+                        if (doap) rhs_new = acc;
+                    }
+                } else if (doap) {
                     for (int e0 = nev0; e0 < nap; e0 += 8) {
                         int rec[8], gv[8];
                         double dl[8];
@@ -2216,7 +2406,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         for (int q8 = 0; q8 < 8; q8++) {
                             const int slot = __builtin_amdgcn_readfirstlane(rec[q8] >> 16);
                             const int k = __builtin_amdgcn_readfirstlane(rec[q8] & 0xffff);
-                            gv[q8] = rowc[max(slot, 0) * P + t];
+                            gv[q8] = rowc[(max(slot, 0) << 6) + t];
                             if (slot < 0) gv[q8] = gp[(size_t)k * P + t];
                         }
 #pragma unroll
@@ -2238,6 +2428,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int w = 0; w < 8; w++) anyv |= w8[w] != 0;
                 }
+                if (t_lo == 0 && nev0 == 0 && !forced) HB_STAMP(19);
                 if (anyv) { // roll the round back; the markers that crossed their threshold join the candidates
                     forced |= viol;
                     if (t == 0) cnts[0] = nev0;
@@ -2268,6 +2459,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         HB_STAMP(2);
         HB_STAMP_VAL(10, nev);
+#if HB_STAMPS
+        HB_STAMP_VAL(16, nround);
+        HB_STAMP_VAL(17, nrerun);
+#endif
+        // ---- with k_fwd beside the chain: what the NEXT panel's take needs from other workgroups is requested here, a results-and-
+        // fold's length ahead of that take, instead of as the last thing of the panel (a round trip the take then waited out) and
+        // three panels ahead (its dots: the ring's copy predates the launch that finalizes them at every panel, and the take's
+        // re-read was a second round trip). One 1-KiB piece of each per ring wave (P = 512); a word not written yet shows the
+        // sentinel the sweep filled dsum[] / fcorr[] with and is polled at the take as before. The pieces are older than anything
+        // the rest of the panel issues, so the counted wait at the top of the next panel covers them.
+        if (HB_R_EARLY && fwd && wave < RW && have_next) {
+            const unsigned wo = (unsigned)__builtin_amdgcn_readfirstlane(wave) << 10;
+            const int nslot_o = (oslot + 1 == HB_RD) ? 0 : oslot + 1;
+            dma_piece_s(reinterpret_cast<const char *>(v.dsum + (size_t)(p + 1) * P) + wo, oring_lds + (unsigned)nslot_o * OSLOT + wo, true);
+            if (p + 1 >= pv.p0 + 2)
+                dma_piece_s(reinterpret_cast<const char *>(pv.fcorr + (size_t)(p + 1) * P) + wo,
+                            (unsigned)(uintptr_t)fcring + (unsigned)(((p + 1) & 1) * P * 8) + wo, true);
+        }
+        // (... and the band rows the panel's first 32 moves fold into the next panel: the loads fly while the moves are published and the
+        // results written, instead of starting after them)
+        int fgv[32];
+        const bool fpre = HB_R_FOLDPRE && K1 <= 3 && fwd && nev > 0 && have_next; // (K1 = 7 has no registers to spare)
+        if (fpre) {
+            const int ixl = (lane < nev && lane < 32) ? (ev_ix[lane] & 0xffff) : 0;
+            const int32_t *blk1 = v.gram + ((size_t)(p + 1) * (pv.Lg + 1) + 1) * ((size_t)P * P) + t;
+#pragma unroll
+            for (int f = 0; f < 16; f++) fgv[f] = blk1[(size_t)__builtin_amdgcn_readlane(ixl, f) * P];
+            if (nev > 16) {
+#pragma unroll
+                for (int f = 16; f < 32; f++) fgv[f] = blk1[(size_t)__builtin_amdgcn_readlane(ixl, f) * P];
+            }
+        }
         HB_STAMP(3);
         if (tot0 > 0) {
             // ---- publish the panel's moves (the update of this group waits for them). Only the last wave does it,
@@ -2317,7 +2540,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 w1 = e1 == c1 ? 0 : (HB_NPF > 1 && e1 == c2 ? 1 : -1);
                 from_pre = w0 >= 0 && w1 >= 0;
             }
-            if (from_pre) {
+            if (fpre) { // (k_fwd beside the chain: the next panel only; the rows were requested before the publish; the same fused multiply-adds in the same order as fold_forward's)
+                const double dll = (lane < nev && lane < 32) ? ev_del[lane] : 0.0;
+                const int slot = (pslot + 1 == R) ? 0 : pslot + 1;
+                double *cp = corrL + (size_t)slot * P + t;
+                double acc = *cp;
+#pragma unroll
+                for (int f = 0; f < 16; f++) acc = fma((double)fgv[f], readlane_f64(dll, f), acc);
+                if (nev > 16) {
+#pragma unroll
+                    for (int f = 16; f < 32; f++) acc = fma((double)fgv[f], readlane_f64(dll, f), acc);
+                }
+                *cp = acc;
+                if (nev > 32) fold_forward<1, 32>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev - 32, ev_ix + 32, ev_del + 32, p);
+            } else if (from_pre) {
                 const double d0 = ev_del[0], d1 = nev > 1 ? ev_del[1] : 0.0;
                 int slot = pslot;
 #pragma unroll
@@ -2365,7 +2601,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // (k_fwd's sums for the NEXT panel first — one 1-KiB piece per ring wave, P = 512 — so that the counted wait at the top of the
         // next panel, which lets the youngest ring group stay in flight, covers them; a word k_fwd has not written yet shows the
         // sentinel the sweep filled fcorr[] with and is polled at the take)
-        if (fwd && wave < RW && have_next && p + 1 >= pv.p0 + 2)
+        if (!HB_R_EARLY && fwd && wave < RW && have_next && p + 1 >= pv.p0 + 2)
             dma_piece_s(reinterpret_cast<const char *>(pv.fcorr + (size_t)(p + 1) * P) + (__builtin_amdgcn_readfirstlane(wave) << 10),
                         (unsigned)(uintptr_t)fcring + (unsigned)(((p + 1) & 1) * P * 8) + ((unsigned)__builtin_amdgcn_readfirstlane(wave) << 10), true);
         if (wave < RW && p + HB_RD - 1 < np) issue_group(p + HB_RD - 1, (oslot + HB_RD - 1) % HB_RD);
@@ -2375,7 +2611,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // then holds ring groups only, which is what makes its counted wait at the top of the panel exact.)
         const int *hpk = reinterpret_cast<const int *>(oslotp + OSZ); // packed list of panel p + 1 (came with group p)
         if (have_next) n_nhot = hpk[0];
-        const int n_total = n_nhot << lgP, n_items = (n_total + 255) >> 8;
+        const bool tri = HB_ROW_TRI && P == 512;
+        const int n2s = tri ? __builtin_amdgcn_readfirstlane(hpk[2]) : 0, shp = tri ? __builtin_amdgcn_readfirstlane(hpk[3]) : 0;
+        const int n_total = n_nhot << lgP, n_items = tri ? n_nhot + n2s : (n_total + 255) >> 8;
         if (have_next && (S == 1 || wave >= RW)) {
             const unsigned rown_lds = (unsigned)(uintptr_t)rown;
             const int w0 = S == 1 ? 0 : wave - RW, ws = S == 1 ? 1 : S - RW;
@@ -2383,9 +2621,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int w0u = __builtin_amdgcn_readfirstlane(w0);
                 const int lg = lgP - 8; // pieces per row = P / 256
                 for (int it = w0u; it < n_items; it += ws) {
-                    const int kk = __builtin_amdgcn_readfirstlane(hpk[4 + (it >> lg)]);
-                    const int32_t *srow = gpn + ((size_t)kk << lgP) + ((it & ((1 << lg) - 1)) << 8);
-                    dma_piece_s(reinterpret_cast<const char *>(srow), rown_lds + ((unsigned)it << 10), false);
+                    // (panel 512: whole rows first, then the second pieces of the rows of the panel's second half — k_hotlist)
+                    const int r = tri ? (it < 2 * n2s ? it >> 1 : it - n2s) : it >> lg;
+                    const int pc = tri ? (it < 2 * n2s ? (it & 1) << 8 : 256) : (it & ((1 << lg) - 1)) << 8; // first column of the piece
+                    const int kk = __builtin_amdgcn_readfirstlane(hpk[4 + r]);
+                    const int32_t *srow = gpn + ((size_t)kk << lgP) + pc;
+                    dma_piece_s(reinterpret_cast<const char *>(srow), rown_lds + ((unsigned)(it + shp) << 10), false);
                 }
             } else
             for (int it = w0; it < n_items; it += ws) {
@@ -2518,7 +2759,7 @@ __global__ __launch_bounds__(256) void k_warm(persist_view pv, chain_view v, int
             for (int i = t * 4; i < P; i += 1024) acc += reinterpret_cast<const int4 *>(pv.slot_of + j0 + i)->x;
         }
         const int *hl = pv.hotpack + (size_t)q * HB_HS;
-        const int cnt = hl[0];
+        const int cnt = max(hl[0], hl[1]); // (with and without a slot in the row cache)
         const int lmax = min(Lb, np - 1 - q);
         const int nitem = cnt * (1 + lmax);
         const int32_t *gp = gram + (size_t)q * (Lg + 1) * PP;
@@ -2943,7 +3184,7 @@ static int chain_nslot(int P) { return (int)((158 * 1024 - ((size_t)P * 16 + 128
 #define HB_PERSIST_RING(P) ((size_t)4 * ((((size_t)12 * (P) + 1023) >> 10 << 10) + 1024)) /* HB_RD slots of the opening ring */
 // move lists (12 B per marker) + reduction / counter words + one round's candidate staging (sized by the model's K1 non-null classes)
 // + the 64 x 64 block of mutual Gram entries + the correction ring + the opening ring; the rest is the double-buffered row cache
-#define HB_PERSIST_FIXED(P, LB, K1) ((size_t)(P) * 12 + 128 + 512 + 64 * (8 * (3 + 3 * (K1)) + 12) + 64 * 64 * 4 + (size_t)((LB) + 1) * (P) * 8 + HB_PERSIST_RING(P) + (size_t)2 * (P) * 8 /* k_fwd's sums, two panels */)
+#define HB_PERSIST_FIXED(P, LB, K1) ((size_t)(P) * 12 + 128 + 512 + 64 * (8 * (3 + 3 * (K1)) + 12) + 64 * 64 * 4 + (size_t)((LB) + 1) * (P) * 8 + HB_PERSIST_RING(P) + (size_t)2 * (P) * 8 /* k_fwd's sums, two panels */ + (72 + 64) * 16 /* a round's moves as the apply reads them */)
 static int persist_nslot(int P, int Lb, int K1) { return std::min(P, std::min(250, (int)((160 * 1024 - HB_PERSIST_FIXED(P, Lb, K1)) / ((size_t)P * 4)))); }
 // the whole 160 KiB: nothing that needs LDS (mat-vec, update) can then be co-scheduled on the chain's CU
 static size_t persist_smem(int) { return (size_t)160 * 1024; }
@@ -3499,6 +3740,14 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     int warm = 4;
     if (const char *e = getenv("HB_WARM")) warm = std::max(0, std::min(16, atoi(e)));
     if (alone || (group_chain && !c->warm_group) || fwd || dense || fwd_persist) warm = 0; // (k_fwd has the third stream)
+    // BayesR with k_fwd beside the chain: the warmers on a stream of their own (HB_WARM_R: workgroups per XCD, 0 = off). They read
+    // the Gram rows of EVERY marker on a panel's hot list, with or without a slot in the chain's row cache, and the rows their
+    // moves fold into the next panel (the chain's share of the band)
+    int warm_r = 0;
+    if (fwd_persist && c->s_warm) {
+        warm_r = 4;
+        if (const char *e = getenv("HB_WARM_R")) warm_r = std::max(0, std::min(16, atoi(e)));
+    }
     if (dense) { // (Lb + 1 target panels are open at any time: Lb ahead for their band, the chain's own for its far sub-blocks)
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         hipLaunchKernelGGL(k_fold_dense, dim3(8 * (c->L + 1)), dim3(256), 0, c->s_upd, cv, pv, c->ddense, c->fcorr2, c->L + 1);
@@ -3533,6 +3782,15 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         int ahead = D + 4;
         if (const char *e = getenv("HB_WARM_AHEAD")) ahead = std::max(1, atoi(e));
         hipLaunchKernelGGL(k_warm, dim3(8 * warm), dim3(256), 0, c->s_upd, pv, cv, kp, c->gram, c->P, ahead, warm, reinterpret_cast<int *>(c->flags + 48));
+        HB_HIP(hipGetLastError());
+    }
+    if (warm_r) {
+        HB_HIP(hipStreamWaitEvent(c->s_warm, c->ev_fork, 0));
+        int ahead = 4;
+        if (const char *e = getenv("HB_WARM_AHEAD")) ahead = std::max(1, atoi(e));
+        persist_view pw = pv;
+        pw.Lb = 1; // (the chain folds into the next panel only)
+        hipLaunchKernelGGL(k_warm, dim3(8 * warm_r), dim3(256), 0, c->s_warm, pw, cv, kp, c->gram, c->P, ahead, warm_r, reinterpret_cast<int *>(c->flags + 48));
         HB_HIP(hipGetLastError());
     }
     const bool inject = c->inject_abort_panel >= 0 && c->s_dbg && !alone;
@@ -3581,6 +3839,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     if (warm || fwd || dense || warm_dense || fwd_persist) {
         HB_HIP(hipEventRecord(c->ev_upd[0], c->s_upd));
         HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[0], 0));
+    }
+    if (warm_r) {
+        HB_HIP(hipEventRecord(c->ev_chain[1 % c->npanels], c->s_warm));
+        HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[1 % c->npanels], 0));
     }
     if (inject) {
         HB_HIP(hipEventRecord(c->ev_dot[0], c->s_dbg));

@@ -42,6 +42,11 @@ if os.environ.get("STAMPS"):
     print("fine: 0->1 take %d, 1->7 issue+barrier %d, 7->2 rounds %d, 2->3 ticket %d, 3->6 results+fwd+landing %d; moves/panel %.2f; waited-for-matvec frac %.3f" % (
         (a[:, 1] - a[:, 0]).mean(), (a[:, 7] - a[:, 1]).mean(), (a[:, 2] - a[:, 7]).mean(), (a[:, 3] - a[:, 2]).mean(), (a[:, 6] - a[:, 3]).mean(), a[:, 10].mean(), a[:, 11].mean()))
     print("  candidates at the opening %.1f per panel, rounds %.2f, repeats of a speculated block %.2f per panel" % (a[:, 15].mean(), a[:, 16].mean(), a[:, 17].mean()))
+    cr = a[:, 15] >= 8
+    if cr.sum():
+        o = a[cr]
+        print("  first round of crowded panels: staged->gathered %d | serial pass %d | barrier+apply %d | violation barrier %d | rest of the rounds %d" % (
+            (o[:,18]-o[:,12]).mean(), (o[:,13]-o[:,18]).mean(), (o[:,14]-o[:,13]).mean(), (o[:,19]-o[:,14]).mean(), (o[:,2]-o[:,19]).mean()))
     nm = a[:, 10]
     for label, one in (("1-move", nm == 1), ("16+-move", nm >= 16)):
       if one.sum():
