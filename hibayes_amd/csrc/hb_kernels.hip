@@ -1457,6 +1457,9 @@ struct persist_view {
 #ifndef HB_ROW_TRI
 #define HB_ROW_TRI 1 /* panel 512: the row cache keeps a row of the panel's second half as its second 1-KiB piece alone (k_hotlist) */
 #endif
+#ifndef HB_FILL_ALL
+#define HB_FILL_ALL 1 /* the ring waves issue their share of the row cache's pieces too (0: the four non-ring waves alone) */
+#endif
 #ifndef HB_APPLY_LEAN
 #define HB_APPLY_LEAN 1 /* a crowded round's moves are applied from 16-byte records read with one broadcast LDS load (0: the round-3 loop) */
 #endif
@@ -1742,6 +1745,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     const int my_pieces = __builtin_amdgcn_readfirstlane(wave < RW ? (NPC - wave + RW - 1) / RW : 0); // ring pieces this wave issues per group
+    int my_rowp = 0; // row-cache pieces this (ring) wave issued behind its last ring group
     int n_nhot = 0;
 
     // ---- prologue ----
@@ -1794,19 +1798,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ring waves: the group of panel p + 1 has landed once at most the youngest group (panel p + 2's) is still in flight;
         // the barrier below hands it to everybody before the next panel's take
         if (wave < RW) {
-            if (S == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a 64-marker panel: the same wave also fills the row cache)
-            else if (fwd && p + HB_RD - 2 >= np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (no group was issued behind this panel's fcorr piece: it is the youngest)
-            else if (my_pieces == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else if (my_pieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            // (what may stay in flight: the youngest ring group — none was issued behind the previous panel near the end of the range —
+            // and, HB_FILL_ALL, the row-cache pieces this wave issued behind it: the counter wants an immediate, hence the ladder)
+            const int keep = (S == 1) ? 0 : ((p + HB_RD - 2 < np || p == pv.p0) ? my_pieces : 0) + my_rowp;
+            switch (min(keep, 31)) {
+#define HB_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+                HB_VMC(0) HB_VMC(1) HB_VMC(2) HB_VMC(3) HB_VMC(4) HB_VMC(5) HB_VMC(6) HB_VMC(7) HB_VMC(8) HB_VMC(9) HB_VMC(10) HB_VMC(11)
+                HB_VMC(12) HB_VMC(13) HB_VMC(14) HB_VMC(15) HB_VMC(16) HB_VMC(17) HB_VMC(18) HB_VMC(19) HB_VMC(20) HB_VMC(21) HB_VMC(22)
+                HB_VMC(23) HB_VMC(24) HB_VMC(25) HB_VMC(26) HB_VMC(27) HB_VMC(28) HB_VMC(29) HB_VMC(30) HB_VMC(31)
+#undef HB_VMC
+            }
         }
         // ---- take over the panel: LDS only ----
         const bool use_fc = fwd && p >= pv.p0 + 2; // (the first two panels of a range have nobody two panels before them)
         // (k_fwd's sums — and, HB_R_EARLY, a second copy of the panel's dots — were brought in by the ring waves during the previous
         // panel, after its barrier — their producers need the panels before — so unlike the ring groups no earlier barrier has handed
         // them to the other waves yet: one extra barrier per panel, a few hundred cycles)
+        HB_STAMP(20);
+#if HB_STAMPS
+        if (v.dbg && lane == 0 && wave < 8) v.dbg[(size_t)p * 32 + 22 + wave] = clock64(); // (each wave's arrival at the barrier)
+#endif
         if (HB_R_EARLY ? fwd : use_fc) __syncthreads();
+        HB_STAMP(21);
         double dj = reinterpret_cast<const double *>(oslotp)[t];
         const float fthr = reinterpret_cast<const float *>(oslotp + 8 * P)[t];
         double fcv = use_fc ? fcring[(size_t)(p & 1) * P + t] : 0.0;
@@ -2590,7 +2603,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // last panel of its mat-vec group: the update of this group is waiting for exactly these moves, and the
             // next panel's take may itself have to wait for a later launch — publish now rather than at that take
             gcount++; // (its bound went out with the moves of its last panel)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (no drain before the flag any more, as in k_chain_group: every consumer of the counts, the bound and the move lists
+            // validates the words themselves, and chain_done only paces k_fwd and k_warm. Waiting here for the acknowledgement of
+            // this wave's write-through stores held the whole workgroup at the next panel's first barrier for ~9 300 cycles —
+            // a fifth of a BayesR panel, profiles/r04_bayesr_chain_phases.txt)
             if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(p + 1));
         }
         HB_STAMP(9);
@@ -2614,19 +2630,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool tri = HB_ROW_TRI && P == 512;
         const int n2s = tri ? __builtin_amdgcn_readfirstlane(hpk[2]) : 0, shp = tri ? __builtin_amdgcn_readfirstlane(hpk[3]) : 0;
         const int n_total = n_nhot << lgP, n_items = tri ? n_nhot + n2s : (n_total + 255) >> 8;
-        if (have_next && (S == 1 || wave >= RW)) {
+        // (HB_FILL_ALL, panels of 256 and more: every wave issues its share — the four non-ring waves alone took ~8 000 cycles over
+        // the ~80 pieces of a BayesR panel while the ring waves stood at the next panel's barrier; a ring wave's pieces go out behind
+        // its ring group and its counted wait at the top of the next panel leaves them in flight too)
+        const bool fill_all = HB_FILL_ALL && P >= 256 && S > 1;
+        my_rowp = 0;
+        if (have_next && (S == 1 || wave >= RW || fill_all)) {
             const unsigned rown_lds = (unsigned)(uintptr_t)rown;
-            const int w0 = S == 1 ? 0 : wave - RW, ws = S == 1 ? 1 : S - RW;
+            const int w0 = S == 1 ? 0 : fill_all ? wave : wave - RW, ws = S == 1 ? 1 : fill_all ? S : S - RW;
             if (P >= 256) { // a piece is (part of) ONE row: scalar base, invariant lane offset
                 const int w0u = __builtin_amdgcn_readfirstlane(w0);
                 const int lg = lgP - 8; // pieces per row = P / 256
-                for (int it = w0u; it < n_items; it += ws) {
+                // (the list's markers in two registers, handed out with v_readlane: an LDS read and its wait per piece made this loop —
+                // ~20 pieces per wave, on the path to the next panel's opening barrier — several thousand cycles long)
+                const int ids0 = hpk[4 + lane], ids1 = hpk[4 + 64 + lane];
+                const int n_it = __builtin_amdgcn_readfirstlane(n_items);
+                const unsigned long long gpn_s = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(uintptr_t)gpn >> 32)) << 32) |
+                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)(uintptr_t)gpn);
+                for (int it = w0u; it < n_it; it += ws) {
                     // (panel 512: whole rows first, then the second pieces of the rows of the panel's second half — k_hotlist)
                     const int r = tri ? (it < 2 * n2s ? it >> 1 : it - n2s) : it >> lg;
                     const int pc = tri ? (it < 2 * n2s ? (it & 1) << 8 : 256) : (it & ((1 << lg) - 1)) << 8; // first column of the piece
-                    const int kk = __builtin_amdgcn_readfirstlane(hpk[4 + r]);
-                    const int32_t *srow = gpn + ((size_t)kk << lgP) + pc;
-                    dma_piece_s(reinterpret_cast<const char *>(srow), rown_lds + ((unsigned)(it + shp) << 10), false);
+                    const int kk = r < 64 ? __builtin_amdgcn_readlane(ids0, r) : __builtin_amdgcn_readlane(ids1, r - 64);
+                    const unsigned long long src = gpn_s + ((((unsigned long long)(unsigned)kk << lgP) + (unsigned)pc) << 2);
+                    const unsigned dst = rown_lds + ((unsigned)(it + shp) << 10);
+                    my_rowp++;
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(dst) : "memory"); // (m0 is not restored: hipcc keeps nothing in it in this kernel — no other use in its ISA — and every piece sets it)
                 }
             } else
             for (int it = w0; it < n_items; it += ws) {
@@ -3605,7 +3634,7 @@ static hipError_t launch_chain_persist(hb_ctx *c, const chain_view &cv, const pe
         if (pv.Lb == 1) return launch_chain_persist2<1, 1>(c, cv, pv, st);
         return launch_chain_persist2<1, 0>(c, cv, pv, st);
     }
-    if (pv.Lb == 2) return launch_chain_persist2<K1 == 1 ? 3 : K1, 2>(c, cv, pv, st);
+    if (pv.Lb == 2 && !pv.fcorr) return launch_chain_persist2<K1 == 1 ? 3 : K1, 2>(c, cv, pv, st); // (with k_fwd beside it the chain requests its fold rows itself, after the rounds)
     return launch_chain_persist2<K1, 0>(c, cv, pv, st);
 }
 
@@ -3786,7 +3815,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     }
     if (warm_r) {
         HB_HIP(hipStreamWaitEvent(c->s_warm, c->ev_fork, 0));
-        int ahead = 4;
+        int ahead = 2; // (measured, BayesR at n = 50k, m = 500k: off 48.3 sweeps/s, 2 panels ahead 51.2, 4 ahead 50.5, 8 ahead 50.0)
         if (const char *e = getenv("HB_WARM_AHEAD")) ahead = std::max(1, atoi(e));
         persist_view pw = pv;
         pw.Lb = 1; // (the chain folds into the next panel only)

@@ -42,6 +42,8 @@ if os.environ.get("STAMPS"):
     print("fine: 0->1 take %d, 1->7 issue+barrier %d, 7->2 rounds %d, 2->3 ticket %d, 3->6 results+fwd+landing %d; moves/panel %.2f; waited-for-matvec frac %.3f" % (
         (a[:, 1] - a[:, 0]).mean(), (a[:, 7] - a[:, 1]).mean(), (a[:, 2] - a[:, 7]).mean(), (a[:, 3] - a[:, 2]).mean(), (a[:, 6] - a[:, 3]).mean(), a[:, 10].mean(), a[:, 11].mean()))
     print("  candidates at the opening %.1f per panel, rounds %.2f, repeats of a speculated block %.2f per panel" % (a[:, 15].mean(), a[:, 16].mean(), a[:, 17].mean()))
+    print("  take: ring waves' counted wait %d | barrier that hands over the early pieces %d | reads, sentinel check, filter %d" % ((a[:,20]-a[:,0]).mean(), (a[:,21]-a[:,20]).mean(), (a[:,1]-a[:,21]).mean()))
+    print("  arrival of waves 0..7 at that barrier, cycles after wave 0's loop top:", [int((a[:, 22 + w] - a[:, 0]).mean()) for w in range(8)])
     cr = a[:, 15] >= 8
     if cr.sum():
         o = a[cr]

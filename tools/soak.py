@@ -49,6 +49,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "dense":  # the models in which every ma
             print("  FAILED %s n=%d m=%d: %s" % (model, n, m, e), flush=True)
     print("dense soak: %d of %d runs failed; %d sweeps completed, %d of them replayed after a device time-out" % (nfail, len(cases), ntot, nrep), flush=True)
     sys.exit(1 if nfail else 0)
+elif len(sys.argv) > 1 and sys.argv[1] == "bayesr":  # soak.py bayesr [sweeps]: config 3's model on its own (k_chain_persist + k_fwd + k_warm)
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
+    rep = run(50000, 500000, "BayesR", k, min(500, k // 2))
+    print("BayesR soak: %d sweeps completed, %d of them replayed after a device time-out" % (k, rep), flush=True)
 else:
     run(10000, 100000, "BayesCpi", 5000, 2500)
     run(50000, 500000, "BayesCpi", 3000, 1500)
