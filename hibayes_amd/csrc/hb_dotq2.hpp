@@ -96,13 +96,13 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
         // software-pipelined by hand: the seven digit reads of chunk ch + 1 (and the column's next 16 bytes) are issued BEFORE
         // the 28 dot4 of chunk ch — a wave parks 78 % of its cycles otherwise (rocprofv3 SQ_WAIT_ANY), every chunk waiting out
         // its own LDS round trip behind the other waves' reads
-#if Q2_AHEAD == 2
-        // (the digit reads TWO chunks ahead of the dot4 that use them, a ring of three register sets, the stage fully unrolled)
-        hb_v4i dr[3][HB_ND], xq[CPL], xqn[CPL];
+#if Q2_AHEAD >= 2
+        // (the digit reads Q2_AHEAD chunks ahead of the dot4 that use them, a ring of Q2_AHEAD + 1 register sets, the stage fully unrolled)
+        hb_v4i dr[Q2_AHEAD + 1][HB_ND], xq[CPL], xqn[CPL];
 #pragma unroll
-        for (int k = 0; k < HB_ND; k++) dr[0][k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS);
+        for (int a = 0; a < Q2_AHEAD; a++)
 #pragma unroll
-        for (int k = 0; k < HB_ND; k++) dr[1][k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS + 16);
+            for (int k = 0; k < HB_ND; k++) dr[a][k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS + a * 16);
 #pragma unroll
         for (int c = 0; c < CPL; c++) xqn[c] = px[c][0];
 #pragma unroll
@@ -112,9 +112,9 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
 #pragma unroll
                 for (int c = 0; c < CPL; c++) xq[c] = xqn[c];
             }
-            const int chn = min(ch + 2, RS / 16 - 1);
+            const int chn = min(ch + Q2_AHEAD, RS / 16 - 1);
 #pragma unroll
-            for (int k = 0; k < HB_ND; k++) dr[(ch + 2) % 3][k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS + chn * 16);
+            for (int k = 0; k < HB_ND; k++) dr[(ch + Q2_AHEAD) % (Q2_AHEAD + 1)][k] = *reinterpret_cast<const hb_v4i *>(pd + k * RS + chn * 16);
             if (w == 2) {
 #pragma unroll
                 for (int c = 0; c < CPL; c++) xqn[c] = px[c][min((ch >> 2) + 1, RS / 64 - 1)];
@@ -122,7 +122,7 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
             __builtin_amdgcn_sched_barrier(0);
             hb_v4i d[HB_ND];
 #pragma unroll
-            for (int k = 0; k < HB_ND; k++) d[k] = dr[ch % 3][k];
+            for (int k = 0; k < HB_ND; k++) d[k] = dr[ch % (Q2_AHEAD + 1)][k];
 #else
         hb_v4i dn[HB_ND], xq[CPL], xqn[CPL];
 #pragma unroll

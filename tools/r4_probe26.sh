@@ -1,0 +1,13 @@
+#!/bin/bash
+O=gpurun_out
+timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k two_bit 2>&1 | tail -1
+for lib in "" "$PWD/build/variants/ahead3.so"; do
+ for tiles in 2000 2300; do
+  echo "== lib=$lib tiles=$tiles"
+  HB_DOTQ2_TILES=$tiles HIBAYES_GPU_LIB=$lib HB_MV_BITS=2 timeout 300 python tools/matvec_only.py 50000 100000 2 5 2>&1 | tail -1
+  HB_DOTQ2_TILES=$tiles HIBAYES_GPU_LIB=$lib timeout 600 python bench.py --no-ab --tertiary "" --secondary "" --no-cpu 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('value', d['value'], d['roofline']['avg_launch_ms'])"
+ done
+done
+HIBAYES_GPU_LIB=$PWD/build/variants/ahead3.so timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k two_bit 2>&1 | tail -1
