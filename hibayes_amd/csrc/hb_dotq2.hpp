@@ -30,6 +30,9 @@
 #ifndef Q2_SCALED
 #define Q2_SCALED 1
 #endif
+#ifndef Q2_TWO_PER_SIMD
+#define Q2_TWO_PER_SIMD 1 /* k_dotq2 allocates 176 VGPRs so that two of its waves fit a SIMD, not three (A/B on one box, twice: 295.8 / 295.9 sweeps/s without and 2000 tiles, 300.7 / 299.2 with and 1600; with and 2000: 277 — the launch no longer fits the chip at once) */
+#endif
 #ifndef Q2_AHEAD
 #define Q2_AHEAD 2 /* chunks the digit reads run ahead of the dot4 that use them: two since round 4 (a ring of three register sets, the stage fully unrolled: 24.2 against 25.7 us per launch isolated, 22.6 against 23.2 in situ); 1 = the round-3 loop */
 #endif
@@ -189,6 +192,11 @@ template <int CPL, int RS>
 __global__ __launch_bounds__(64) void k_dotq2(dq_view v, upd_view uq)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#if Q2_TWO_PER_SIMD
+    // (a register the kernel does not need, named so that its allocation passes 170: the hardware then fits two of its waves on a SIMD,
+    // not three — a launch's tiles are VALU-bound, a SIMD with three of them ends half a tile time after one with two)
+    asm volatile("" ::: "v175");
+#endif
     unsigned long long t0 = 0;
     if (v.stamp || v.ldiag) t0 = wall_clock64();
     int b = blockIdx.x;

@@ -74,7 +74,7 @@ struct hb_ctx {
     uint32_t *X2 = nullptr;
     int64_t ld2 = 0;     // bytes per column of X2 = 128 * ceil(ld / 512)
     int layout = 8;      // 8: int8 columns, 2: 2-bit columns
-    int dotq2_cpl = 1, dotq2_tiles = 2000, dotq2_rs = 256; // (tiles: ~7 single-wave tiles per compute unit all start with the launch — 3072 left a second round of tiles that started at 12 us: 22.8 against 24.2 us per launch in situ, round 4)
+    int dotq2_cpl = 1, dotq2_tiles = 1600, dotq2_rs = 256; // (tiles per full-width k_dotq2 launch, HB_DOTQ2_TILES: 1568 of seven stages at n = 50k — with two waves per SIMD (Q2_TWO_PER_SIMD) 2048 waves are resident, and tiles + update rows + the chain's and k_fwd's compute units must fit; until that cap 2000 -> 1848 tiles of six stages: 296 against 300 sweeps/s)
     int dotq2_kind = 0, dotq2_nc = 16;    // (measured: 23.3 us per 3584-column launch for kind 0 at these defaults, 26.1 for kind 1) 1: individuals across the lanes, no LDS (k_dotq2r), NC columns per tile; 0: lane = column through LDS (k_dotq2) // k_dotq2 launch shape (HB_DOTQ2_CPL, HB_DOTQ2_TILES)
     double *xpx = nullptr, *vx = nullptr, *g = nullptr, *vargL = nullptr;
     double *s1 = nullptr; // column sums of the resident rows (k_stats), for the row-sharded mode's global statistics

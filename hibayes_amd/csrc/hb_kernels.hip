@@ -1457,6 +1457,9 @@ struct persist_view {
 #ifndef HB_ROW_TRI
 #define HB_ROW_TRI 1 /* panel 512: the row cache keeps a row of the panel's second half as its second 1-KiB piece alone (k_hotlist) */
 #endif
+#ifndef HB_FPRE_N
+#define HB_FPRE_N 64 /* band rows (moves) requested before the publish: 16, 32, 48 or 64 */
+#endif
 #ifndef HB_FILL_ALL
 #define HB_FILL_ALL 1 /* the ring waves issue their share of the row cache's pieces too (0: the four non-ring waves alone) */
 #endif
@@ -2492,16 +2495,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         // (... and the band rows the panel's first 32 moves fold into the next panel: the loads fly while the moves are published and the
         // results written, instead of starting after them)
-        int fgv[32];
+        int fgv[HB_FPRE_N];
         const bool fpre = HB_R_FOLDPRE && K1 <= 3 && fwd && nev > 0 && have_next; // (K1 = 7 has no registers to spare)
+        int fixl[HB_FPRE_N / 64 + 1];
         if (fpre) {
-            const int ixl = (lane < nev && lane < 32) ? (ev_ix[lane] & 0xffff) : 0;
             const int32_t *blk1 = v.gram + ((size_t)(p + 1) * (pv.Lg + 1) + 1) * ((size_t)P * P) + t;
 #pragma unroll
-            for (int f = 0; f < 16; f++) fgv[f] = blk1[(size_t)__builtin_amdgcn_readlane(ixl, f) * P];
-            if (nev > 16) {
+            for (int h = 0; h < (HB_FPRE_N + 63) / 64; h++) fixl[h] = (h * 64 + lane < nev) ? (ev_ix[h * 64 + lane] & 0xffff) : 0;
 #pragma unroll
-                for (int f = 16; f < 32; f++) fgv[f] = blk1[(size_t)__builtin_amdgcn_readlane(ixl, f) * P];
+            for (int f0 = 0; f0 < HB_FPRE_N; f0 += 16) {
+                if (f0 == 0 || nev > f0) { // (uniform: sixteen rows at a time, as many as the panel has moves)
+#pragma unroll
+                    for (int f = f0; f < f0 + 16; f++) fgv[f] = blk1[(size_t)__builtin_amdgcn_readlane(fixl[f >> 6], f & 63) * P];
+                }
             }
         }
         HB_STAMP(3);
@@ -2554,18 +2560,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 from_pre = w0 >= 0 && w1 >= 0;
             }
             if (fpre) { // (k_fwd beside the chain: the next panel only; the rows were requested before the publish; the same fused multiply-adds in the same order as fold_forward's)
-                const double dll = (lane < nev && lane < 32) ? ev_del[lane] : 0.0;
                 const int slot = (pslot + 1 == R) ? 0 : pslot + 1;
                 double *cp = corrL + (size_t)slot * P + t;
                 double acc = *cp;
+                double dll[HB_FPRE_N / 64 + 1];
 #pragma unroll
-                for (int f = 0; f < 16; f++) acc = fma((double)fgv[f], readlane_f64(dll, f), acc);
-                if (nev > 16) {
+                for (int h = 0; h < (HB_FPRE_N + 63) / 64; h++) dll[h] = (h * 64 + lane < nev) ? ev_del[h * 64 + lane] : 0.0;
 #pragma unroll
-                    for (int f = 16; f < 32; f++) acc = fma((double)fgv[f], readlane_f64(dll, f), acc);
+                for (int f0 = 0; f0 < HB_FPRE_N; f0 += 16) {
+                    if (f0 == 0 || nev > f0) {
+#pragma unroll
+                        for (int f = f0; f < f0 + 16; f++) acc = fma((double)fgv[f], readlane_f64(dll[f >> 6], f & 63), acc);
+                    }
                 }
                 *cp = acc;
-                if (nev > 32) fold_forward<1, 32>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev - 32, ev_ix + 32, ev_del + 32, p);
+                if (nev > HB_FPRE_N) fold_forward<1, 32>(corrL, R, v.gram, pv.Lg, lcount, pslot, P, t, nev - HB_FPRE_N, ev_ix + HB_FPRE_N, ev_del + HB_FPRE_N, p);
             } else if (from_pre) {
                 const double d0 = ev_del[0], d1 = nev > 1 ? ev_del[1] : 0.0;
                 int slot = pslot;
