@@ -204,9 +204,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 dmine = act ? sv_ : 0.0;                                                                                          \
             } else { /* :728 clamps an effect with |g| < 1e-6 to 1e-6 (common while the effects are small): decided in the loop   */ \
                 const double forced_ = 1e-6 - gold;                                                                               \
-                _Pragma("unroll") for (int k = 0; k < 64; k++) {                                                                  \
-                    const double cur_ = (act && fabs(gold + sv_) < 1e-6) ? forced_ : sv_;                                         \
-                    sv_ = fma((double)dg[k] * ninvv_, readlane_f64(cur_, k), sv_);                                                \
+                /* (round 4: the test sits on the dependent chain — add, compare, two selects before the broadcast: BayesL ran 39   */ \
+                /* sweeps/s against BayesRR's 55 — and in the stationary regime it almost never fires. So: the pass WITHOUT it      */ \
+                /* first; a marker's sv is not touched after its own step, so whether any marker of the sub-block would have been   */ \
+                /* clamped at its step can be read off the final values; if none, the pass was the exact one — same operands, same  */ \
+                /* operations; if one, again from the saved values with the test in the loop.)                                       */ \
+                const double sv0_ = sv_;                                                                                          \
+                _Pragma("unroll") for (int k = 0; k < 64; k++) sv_ = fma((double)dg[k] * ninvv_, readlane_f64(sv_, k), sv_);      \
+                if (__any(act && fabs(gold + sv_) < 1e-6)) {                                                                      \
+                    sv_ = sv0_;                                                                                                   \
+                    double ninvv2_ = ninvv_;                                                                                      \
+                    asm volatile("" : "+v"(ninvv2_)); /* (hipcc must not keep the first pass's 64 products for this one: 455 spills) */ \
+                    _Pragma("unroll") for (int k = 0; k < 64; k++) {                                                              \
+                        const double cur_ = (act && fabs(gold + sv_) < 1e-6) ? forced_ : sv_;                                     \
+                        int dgk_ = dg[k];                                                                                         \
+                        asm volatile("" : "+v"(dgk_));                                                                            \
+                        sv_ = fma((double)dgk_ * ninvv2_, readlane_f64(cur_, k), sv_);                                            \
+                    }                                                                                                             \
                 }                                                                                                                 \
                 const bool cl_ = act && fabs(gold + sv_) < 1e-6;                                                                  \
                 gn_f = act ? (cl_ ? 1e-6 : gold + sv_) : 0.0;                                                                     \
