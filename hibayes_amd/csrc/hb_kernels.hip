@@ -409,10 +409,15 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
 #pragma unroll
     for (int i = 0; i < 8; i++) off[i + 1] = off[i] + (q.p0 + i < q.p1 ? nevs[i] : 0);
     total = off[8];
-    constexpr int CH = 512; // moves staged per pass (s_ix: 512 ints, s_dl: 512 doubles)
+    constexpr int CH = 448; // moves staged per pass (s_ix: 512 ints, s_dl: 512 doubles — the 64 behind the last move hold changes of zero: a batch reads past the list without a test per move)
+    // (the group's columns from a scalar base + a 32-bit byte offset wherever the group's genotypes span less than 4 GB)
+    const int8_t *Xg = q.X ? q.X + (int64_t)q.p0 * q.P * ld : nullptr;
+    const uint32_t *X2g = q.X2 ? q.X2 + (int64_t)q.p0 * q.P * q.ld2w : nullptr;
+    const bool wide_off = (uint64_t)(q.p1 - q.p0) * q.P * (uint64_t)ld < (1ull << 32);
     for (int base = 0; base < total; base += CH) {
         const int cnt = min(CH, total - base);
         __syncthreads();
+        if (threadIdx.x < 64) s_dl[cnt + threadIdx.x] = 0.0;
         for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
             const int ge = base + e;
             int i = 0;
@@ -433,7 +438,7 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
                     dl = ld_sc1(q.ev_delta + src);
                 }
             }
-            s_ix[e] = (q.p0 + i) * q.P + ix; // the move's COLUMN
+            s_ix[e] = i * q.P + ix; // the move's COLUMN, counted from the group's first (a 32-bit byte offset from a scalar base then addresses it: one register per load in flight instead of two)
             s_dl[e] = dl;
         }
         __syncthreads();
@@ -442,14 +447,32 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
         // columns in flight per thread: 32 where a panel has many moves (BayesR's ~50: two trips), 8 where a group has a handful (the
         // point-mass models in the stationary regime: padding a batch of 32 with repeats of the last column cost 100 conversions and
         // fp64 multiply-adds per row for nothing, beside tiles that keep the vector unit busy — 11 us of a block's 18, r04_launch_roles_*)
-        auto batch = [&](auto UBC, int e) {
+        auto batch = [&](auto UBC, auto WOC, int e) {
             constexpr int UB = decltype(UBC)::value;
+            constexpr bool WO = decltype(WOC)::value; // (32-bit offsets from the group's scalar base)
             int w[UB];
+            // (which layout is decided OUTSIDE the loops: a test per load made hipcc branch per load and wait for each 2-bit word before
+            // the next was requested)
+            if (!WO) {
 #pragma unroll
-            for (int k = 0; k < UB; k++) w[k] = hb_ld4(q.X, ld, q.X2, q.ld2w, (int64_t)s_ix[min(e + k, cnt - 1)], row0);
+                for (int k = 0; k < UB; k++) w[k] = hb_ld4(q.X, ld, q.X2, q.ld2w, (int64_t)q.p0 * q.P + s_ix[min(e + k, cnt - 1)], row0);
+            } else if (q.X2) {
+                const unsigned rw = ((unsigned)row0 >> 4) * 4u, sh = ((unsigned)row0 & 12u) >> 1, ldb = (unsigned)q.ld2w * 4u;
+#pragma unroll
+                for (int k = 0; k < UB; k++)
+                    w[k] = (int)*reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(X2g) + ((unsigned)s_ix[min(e + k, cnt - 1)] * ldb + rw));
+#pragma unroll
+                for (int k = 0; k < UB; k++) w[k] = (int)(((unsigned)w[k] >> sh) & 0x03030303u);
+            } else {
+#pragma unroll
+                for (int k = 0; k < UB; k++)
+                    w[k] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(Xg) + ((unsigned)s_ix[min(e + k, cnt - 1)] * (unsigned)ld + (unsigned)row0));
+            }
+            if (UB > 32) __builtin_amdgcn_sched_barrier(0); // (all loads out before any arithmetic, and the arithmetic eight moves at a time: hipcc otherwise reads all 64 changes from LDS ahead — 231 VGPRs)
 #pragma unroll
             for (int k = 0; k < UB; k++) {
-                const double d = (e + k < cnt) ? s_dl[e + k] : 0.0;
+                if (UB > 32 && (k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                const double d = s_dl[e + k]; // (zero past the list)
                 a0 = fma((double)(int8_t)(w[k]), d, a0);
                 a1 = fma((double)(int8_t)(w[k] >> 8), d, a1);
                 a2 = fma((double)(int8_t)(w[k] >> 16), d, a2);
@@ -457,8 +480,14 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
             }
         };
         int e = 0;
-        for (; cnt - e > 8; e += 32) batch(std::integral_constant<int, 32>(), e);
-        if (e < cnt) batch(std::integral_constant<int, 8>(), e);
+        if (wide_off) {
+            for (; cnt - e > 32; e += 64) batch(std::integral_constant<int, 64>(), std::true_type(), e); // (BayesR's ~52 moves in ONE trip: the update rows of a launch are what the chain's next dots wait for)
+            for (; cnt - e > 8; e += 32) batch(std::integral_constant<int, 32>(), std::true_type(), e);
+            if (e < cnt) batch(std::integral_constant<int, 8>(), std::true_type(), e);
+        } else {
+            for (; cnt - e > 8; e += 32) batch(std::integral_constant<int, 32>(), std::false_type(), e);
+            if (e < cnt) batch(std::integral_constant<int, 8>(), std::false_type(), e);
+        }
     }
     if (ust) { asm volatile("" : "+v"(a0), "+v"(a1)); tD = wall_clock64(); }
     if (!mine || (total == 0 && q.r_in == q.r)) return;
