@@ -1486,6 +1486,9 @@ struct persist_view {
 #ifndef HB_ROW_TRI
 #define HB_ROW_TRI 1 /* panel 512: the row cache keeps a row of the panel's second half as its second 1-KiB piece alone (k_hotlist) */
 #endif
+#ifndef HB_RING_NODOTS
+#define HB_RING_NODOTS 1 /* with k_fwd beside the chain the ring does not fetch the dots three panels ahead: they are never there yet, and the line it read stayed in the XCD's L2 as the copy the early request one panel ahead then got (sentinel at 80 % of the panels; 0 % without) */
+#endif
 #ifndef HB_FPRE_N
 #define HB_FPRE_N 64 /* band rows (moves) requested before the publish: 16, 32, 48 or 64 */
 #endif
@@ -1762,6 +1765,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 dma_piece_s(hsrc, dst + (unsigned)OSZ, false);
             } else if (P >= 128) {
                 const int off = i << 10; // whole piece inside one segment
+                // (with k_fwd beside the chain the dots come with the early request one panel ahead: three panels ahead they are
+                // never there yet, and the line read now would be the copy the early request then finds in this XCD's L2)
+                if (HB_RING_NODOTS && HB_R_EARLY && fwd && off < 8 * P && x > pv.p0) continue;
                 dma_piece_s(off < 8 * P ? dsrc + off : fsrc + (off - 8 * P), dst + (unsigned)off, true);
             } else {
                 const int off = (i << 10) + lane * 16;
@@ -1776,7 +1782,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     };
-    const int my_pieces = __builtin_amdgcn_readfirstlane(wave < RW ? (NPC - wave + RW - 1) / RW : 0); // ring pieces this wave issues per group
+    int my_pieces = __builtin_amdgcn_readfirstlane(wave < RW ? (NPC - wave + RW - 1) / RW : 0); // ring pieces this wave issues per group
+    if (HB_RING_NODOTS && HB_R_EARLY && fwd && P >= 128 && wave < RW) { // (without the dots' pieces)
+        int c = 0;
+        for (int i = __builtin_amdgcn_readfirstlane(wave); i < NPC; i += RW) c += (i == NPC - 1 || (i << 10) >= 8 * P) ? 1 : 0;
+        my_pieces = c;
+    }
     int my_rowp = 0; // row-cache pieces this (ring) wave issued behind its last ring group
     int n_nhot = 0;
 

@@ -10,3 +10,4 @@ d=json.loads(open('gpurun_out/r04_bench_final.json').read().strip().splitlines()
 print('value', d['value'], 'int8', d['int8']['value'], 'mfma', d['mfma_ab']['value'], 'secondary', d['secondary']['value'], [(t['model'], round(t['value'],1)) for t in d['all_move']])
 PY
 timeout 600 python tools/soak.py bayesr 5000 > $O/r04_bayesr_soak.txt 2>&1; tail -3 $O/r04_bayesr_soak.txt
+timeout 900 python tools/soak.py dense l 3000 > $O/r04_dense_soak_l.txt 2>&1; tail -2 $O/r04_dense_soak_l.txt
