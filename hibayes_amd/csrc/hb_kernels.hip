@@ -2696,6 +2696,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int n_it = __builtin_amdgcn_readfirstlane(n_items);
                 const unsigned long long gpn_s = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(uintptr_t)gpn >> 32)) << 32) |
                                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)(uintptr_t)gpn);
+                unsigned keep_m0;
+                asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0)); // (M0 — the LDS destination — is compiler-reserved: saved once around the loop, set by every piece)
                 for (int it = w0u; it < n_it; it += ws) {
                     // (panel 512: whole rows first, then the second pieces of the rows of the panel's second half — k_hotlist)
                     const int r = tri ? (it < 2 * n2s ? it >> 1 : it - n2s) : it >> lg;
@@ -2704,8 +2706,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const unsigned long long src = gpn_s + ((((unsigned long long)(unsigned)kk << lgP) + (unsigned)pc) << 2);
                     const unsigned dst = rown_lds + ((unsigned)(it + shp) << 10);
                     my_rowp++;
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(dst) : "memory"); // (m0 is not restored: hipcc keeps nothing in it in this kernel — no other use in its ISA — and every piece sets it)
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(dst) : "memory");
                 }
+                asm volatile("s_mov_b32 m0, %0" : : "s"(keep_m0));
             } else
             for (int it = w0; it < n_items; it += ws) {
                 const int lin = (it << 8) + lane * 4;
