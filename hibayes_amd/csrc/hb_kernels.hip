@@ -379,7 +379,7 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
         }
 #endif
         const unsigned long long t0 = wall_clock64();
-        for (unsigned looks = 0;; looks++) {
+        for (;;) {
             if (q.rq) mbv = ld_sc1(q.mbv); // (every thread the same word: one broadcast load per wave, in flight with the counts)
 #pragma unroll
             for (int i = 0; i < 8; i++) nevs[i] = ld_sc1(q.ev_count + (size_t)min(q.p0 + i, q.p1 - 1) * HB_EVS);
@@ -527,7 +527,6 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
 __device__ __forceinline__ void update_rows_dense(int64_t ld, const upd_view &q, int blk, int nblk, char *smem)
 {
     double *s_dl = reinterpret_cast<double *>(smem);
-    int *s_ok = reinterpret_cast<int *>(smem + 8192);
     const signed char *slab = reinterpret_cast<const signed char *>(smem + HBU_SLAB);
     const unsigned slab_lds = (unsigned)(uintptr_t)(smem + HBU_SLAB);
     const int lane = threadIdx.x;
