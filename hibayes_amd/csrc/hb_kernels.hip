@@ -1494,6 +1494,9 @@ struct persist_view {
 #ifndef HB_FILL_ALL
 #define HB_FILL_ALL 1 /* the ring waves issue their share of the row cache's pieces too (0: the four non-ring waves alone) */
 #endif
+#ifndef HB_APPLY_PROG
+#define HB_APPLY_PROG 0 /* (A/B, off) ... and while the serial pass is still running: every verified block of it publishes its moves' records and the waves at the barrier apply them. Measured: apply + violation barrier 6 500 -> 950 cycles, but the serial pass 7 800 -> 13 000 (the publishing, and SGPR spills in its loop at 254 VGPRs): 52.7 sweeps/s against 52.8 */
+#endif
 #ifndef HB_APPLY_LEAN
 #define HB_APPLY_LEAN 1 /* a crowded round's moves are applied from 16-byte records read with one broadcast LDS load (0: the round-3 loop) */
 #endif
@@ -1797,6 +1800,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         st_flag(pv.flags + HB_FLAG_XCC, (xcc & 15u) + 1u);
     }
     for (int i = t; i < 128; i += P) cnts[i] = 0; // (a 64-marker panel has 64 threads; absent waves' words must read 0)
+    for (int i = t; i < 72 + 64; i += P) ap_rec[i] = make_int4(0, 0x7fffffff, 0, 0); // (a record read ahead of its count must at least address LDS)
     if (wave < RW)
         for (int x = pv.p0; x < pv.p0 + HB_RD - 1 && x < np; x++) issue_group(x, x - pv.p0);
     bool ok = true;
@@ -2116,6 +2120,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const bool inr = isc && rank < 64;
                 const int ncr = min(tot, 64);
                 if (isc && rank == 64) *s_thi = t;
+                if (t == 0) { cnts[2] = 0; cnts[3] = 0; cnts[4] = 0; } // (this round's records: none yet; the barrier below orders it against the serial pass)
                 if (inr) {
                     cs_d[rank] = rhs;
                     cs_d[64 + rank] = gold;
@@ -2252,7 +2257,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                     b = ge ? csdz[c] : b;
                                 }
                             };
-                            int cls_s;
+                            int cls_s, nsp = 0, nmp = 0; // (records published so far: cached rows, others)
                             double a_s, b_s;
                             classify(crhs, cls_s, a_s, b_s);
                             constexpr int SB = K1 > 3 ? 8 : HB_SPEC_B; // (steps per block)
@@ -2281,6 +2286,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                     nrerun++;
 #endif
                                     crhs = save;
+                                }
+                                if (HB_APPLY_LEAN && HB_APPLY_PROG) {
+                                    // the block is final: its moves go out now, as the records the other waves' apply reads — they
+                                    // are standing at the round's barrier otherwise (the same records, at the same places, as the
+                                    // listing after the pass writes once more)
+                                    const double dmb = fma(crhs, a_s, b_s) - cgold;
+                                    const bool mvl = inblk && dmb != 0.0;
+                                    const unsigned long long mvb = __ballot(mvl), mvs = mvb & ~noslot, mvm = mvb & noslot, below = (1ull << lane) - 1ull;
+                                    if (mvl) {
+                                        const long long db = __double_as_longlong(dmb);
+                                        if (cslot >= 0) ap_rec[nsp + __popcll(mvs & below)] = make_int4(cslot << 8, ct, (int)db, (int)(db >> 32));
+                                        else ms_rec[nmp + __popcll(mvm & below)] = make_int4(0, ct, (int)db, (int)(db >> 32));
+                                    }
+                                    nsp += __popcll(mvs);
+                                    nmp += __popcll(mvm);
+                                    if (lane == 0) {
+                                        __hip_atomic_store(&cnts[3], nmp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        __hip_atomic_store(&cnts[2], nsp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    }
                                 }
                             }
                         } else
@@ -2371,7 +2395,78 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             }
                             const int nsr = __popcll(mvs);
                             if (lane < 8) ap_rec[nsr + lane] = make_int4(0, 0x7fffffff, 0, 0);
-                            if (lane == 0) { cnts[2] = nsr; cnts[3] = __popcll(mvm); }
+                            if (lane == 0) {
+                                cnts[3] = __popcll(mvm);
+                                __hip_atomic_store(&cnts[2], nsr, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(&cnts[4], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); // the list is complete
+                            }
+                        }
+                    }
+                }
+                // ---- the apply of a crowded round, WHILE the serial pass runs (HB_APPLY_PROG): the other waves take the records of every
+                // block the pass has finished (the count is released after them) instead of standing at the barrier below until the
+                // whole pass is through; wave 0 does its own non-candidates afterwards. Cached rows in marker order, whatever the
+                // blocks' timing (a block's records are appended in marker order and applied in list order), the others after the
+                // pass — the same sums bit for bit as the apply behind the barrier.
+                double acc_prog = rhs;
+                if (HB_APPLY_LEAN && HB_APPLY_PROG && crowded) {
+                    const bool doap0 = undec && !inr;
+                    const bool anyap = __any(doap0);
+                    int lo = 0;
+                    // (the wave that shares wave 0's SIMD — four SIMDs, waves dealt round-robin — stays asleep until the pass is through:
+                    // every instruction it issues is an issue slot the serial pass does not get: 7 800 -> 13 000 cycles measured)
+                    if (S == 8 && wave == 4)
+                        while (!__hip_atomic_load(&cnts[4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) __builtin_amdgcn_s_sleep(8);
+                    for (;;) {
+                        const int fin = __hip_atomic_load(&cnts[4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const int hi = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cnts[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        if (anyap && hi > lo) {
+                            const int kl = lo + lane < hi ? ap_rec[lo + lane].y : 0x7fffffff; // (a round has at most 64 moves)
+                            const int n_in = __popcll(__ballot(kl < (t | 63)));
+                            const int n_un = __popcll(__ballot(kl < (t & ~63))) & ~7;
+                            for (int e0 = lo; e0 < lo + n_un; e0 += 8) { // moves of markers before the wave's first: no select
+                                int4 rc[8];
+                                int gv[8];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) rc[q] = ap_rec[e0 + q];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) gv[q] = reinterpret_cast<const int *>(smem + rc[q].x)[t];
+#pragma unroll
+                                for (int q = 0; q < 8; q++)
+                                    acc_prog = fma(-(double)gv[q], __longlong_as_double(((long long)rc[q].w << 32) | (unsigned)rc[q].z), acc_prog);
+                            }
+                            for (int e0 = lo + n_un; e0 < lo + n_in; e0 += 8) { // the wave's own stretch (records past `hi` may be half written: never used)
+                                int4 rc[8];
+                                int gv[8];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) rc[q] = ap_rec[e0 + q];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) gv[q] = reinterpret_cast<const int *>(smem + (rc[q].x & 0x3fffc))[t];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) {
+                                    const double nw = fma(-(double)gv[q], __longlong_as_double(((long long)rc[q].w << 32) | (unsigned)rc[q].z), acc_prog);
+                                    acc_prog = (e0 + q < hi && rc[q].y < t) ? nw : acc_prog;
+                                }
+                            }
+                        }
+                        lo = max(lo, hi);
+                        if (fin) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    const int nmr = cnts[3];
+                    if (anyap) {
+                        for (int e0 = 0; e0 < nmr; e0 += 8) { // moves whose row is not in the cache
+                            int4 rc[8];
+                            int gv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) rc[q] = ms_rec[min(e0 + q, nmr - 1)];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) gv[q] = gp[(size_t)__builtin_amdgcn_readfirstlane(rc[q].y) * P + t];
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                const double nw = fma(-(double)gv[q], __longlong_as_double(((long long)rc[q].w << 32) | (unsigned)rc[q].z), acc_prog);
+                                acc_prog = (e0 + q < nmr && rc[q].y < t) ? nw : acc_prog;
+                            }
                         }
                     }
                 }
@@ -2391,7 +2486,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
 #endif
                 const bool doap = undec && !inr;
-                if (HB_APPLY_LEAN && crowded) {
+                if (HB_APPLY_LEAN && HB_APPLY_PROG && crowded) {
+                    if (doap) rhs_new = acc_prog; // (applied before the barrier, while the serial pass ran)
+                } else if (HB_APPLY_LEAN && crowded) {
                     // A crowded round (BayesR: ~50 moves): the apply used to be the longest phase of the panel — eight waves, two
                     // per SIMD, each issuing ~15 instructions per move (the move's record handed round by v_readlane, a scalar row
                     // address, the test for a row outside the cache, the select for "this marker comes later") at ~13 cycles an

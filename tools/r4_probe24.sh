@@ -1,10 +1,6 @@
 #!/bin/bash
 O=gpurun_out
-( timeout 1200 python -m pytest tests/test_gpu_depth.py tests/test_gpu_parity.py tests/test_gpu_recovery.py tests/test_gpu_kernels.py -q -x > $O/r4_p24_tests.txt 2>&1; grep "passed\|failed" $O/r4_p24_tests.txt )
+( timeout 1200 python -m pytest tests/test_gpu_depth.py tests/test_gpu_parity.py tests/test_gpu_recovery.py -q -x > $O/r4_p24_tests.txt 2>&1; grep "passed\|failed" $O/r4_p24_tests.txt )
 timeout 500 python tools/geo_sweep.py 50000 500000 BayesR 300 512 "2,1 3,1" 60 2>&1 | tail -2
 export HIBAYES_GPU_LIB=$PWD/build/variants/stamps.so
-STAMPS=1 timeout 500 python tools/geo_sweep.py 50000 500000 BayesR 300 512 "2,1" 40 > $O/r4_bayesr_stamps5.log 2>&1; tail -8 $O/r4_bayesr_stamps5.log
-unset HIBAYES_GPU_LIB
-timeout 600 python bench.py --no-ab --tertiary "" --no-cpu 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('value', d['value'], d['roofline']['avg_launch_ms'], 'secondary', d['secondary']['value'])"
+STAMPS=1 timeout 500 python tools/geo_sweep.py 50000 500000 BayesR 300 512 "2,1" 40 > $O/r4_bayesr_stamps7.log 2>&1; tail -8 $O/r4_bayesr_stamps7.log
