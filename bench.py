@@ -43,6 +43,10 @@ def parse():
                     help="MCMC burn-in sweeps run as part of the set-up, before the warm-up steps: the chain starts with ~5 %% of the "
                          "markers in the model and needs a few hundred sweeps to reach the regime a 20 000-iteration run spends its time in")
     ap.add_argument("--burnin-secondary", type=int, default=300)
+    ap.add_argument("--burnin-converged", type=int, default=2500,
+                    help="the secondary model (BayesR) is measured twice: after --burnin-secondary sweeps (the chain has not found the signal "
+                         "yet: ~30 000 markers in the model, ~49 000 moves per sweep) and again after this many MORE sweeps, continued from "
+                         "the first leg's state (nnz ~2 000-5 000: the regime a 50 000-iteration run lives in); 0 = first figure only")
     ap.add_argument("--stamped", type=int, default=10,
                     help="sweeps run right after the timed region with every block of every mat-vec launch stamped on the device's "
                          "100 MHz clock (hb_ctx_matvec_stamps): the in-situ launch duration the roofline is computed from")
@@ -127,13 +131,14 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
                 rng=O.RNG_PHILOX, seed=args.seed, g_init=gi)
     out[1] = r["iters_done"] / r["loop_seconds"] * (mc / float(args.m))
     one_thread_s = r["loop_seconds"]
-    # threaded dot/axpy (what a threaded BLAS would give the reference, README.md:18; BASELINE.md §3: threads = 1 and = all
-    # cores). BLAS-1 on n-long vectors rarely scales; each setting is bounded by a wall-clock guard in a child process.
+    # threaded dot/axpy (what a threaded BLAS would give the reference, README.md:18): ONE persistent team of
+    # workers for the whole run, each owning a fixed chunk of the rows, partial sums through padded slots and a two-level tree
+    # (oracle/hb_oracle.c team_*; rounds 1-4 forked an OpenMP region per call and ran slower with more threads). Each setting
+    # is bounded by a wall-clock guard in a child process.
     import multiprocessing as mp
 
     def timed(thr):
         def _child(q):
-            os.environ["OMP_WAIT_POLICY"] = "passive"
             rr = O.bayes(y, Xd, args.model, Pi, fold=fold, niter=it, nburn=it - 1, thin=1, threads=thr,
                          rng=O.RNG_PHILOX, seed=args.seed, g_init=gi)
             q.put(rr["iters_done"] / rr["loop_seconds"])
@@ -150,7 +155,7 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
         return q.get() * (mc / float(args.m)) if not q.empty() else "no result"
 
     slow = {}
-    for thr in sorted(set([min(cores, 16), min(cores, 64), cores]) - {1}):
+    for thr in sorted(set([min(cores, 8), min(cores, 16), min(cores, 64)]) - {1}):
         v = timed(thr)
         if isinstance(v, float):
             out[thr] = v
@@ -166,7 +171,7 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
     except OSError:
         pass
     return {"value": out[best_thr], "unit": "sweeps/s", "cores": best_thr, "kind": "port",
-            "sample": "oracle/hb_oracle.c (double col-major X, serial marker loop, OpenMP inside dot/axpy) on the first %d of %d "
+            "sample": "oracle/hb_oracle.c (double col-major X, serial marker loop, dot/axpy on a persistent team of row-chunk workers) on the first %d of %d "
                       "markers, n=%d, %d sweeps, scaled by m_sample/m" % (mc, args.m, args.n, 1 + args.cpu_sweeps),
             "value_1thread": out[1], "by_threads": {str(k): v for k, v in sorted(out.items())}, "not_finished": slow,
             "regime": "warm start from the GPU chain's effects after its timed region" if gi is not None else "cold start",
@@ -236,6 +241,16 @@ def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8, kin
     return r
 
 
+def regime_tag(ms_per_step, insitu):
+    """A leg whose timed ms per step differs by more than 10 % from the stamped sweeps that follow it was not timed in the regime
+    the roofline's launches ran in (markers still being re-admitted or shed): tagged, not hidden."""
+    if not insitu:
+        return {"regime": "unchecked (no stamped sweeps)"}
+    st = insitu["ms_per_step_of_the_stamped_sweeps"]
+    rel = abs(ms_per_step - st) / max(1e-12, st)
+    return {"regime": "stationary" if rel <= 0.10 else "transient", "timed_vs_stamped_ms_per_step": [ms_per_step, st]}
+
+
 def pmc_traffic(n, cols, kernel):
     """HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE passes kept under profiles/ (counters cannot be read from
     inside this process): reported only when a pass with the same kernel, n and launch width exists."""
@@ -248,6 +263,12 @@ def pmc_traffic(n, cols, kernel):
         pass
     return None
 
+
+# untimed sweeps at the start of a side leg of the headline model (matrix-core A/B, int8 columns), whatever --warmup says: the leg
+# continues from the headline run's effects AND hyper-parameters (hb_warm_state), these sweeps only let the geometry choice, the hot
+# list and the row cache settle (round 4: the legs restarted from prior-default pi / varg and re-admitted tens of thousands of markers
+# — 76 instead of 209 sweeps/s under the driver's --warmup 5)
+SIDE_WARMUP = 40
 
 PIPELINE = {  # (pipeline, look-ahead groups, panels per mat-vec launch): see DESIGN.md §2
     "BayesCpi": (1, 3, 7), "BayesC": (1, 3, 7), "BayesB": (1, 3, 7), "BayesBpi": (1, 3, 7),
@@ -266,11 +287,13 @@ def prior(model):
     return [0.95, 0.05], None
 
 
-def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, m_global, comm, torch, note, burn=0, g_init=None):
+def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, m_global, comm, torch, note, burn=0, g_init=None, warm=None):
     """burn set-up sweeps, W warm-up iterations, then exactly K iterations between barriers; returns the result dict pieces.
-    g_init: effects the chain starts from (a leg that continues in the regime an earlier leg reached: no burn-in of its own)."""
+    g_init + warm: effects and hyper-parameters (hb_warm_state) the chain starts from — a leg that CONTINUES in the regime an
+    earlier leg reached (same markers in the model, same pi / varg / vare) instead of re-admitting markers from the prior
+    defaults. measure.final = (effects, WarmState) after the leg's last sweep."""
     measure.insitu = None
-    from hibayes_amd._lib import BayesArgs, RunInfo, check
+    from hibayes_amd._lib import BayesArgs, RunInfo, WarmState, check
     n, m = args.n, args.m
     Pi, fold = prior(model)
     a = BayesArgs()
@@ -292,6 +315,9 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
         gi = np.ascontiguousarray(g_init, dtype=np.float64)
         a.g_init = gi.ctypes.data
         keep.append(gi)
+    if warm is not None:
+        a.warm = ct.addressof(warm)
+        keep.append(warm)
     if comm is not None:
         a.rank, a.world, a.m_global, a.m_offset = rank, world, m_global, m_offset
         if getattr(comm, "rccl", None) is not None:
@@ -340,10 +366,13 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
     sync()
     elapsed = time.perf_counter() - t1
     note("%s: timed region done: %.3fs for %d steps" % (model, elapsed, K))
+    measure.per_rank_ms = None
     if comm is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm.device)
-        comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.zeros(world, dtype=torch.float64, device=comm.device)
+        mine[rank] = elapsed
+        comm.dist.all_reduce(mine)                      # one slot per rank: every rank's own time for its K steps
+        measure.per_rank_ms = [float(v) / K * 1e3 for v in mine.cpu()]
+        elapsed = float(mine.max().item())              # the contract: MAX over ranks
     info = RunInfo()
     check(L.hb_run_state(run, ct.byref(info)))
     # ---- in-situ duration of the dominant kernel: the SAME run goes on for a few sweeps with every block of every mat-vec
@@ -372,6 +401,12 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
              % (model, args.stamped, acc["avg_ms"] * 1e3, st["launches_all"], acc["span_ms"], wall / args.stamped * 1e3))
     measure.insitu = insitu
     measure.replayed = info.sweeps_replayed
+    info_end = RunInfo()
+    check(L.hb_run_state(run, ct.byref(info_end)))
+    g_end, _, vl_end = ctx.get_effects()
+    measure.final = (g_end, WarmState.from_info(info_end, len(Pi), vl_end if model == "BayesL" else None))
+    measure.state = {"NumNZSnp": info_end.nnz, "pi": [info_end.pi[j] for j in range(len(Pi))], "varg": info_end.varg,
+                     "vare": info_end.vare, "vara": info_end.vara}
     L.hb_run_destroy(run)
     del keep
     ev = (info.mean_events * info.iter - info0.mean_events * info0.iter) / max(1, K)   # over the timed sweeps only
@@ -511,7 +546,9 @@ def main():
     elapsed, mean_events, nnz, misses = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
                                         m_global, comm, torch, note, burn=args.burnin)
     replayed_main = getattr(measure, "replayed", 0)
-    g_main = ctx.get_effects()[0]
+    per_rank_main = getattr(measure, "per_rank_ms", None)
+    g_main, warm_main = measure.final     # the state the side legs of this model continue from
+    state_main = dict(measure.state)
     curve_main = list(getattr(measure, "curve", []))
     curve_main.append({"sweeps": "timed region", "moves_per_sweep": round(mean_events, 1), "sweeps_per_s": round(world * K / elapsed, 2)})
     insitu_main = measure.insitu
@@ -553,7 +590,12 @@ def main():
                           "what": "n x m genotypes per sweep (SURVEY 8d's unit; = GB/s at one byte per genotype)"},
         "roofline": roof,
         "regime_curve": curve_main,   # sweeps/s is set by the serial chain, i.e. by how many markers change per sweep
+        "state_after": state_main,
     }
+    res.update(regime_tag(elapsed / K * 1e3, insitu_main))
+    roof["regime"] = res["regime"]
+    roof["traffic_source"] = ("separate rocprofv3 --pmc FETCH_SIZE pass of the same launch shape, read from the tracked profiles/r04_pmc_traffic.json "
+                              "(counters cannot be collected inside this process)") if roof.get("traffic") is not None else "none (no counter pass on file for this launch shape)"
 
     def leg_block(model, el, Kx, Wx, ev, nnzx, missx, ins, iso, launches_x, cols_x, bits_x, kind, geo_x, burn_x, curve=None):
         kern = roofline_block(args, n, cols_x, launches_x, ins, iso, None, bits_x, kind)
@@ -565,6 +607,8 @@ def main():
              "mean_changed_markers_per_sweep": ev, "row_cache_misses_per_sweep": missx, "NumNZSnp_last": nnzx,
              "sweeps_replayed_after_a_device_time_out": getattr(measure, "replayed", 0),
              "pipeline": {"persistent_chain": geo_x[0], "lookahead_groups": geo_x[1], "panels_per_matvec": geo_x[2]}}
+        b.update(regime_tag(el / Kx * 1e3, ins))
+        b["state_after"] = dict(getattr(measure, "state", {}))
         if curve is not None:
             b["regime_curve"] = curve
         return b
@@ -574,9 +618,9 @@ def main():
     if single and bits == 2 and args.precise == 2 and not args.no_ab:
         try:
             ctx.set_matvec_kernel(2)
-            Wm = max(5, min(W, 30))
+            Wm = SIDE_WARMUP
             elm, evm, nnzm, missm = measure(H, L, ctx, y, args.model, K, Wm, args, rank, local_rank, world, m_offset, m_global, comm, torch, note,
-                                            burn=0, g_init=g_main)
+                                            burn=0, g_init=g_main, warm=warm_main)
             insm = measure.insitu
             ctx.time_matvec(reps=1)
             isom, lm, cm = ctx.time_matvec(reps=3)
@@ -592,9 +636,9 @@ def main():
             geo8 = (1, 2, 7) if geo == (1, 3, 7) else geo
             ctx.set_layout(8)
             ctx.set_pipeline(*geo8)
-            W8 = max(5, min(W, 30))
+            W8 = SIDE_WARMUP
             el8, ev8, nnz8, miss8 = measure(H, L, ctx, y, args.model, K, W8, args, rank, local_rank, world, m_offset, m_global, comm, torch, note,
-                                            burn=0, g_init=g_main)
+                                            burn=0, g_init=g_main, warm=warm_main)
             ins8 = measure.insitu
             ctx.time_matvec(reps=1)
             iso8, l8, c8 = ctx.time_matvec(reps=3)
@@ -638,11 +682,64 @@ def main():
                 res.setdefault(key, []).append(blk)
             else:
                 res[key] = blk
+                if args.burnin_converged > 0:
+                    g2, warm2 = measure.final
+                    el3, ev3, nnz3, miss3 = measure(H, L, ctx, y2, side, K2, W2, args, rank, local_rank, world, m_offset, m_global, comm, torch, note,
+                                                    burn=args.burnin_converged, g_init=g2, warm=warm2)
+                    curve3 = list(getattr(measure, "curve", []))
+                    curve3.append({"sweeps": "timed region", "moves_per_sweep": round(ev3, 1), "sweeps_per_s": round(K2 / el3, 2)})
+                    blk["converged"] = leg_block(side, el3, K2, W2, ev3, nnz3, miss3, measure.insitu, iso2, launches2, cols2, bits2, 0, geo2,
+                                                 burn_s + W2 + K2 + args.stamped + 1 + args.burnin_converged, curve3)
+                    blk["converged"]["note"] = ("the same run continued (effects + hyper-parameters, hb_warm_state) for %d more sweeps: the chain has "
+                                                "found the signal, few markers are left in the model" % args.burnin_converged)
+                    blk["note"] = ("measured %d sweeps after a cold start, where the chain has not found the signal yet (tens of thousands of markers "
+                                   "in the model, see state_after); `converged` is the later regime" % burn_s)
         except Exception as e:
             if key == "all_move":
                 res.setdefault(key, []).append({"model": side, "error": repr(e)})
             else:
                 res[key] = {"model": side, "error": repr(e)}
+    # scalars of the side legs inside `roofline` (the driver's parsed record keeps the scalar keys of this block only)
+    for key, pre in (("int8", "int8"), ("mfma_ab", "mfma")):
+        b = res.get(key)
+        if isinstance(b, dict) and "roofline" in b:
+            roof[pre + "_value"] = b["value"]
+            roof[pre + "_ms_per_step"] = b["ms_per_step"]
+            roof[pre + "_frac"] = b["roofline"]["frac"]
+            roof[pre + "_avg_launch_ms"] = b["roofline"]["avg_launch_ms"]
+            roof[pre + "_kernel"] = b["roofline"]["kernel"]
+            roof[pre + "_regime"] = b.get("regime")
+    b = res.get("secondary")
+    if isinstance(b, dict) and "value" in b:
+        roof["secondary_model"] = b["model"]
+        roof["secondary_value"] = b["value"]
+        roof["secondary_regime"] = b.get("regime")
+        if isinstance(b.get("converged"), dict):
+            roof["secondary_converged_value"] = b["converged"]["value"]
+            roof["secondary_converged_regime"] = b["converged"].get("regime")
+    for b in res.get("all_move", []):
+        if "value" in b:
+            roof["all_move_%s_value" % b["model"]] = b["value"]
+    if world > 1:
+        # what the scaling curve is made of: every rank's own time per step, and the exchange a sweep ends with on its own
+        res["per_rank_ms_per_step"] = {"min": min(per_rank_main), "max": max(per_rank_main), "all": per_rank_main} if per_rank_main else None
+        try:
+            xc = int(L.hb_exchange_count(n))
+            buf = torch.zeros(xc, dtype=torch.float64, device=comm.device)
+            for _ in range(5):
+                comm.dist.all_reduce(buf)
+            torch.cuda.synchronize(local_rank)
+            ta = time.perf_counter()
+            for _ in range(50):
+                comm.dist.all_reduce(buf)
+            torch.cuda.synchronize(local_rank)
+            ar_ms = (time.perf_counter() - ta) / 50 * 1e3
+            res["allreduce"] = {"doubles": xc, "bytes": xc * 8, "ms_per_call_back_to_back": ar_ms, "calls_per_sweep": 1,
+                                "share_of_ms_per_step": ar_ms / (elapsed / K * 1e3),
+                                "what": "torch.distributed all_reduce (%s) of the sweep's exchange message on its own, 50 calls back to back; "
+                                        "inside a sweep the library enqueues the same collective on the sweep stream" % args.backend}
+        except Exception as e:  # noqa: BLE001
+            res["allreduce"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
             res["cpu_baseline"] = cpu_baseline(ctx, y, args, Pi, fold, g_main)

@@ -60,7 +60,35 @@ class BayesArgs(C.Structure):
         ("sync_blocks", C.c_int32),
         ("genotype_bits", C.c_int32),
         ("shard_rows", C.c_int32), ("n_global", C.c_int64), ("row_offset", C.c_int64),
+        ("warm", C.c_void_p),
     ]
+
+
+class WarmState(C.Structure):
+    """hb_warm_state (ABI 6): the scalars a continued chain starts from; see include/hibayes_gpu.h."""
+    _fields_ = [("mu", C.c_double), ("vare", C.c_double), ("varg", C.c_double), ("lambda2", C.c_double),
+                ("pi", C.c_double * HB_MAX_FOLD), ("vargL", C.c_void_p)]
+
+    @classmethod
+    def make(cls, mu, vare, varg=0.0, pi=(), lambda2=0.0, vargL=None):
+        import numpy as np
+        w = cls()
+        w.mu, w.vare, w.varg, w.lambda2 = float(mu), float(vare), float(varg), float(lambda2)
+        for j, p in enumerate(pi):
+            w.pi[j] = float(p)
+        w._keep = None
+        if vargL is not None:
+            w._keep = np.ascontiguousarray(vargL, dtype=np.float64)
+            w.vargL = w._keep.ctypes.data
+        return w
+
+    def as_dict(self, n_pi):
+        return {"mu": self.mu, "vare": self.vare, "varg": self.varg, "lambda2": self.lambda2, "pi": [self.pi[j] for j in range(n_pi)]}
+
+    @classmethod
+    def from_info(cls, info, n_pi, vargL=None):
+        """the state hb_run_state() reported (RunInfo) as the start of another run"""
+        return cls.make(info.mu, info.vare, info.varg, [info.pi[j] for j in range(n_pi)], info.lambda2, vargL)
 
 
 class BayesOut(C.Structure):
@@ -78,6 +106,7 @@ class BayesOut(C.Structure):
         ("iters_done", C.c_int32),
         ("mean_events", C.c_double),
         ("sweeps_replayed", C.c_int32), ("reserved_", C.c_int32),
+        ("last", WarmState), ("g_last", C.c_void_p), ("vargL_last", C.c_void_p),
     ]
 
 
@@ -113,6 +142,7 @@ class RunInfo(C.Structure):
         ("pi", C.c_double * HB_MAX_FOLD), ("mean_events", C.c_double), ("mean_misses", C.c_double), ("mean_redo", C.c_double),
         ("loop_seconds", C.c_double), ("setup_seconds", C.c_double), ("gram_seconds", C.c_double),
         ("sweeps_replayed", C.c_int32), ("reserved_", C.c_int32),
+        ("lambda2", C.c_double),
     ]
 
 

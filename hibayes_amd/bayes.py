@@ -29,7 +29,7 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
           dfvg=None, s2vg=None, ve=None, dfve=None, s2ve=None, windindx=None, outfreq=100, threads=0,
           verbose=True, *, seed=666666, device=0, panel=0, precise=2, store_alpha=True,
           comm=None, m_global=None, m_offset=0, log=None, C=None, g_init=None, ctx=None, sync_every_blocks=1, genotype_bits=8,
-          shard_rows=False, n_global=None, row_offset=0):
+          shard_rows=False, n_global=None, row_offset=0, warm=None):
     """Individual-level Gibbs sampler on one MI355X (or one marker shard of it when `comm` is given).
 
     X is n x m: int8 (fast path, no double blow-up) or any integer-valued float array in the
@@ -39,6 +39,8 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
     an fp64 ddot's own rounding and independent of the launch geometry; 1 fp64 FMA; 0 the fp32 image of the residual.
     `ctx` (an engine.Context with genotypes already resident) replaces X: one upload serves several fits;
     the context's own pipeline geometry, seed addressing (m_offset) and panel are then used as they are.
+    `warm` (a dict mu / vare / varg / pi / lambda2 / vargL, or a _lib.WarmState) with `g_init` continues a chain from a reported
+    state instead of the prior defaults (hb_warm_state, include/hibayes_gpu.h).
     """
     if C is not None and C_ is None:
         C_ = C
@@ -138,6 +140,10 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
             raise HibayesError(1, "g_init must have one entry per marker")
         a.g_init = gi.ctypes.data
         keep.append(gi)
+    if warm is not None:
+        ws = _lib.WarmState.make(**warm) if isinstance(warm, dict) else warm
+        a.warm = ct.addressof(ws)
+        keep.append(ws)
     if shard_rows:  # exact cross-check mode: this process holds rows [row_offset, row_offset + n) of every marker (include/hibayes_gpu.h)
         a.shard_rows, a.n_global, a.row_offset = 1, int(n if n_global is None else n_global), int(row_offset)
     a.genotype_bits = int(genotype_bits)  # 8: int8 columns resident; 2: 2 bits per genotype resident (codes 0..3), same chain
@@ -172,6 +178,9 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
     if store_alpha:
         o.s_alpha = buf("s_alpha", (m, nrec))
     o.alpha_sd = buf("alpha_sd", m)
+    o.g_last = buf("g_last", m)
+    if model == "BayesL":
+        o.vargL_last = buf("vargL_last", m)
 
     check(L.hb_bayes_run(ct.byref(a), ct.byref(o)))
 
@@ -205,6 +214,11 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
     if nw:
         res["gwas"] = bufs["gwas"]
     res["MCMCsamples"] = mc
+    # the chain after its last iteration: Bayes(..., g_init=last["g"], warm=last["warm"]) continues it (hb_warm_state)
+    lw = o.last.as_dict(Pi.size)
+    if model == "BayesL":
+        lw["vargL"] = bufs["vargL_last"]
+    res["last"] = {"g": bufs["g_last"], "warm": lw}
     res["alpha_sd"] = bufs["alpha_sd"]
     res["timing"] = {"setup_seconds": o.setup_seconds, "loop_seconds": o.loop_seconds,
                      "iters_done": o.iters_done, "mean_events": o.mean_events,

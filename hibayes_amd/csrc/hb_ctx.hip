@@ -135,7 +135,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_WARM_GROUP")) c->warm_group = atoi(e) != 0;
     if (const char *e = getenv("HB_FWD")) c->fwd_group = atoi(e) != 0;
     if (const char *e = getenv("HB_DENSE")) c->dense_chain = atoi(e) != 0;
-    if (const char *e = getenv("HB_TIMEOUT_MS")) c->timeout_ms = std::max(1, std::min(60000, atoi(e)));
+    if (const char *e = getenv("HB_TIMEOUT_MS")) { c->timeout_ms = std::max(1, std::min(60000, atoi(e))); c->timeout_env = true; }
     if (const char *e = getenv("HB_KAPPA")) c->kappa = atof(e);
     if (const char *e = getenv("HB_DOT_LDS")) c->dot_lds = std::min(65536, std::max(0, atoi(e)));
     if (const char *e = getenv("HB_CANDF")) c->candf = std::min(1.0, std::max(0.0, atof(e)));
@@ -541,7 +541,7 @@ int hb_ctx_set_pipeline(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t 
 {
     int rc = check_cols(c, 0, 0, "hb_ctx_set_pipeline");
     if (rc) return rc;
-    if (c->env_pinned && c->concurrent) return HB_OK; // HB_PIPELINE / HB_LOOKAHEAD / HB_DOTGROUP in the environment win (tuning runs)
+    if (c->env_pinned && c->concurrent && !c->force_geometry) return HB_OK; // HB_PIPELINE / HB_LOOKAHEAD / HB_DOTGROUP in the environment win (tuning runs)
     const int op = c->pipeline, ol = c->Lv, od = c->D;
     c->pipeline = pipeline ? 1 : 0;
     c->Lv = lookahead;

@@ -175,7 +175,10 @@ struct hb_ctx {
     size_t snap_cap = 0;
     std::vector<snap_seg> snap_segs; // what the last snapshot holds
     bool aborted = false;            // the last fetch found the abort flag raised
-    int timeout_ms = 100;            // a device-side wait gives up after this long (HB_TIMEOUT_MS; hb_run_step raises it for a replay)
+    int timeout_ms = 3000;           // a device-side wait gives up after this long. 3 s for whoever drives the context directly (hb_ctx_sweep:
+                                     // nothing replays an aborted sweep there); hb_run_step, which does replay, runs its sweeps with 100 ms
+    bool timeout_env = false;        // HB_TIMEOUT_MS given: that value everywhere, hb_run_step does not shorten it
+    bool force_geometry = false;     // hb_run_step's fall-back to the per-panel kernels: hb_ctx_set_pipeline ignores env_pinned while set
     int inject_abort_panel = -1;     // debug hook (hb_ctx_debug_inject_abort): the next sweeps are aborted once chain_done reaches this panel
     int inject_abort_times = 0;
     hipStream_t s_dbg = nullptr;

@@ -16,6 +16,8 @@
 #include <type_traits>
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #define HB_INF __builtin_huge_val()
 
@@ -953,7 +955,9 @@ __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, un
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (acc && i < HB_ACC_N) acc[i] = 0.0; // (null: a later range of the same sweep keeps the sums)
-    if (i < HB_NFLAGS && (acc || i != HB_FLAG_ABORT)) flags[i] = 0u; // (a later range keeps an abort raised by an earlier one)
+    // (a later range of the same sweep keeps an abort raised by an earlier one, and with it who gave up waiting for what — words 8..14
+    // and the abort log's record count — which is what HB_DEBUG_ABORT prints)
+    if (i < HB_NFLAGS && (acc || (i != HB_FLAG_ABORT && !(i >= 8 && i <= 14) && i != HB_FLAG_LOGN))) flags[i] = 0u;
     // move counts and list entries of the panels of this range on: "not written yet" (the update rows poll them directly; an earlier
     // range's move lists stay readable)
     for (int k = p_lo + i; k < np; k += stride) ev_count[(size_t)k * HB_EVS] = -1;
@@ -4264,15 +4268,22 @@ int hbk_abort_poison(hb_ctx *c, double *sums)
     return HB_OK;
 }
 
+// The bound is ONE device global per device (every kernel of the module reads it), so two contexts on one device share it: the cache of
+// what was uploaded is keyed by the device ordinal and guarded — two host threads driving two contexts must not race on it — and a
+// context whose value differs from the device's re-uploads before its sweep. (Contexts on one device that want DIFFERENT bounds at
+// the same time get the later one for both: the bound only decides how soon a stalled sweep is given up, never a result.)
 int hbk_set_timeout(hb_ctx *c)
 {
-    static int uploaded_ms[64];
-    const int dev = c->device & 63, ms = std::max(1, c->timeout_ms);
-    if (uploaded_ms[dev] == ms) return HB_OK;
+    static std::mutex mu;
+    static std::map<int, int> uploaded_ms;
+    const int ms = std::max(1, c->timeout_ms);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = uploaded_ms.find(c->device);
+    if (it != uploaded_ms.end() && it->second == ms) return HB_OK;
     const unsigned long long ticks = (unsigned long long)ms * 100000ull;
     HB_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(hb_timeout_ticks), &ticks, sizeof ticks, 0, hipMemcpyHostToDevice, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream)); // (the source is a stack word; this happens once per change of the value)
-    uploaded_ms[dev] = ms;
+    uploaded_ms[c->device] = ms;
     return HB_OK;
 }
 

@@ -64,6 +64,9 @@ struct hb_run {
     hb_bayes_args a{};
     std::string model;
     std::vector<double> y, Cmat, Pi, fold_, g_init;
+    bool has_warm = false;     // hb_bayes_args.warm: continue from a reported state instead of the prior defaults
+    hb_warm_state warm_{};
+    std::vector<double> warm_vargL;
     std::vector<uint32_t> wind;
     int n = 0, m = 0, model_index = 0, n_pi = 0, n_fold = 0, nc = 0, nr = 0, world = 1;
     bool fixpi = false, always_in = false, sharded = false;
@@ -424,6 +427,31 @@ int hb_run::setup(const hb_bayes_args *args)
             if (!std::isfinite(v)) return hb_fail(HB_ERR_INVALID, "hb_bayes_run: g_init must be finite");
         a.g_init = nullptr; // consumed
     }
+    if (a.warm) {
+        has_warm = true;
+        warm_ = *a.warm;
+        if (!(std::isfinite(warm_.mu) && warm_.vare > 0 && std::isfinite(warm_.vare)))
+            return hb_fail(HB_ERR_INVALID, "hb_bayes_run: warm state needs a finite mu and vare > 0");
+        if ((model_index == 1 || model_index == 4 || model_index == 6) && !(warm_.varg > 0 && std::isfinite(warm_.varg)))
+            return hb_fail(HB_ERR_INVALID, "hb_bayes_run: warm state needs varg > 0 for this model");
+        if (model_index == 5 && !(warm_.lambda2 > 0 && std::isfinite(warm_.lambda2)))
+            return hb_fail(HB_ERR_INVALID, "hb_bayes_run: warm state needs lambda2 > 0 for BayesL");
+        if (!always_in && !fixpi) {
+            double sp = 0;
+            for (int j = 0; j < n_fold; j++) {
+                if (!(warm_.pi[j] > 0 && warm_.pi[j] < 1)) return hb_fail(HB_ERR_INVALID, "hb_bayes_run: warm state needs every pi in (0, 1)");
+                sp += warm_.pi[j];
+            }
+            if (std::fabs(sp - 1.0) > 1e-9) return hb_fail(HB_ERR_INVALID, "hb_bayes_run: warm pi must sum to 1");
+        }
+        if (model_index == 5 && warm_.vargL) {
+            warm_vargL.assign(warm_.vargL, warm_.vargL + m);
+            for (double v : warm_vargL)
+                if (!(v >= 0 && std::isfinite(v))) return hb_fail(HB_ERR_INVALID, "hb_bayes_run: warm vargL must be finite and >= 0");
+        }
+        warm_.vargL = nullptr;
+        a.warm = nullptr; // consumed
+    }
 
     // =========================== device set-up ===========================
     int rc;
@@ -528,6 +556,19 @@ int hb_run::setup(const hb_bayes_args *args)
         sumvx = sv[0];
         nvar0 = (int)sv[1];
     }
+    if (sharded && world > 1) {
+        // every rank must take the same replay decision (an aborting rank poisons the exchanged sums; a rank that would not replay
+        // would fail while the others re-enter the all-reduce and hang): recovery is on only where ALL ranks have it — the
+        // persistent pipeline available (the concurrency probe is per process) and HB_RECOVER not switched off
+        double ok[1] = {(recover_on && c->pipeline) ? 1.0 : 0.0};
+        rc = allreduce_host(ok, 1);
+        if (rc) return rc;
+        if (ok[0] < (double)world) {
+            if (recover_on && c->pipeline)
+                fprintf(stderr, "hibayes_gpu: rank %d: sweep replay switched off — not every rank can replay (HB_RECOVER / pipeline availability differ)\n", a.rank);
+            recover_on = false;
+        }
+    }
     if (!c->gram_ready) {
         rc = hb_ctx_build_gram(c, &gram_seconds);
         if (rc) return rc;
@@ -571,7 +612,7 @@ int hb_run::setup(const hb_bayes_args *args)
     {
         std::vector<double> g0(m, 0.0), vl(m, varg);
         std::vector<uint8_t> t0v(m, 0);
-        rc = hb_ctx_set_effects(c, g0.data(), t0v.data(), vl.data()); // vargL.fill(varg), :364-368
+        rc = hb_ctx_set_effects(c, g0.data(), t0v.data(), warm_vargL.empty() ? vl.data() : warm_vargL.data()); // vargL.fill(varg), :364-368
         if (rc) return rc;
         HB_HIP(hipMemsetAsync(c->nzrate, 0, sizeof(uint32_t) * (size_t)c->m_pad, c->stream));
         HB_HIP(hipMemsetAsync(c->alpha_sum, 0, sizeof(double) * (size_t)c->m_pad, c->stream));
@@ -624,8 +665,22 @@ int hb_run::setup(const hb_bayes_args *args)
     line("MCMC started: ");
     line(" Iter  NumNZSnp  pi  %sVg  Ve  h2  Timeleft", model == "BayesL" ? "Lambda  " : "");
 
+    // ---- warm state: the scalars of a chain that is continued (the constants above stay the cold run's) ----
+    if (has_warm) {
+        vare_ = warm_.vare;
+        if (model_index == 1 || model_index == 4 || model_index == 6) varg = warm_.varg;
+        if (model_index == 6)
+            for (int j = 0; j < n_fold; j++) vara_fold[j] = varg * fold_[j]; // :808
+        if (model_index == 5) {
+            lambda2 = warm_.lambda2;
+            lambda = std::sqrt(lambda2);
+        }
+        if (!always_in && !fixpi)
+            for (int j = 0; j < n_fold; j++) Pi[j] = warm_.pi[cls_of[j]]; // (internal class j is the caller's cls_of[j])
+    }
+
     // ---- :469-472 ----
-    mu = rowmode ? ymean_glob : arma_sum(y.data(), n) / n;
+    mu = has_warm ? warm_.mu : (rowmode ? ymean_glob : arma_sum(y.data(), n) / n);
     {
         std::vector<double> yadj(n), zero(n, 0.0);
         for (int i = 0; i < n; i++) yadj[i] = y[i] - mu;
@@ -748,9 +803,27 @@ int hb_run::step()
     // replay is the same chain. A second failure of the same sweep replays it on the event-ordered per-panel kernels, which wait
     // for nothing on the device; sharded, the abort reaches every rank through the exchange and all of them replay.
     const bool recover = recover_on && c->pipeline && !rowmode;
-    int saved_geo[4] = {0, 0, 0, 0};
-    bool fell_back = false;
-    const int base_timeout = c->timeout_ms;
+    // Whatever way this iteration ends, the context gets back the wait bound and the geometry it came with (a caller-owned context
+    // outlives the run): a scope guard, not a line after the loop that the error returns inside it would skip.
+    struct restore_ctx {
+        hb_ctx *c;
+        int timeout_ms;
+        int geo[4] = {0, 0, 0, 0};
+        bool fell_back = false;
+        ~restore_ctx()
+        {
+            c->timeout_ms = timeout_ms;
+            if (fell_back) {
+                c->force_geometry = true;
+                (void)hb_ctx_set_pipeline(c, geo[0], geo[1], geo[2]);
+                c->force_geometry = false;
+            }
+        }
+    } guard{c, c->timeout_ms};
+    // A sweep that is replayed when it times out may give up early: a healthy hand-off takes microseconds, the device's own pauses a
+    // millisecond, so 100 ms instead of the context's 3 s — unless HB_TIMEOUT_MS fixed the bound, or the run has
+    // learnt that this device is slow (three aborts within 64 iterations raise slow_timeout). Without recovery the context's bound stays.
+    if (recover && !c->timeout_env) c->timeout_ms = std::max(100, slow_timeout);
     if (recover) {
         rc = hb_ctx_snapshot(c, model_index, in.store != 0, in.count_pip != 0);
         if (rc) return rc;
@@ -785,26 +858,28 @@ int hb_run::step()
         rc = hb_ctx_sweep_end(c, &so);
         if (rc != HB_ERR_ABORTED || !recover || attempt >= 3) break;
         aborts++;
+        // a second time-out of the same sweep: the event-ordered per-panel kernels, which wait for nothing on the device (the switch is
+        // forced past HB_PIPELINE / HB_LOOKAHEAD / HB_DOTGROUP: a tuning variable must not turn the fall-back into a third try of the
+        // pipeline that just stalled twice)
+        bool per_panel = guard.fell_back;
+        if (attempt >= 1 && !guard.fell_back) {
+            (void)hb_ctx_get_pipeline(c, &guard.geo[0], &guard.geo[1], &guard.geo[2], &guard.geo[3]);
+            c->force_geometry = true;
+            const int rc2 = hb_ctx_set_pipeline(c, 0, 0, 1);
+            c->force_geometry = false;
+            if (rc2) return rc2;
+            guard.fell_back = true;
+            per_panel = c->pipeline == 0;
+        }
         fprintf(stderr, "hibayes_gpu: iteration %d: %s — state restored, replaying the sweep%s\n", iter + 1, hb_last_error(),
-                attempt >= 1 ? " on the per-panel kernels" : "");
+                per_panel ? " on the per-panel kernels" : "");
         rc = hb_ctx_restore(c);
         if (rc) return rc;
-        // (the replay waits as long as round 3's pipeline did: a wait that was merely slow — a shared or profiled GPU — then gets through)
-        c->timeout_ms = std::max(base_timeout, 3000);
+        // (the replay waits 3 s: a wait that was merely slow — a shared or profiled GPU — then gets through)
+        c->timeout_ms = std::max(c->timeout_ms, 3000);
         // a run that keeps aborting is on a slow device, not in a stall (those come once in a few thousand sweeps): wait longer from now on
         if (iter - abort_win_start > 64) { abort_win_start = iter; abort_win_count = 0; }
-        if (++abort_win_count >= 3) slow_timeout = std::min(3000, std::max(base_timeout, slow_timeout) * 4);
-        if (attempt >= 1 && !fell_back) {
-            (void)hb_ctx_get_pipeline(c, &saved_geo[0], &saved_geo[1], &saved_geo[2], &saved_geo[3]);
-            rc = hb_ctx_set_pipeline(c, 0, 0, 1);
-            if (rc) return rc;
-            fell_back = true;
-        }
-    }
-    c->timeout_ms = std::max(base_timeout, slow_timeout);
-    if (fell_back) {
-        const int rc2 = hb_ctx_set_pipeline(c, saved_geo[0], saved_geo[1], saved_geo[2]);
-        if (rc2) return rc2;
+        if (++abort_win_count >= 3) slow_timeout = std::min(3000, std::max(100, slow_timeout) * 4);
     }
     if (rc) return rc;
     events_sum += so.n_events;
@@ -972,6 +1047,19 @@ int hb_run::finish(hb_bayes_out *o)
         }
         for (int k = 0; k < n; k++) e[k] -= xa[k];
     }
+    { // the state after the last iteration (hb_bayes_out.last), before Pi becomes its posterior mean below
+        o->last = hb_warm_state{};
+        o->last.mu = mu;
+        o->last.vare = vare_;
+        o->last.varg = varg;
+        o->last.lambda2 = lambda2;
+        for (int j = 0; j < n_fold; j++) o->last.pi[cls_of[j]] = Pi[j];
+        o->last.vargL = o->vargL_last;
+        if (o->g_last || o->vargL_last) {
+            rc = hb_ctx_get_effects(c, o->g_last, nullptr, o->vargL_last);
+            if (rc) return rc;
+        }
+    }
     if (!fixpi) {
         for (int j = 0; j < n_fold; j++) Pi[j] = pi_sum[j] / Rn;
     } else { // :979-983
@@ -1086,6 +1174,7 @@ int hb_run_state(hb_run *r, hb_run_info *info)
     info->mean_redo = r->iter > 0 ? r->redo_sum / r->iter : 0.0;
     info->sweeps_replayed = r->aborts;
     info->reserved_ = 0;
+    info->lambda2 = r->lambda2;
     info->loop_seconds = r->loop_seconds;
     info->setup_seconds = r->setup_seconds;
     info->gram_seconds = r->gram_seconds;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HB_ABI_VERSION 5
+#define HB_ABI_VERSION 6
 #define HB_MAX_FOLD 8
 
 typedef enum {
@@ -78,6 +78,23 @@ typedef int (*hb_interrupt_fn)(void *user);
 /* console lines the reference prints through Rcpp::Rcout (src/Bayes.cpp:393-461, :884-914,
  * :1042-1091); NULL = print to stdout when verbose */
 typedef void (*hb_log_fn)(const char *line, void *user);
+
+/* The scalars (and BayesL's per-marker variances) the loop at src/Bayes.cpp:477 carries from one iteration to the next, beside the
+ * effects g: what hb_run_state() reports after an iteration is what a second run needs — together with g_init = the effects — to go
+ * on in the same regime (same markers in the model, same pi / marker variance / residual variance) rather than re-admit markers from
+ * the prior defaults for its first sweeps. The prior's own constants (s2varg_, dfvara_, s2vare_, rate0 ...: :319-374) are still
+ * derived from the arguments exactly as in a cold run. Draws are addressed by (seed, iteration, marker) from iteration 0 of the
+ * new run. bench.py's side legs and the stationary-state parity tests (tests/test_gpu_configs.py) start runs this way; the oracle
+ * takes the same state (hbo_args.warm). */
+typedef struct hb_warm_state {
+    double mu;               /* intercept (:469)                                           */
+    double vare;             /* residual variance vare_ (:823)                             */
+    double varg;             /* shared marker variance (RR / C / R: :603, :713, :807); ignored by A / B / L */
+    double lambda2;          /* BayesL (:738-741); ignored elsewhere                       */
+    double pi[HB_MAX_FOLD];  /* class proportions in the CALLER's class order (as hb_run_info.pi); used unless the model fixes pi
+                                (BayesB / BayesC, :669 / :716) or has none (RR / A / L)   */
+    const double *vargL;     /* BayesL: m per-marker variances (:730), NULL = the prior's fill (:364-368) */
+} hb_warm_state;
 
 /* ------------------------------------------------------------------------------------
  * Arguments of Bayes(), reference src/Bayes.cpp:60-88, same order.
@@ -166,7 +183,11 @@ typedef struct hb_bayes_args {
      * pipeline), so it scales capacity, not throughput. Needs precise = 2; covariates / random effects are refused here. */
     int32_t shard_rows;
     int64_t n_global, row_offset;
+    /* Warm hyper-parameter state (ABI 6; no reference counterpart): with g_init, the state a chain is CONTINUED from instead of
+     * started at the prior defaults of src/Bayes.cpp:319-374. NULL = the reference's start. See hb_warm_state above. */
+    const hb_warm_state *warm;
 } hb_bayes_args;
+
 
 /* number of doubles exchanged per sweep for n individuals: the residual delta (u moves by its negative) + 16 scalar sums */
 size_t hb_exchange_count(int32_t n);
@@ -207,6 +228,12 @@ typedef struct hb_bayes_out {
     double mean_events;      /* mean number of markers whose effect changed per sweep     */
     int32_t sweeps_replayed; /* (ABI 5) sweeps that timed out on the device and were replayed from the saved state */
     int32_t reserved_;
+    /* (ABI 6) the chain's state after its LAST iteration — what hb_bayes_args.g_init / .warm of a following run take to continue it:
+     * the scalars in `last` (last.vargL is set to vargL_last), the effects in g_last (m, caller-allocated or NULL) and, for BayesL,
+     * the per-marker variances in vargL_last (m, caller-allocated or NULL). */
+    hb_warm_state last;
+    double *g_last;
+    double *vargL_last;
 } hb_bayes_out;
 
 /* The whole sampler: replaces Bayes() (reference src/Bayes.cpp:60-1094). */
@@ -229,6 +256,7 @@ typedef struct hb_run_info {
     double loop_seconds, setup_seconds, gram_seconds;
     int32_t sweeps_replayed; /* (ABI 5) sweeps whose device pipeline timed out and that were replayed from the saved state (HB_ERR_ABORTED) */
     int32_t reserved_;
+    double lambda2;          /* (ABI 6) BayesL's lambda^2 after the last iteration (hb_warm_state.lambda2) */
 } hb_run_info;
 int hb_run_create(const hb_bayes_args *args, hb_run **out);
 int hb_run_step(hb_run *r, int32_t nsteps, int32_t *finished);

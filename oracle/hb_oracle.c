@@ -27,29 +27,166 @@
 /* ---------------------------------------------------------------------------------- */
 static int g_threads = 1;
 
-/* ddot_/daxpy_ stand-ins (reference src/hibayes.h:21-29 declares the BLAS symbols). */
+/* ddot_/daxpy_ stand-ins (reference src/hibayes.h:21-29 declares the BLAS symbols).
+ *
+ * Threaded form = what a threaded BLAS amounts to for n-long level-1 calls: ONE persistent team of workers for the whole run
+ * (created in hbo_bayes, never forked/joined per call), every worker owning a fixed chunk of the rows, woken by a generation
+ * word it spins on, handing its partial sum back through its own cache line; the partial sums are combined in a two-level tree
+ * (groups of 8) in a fixed order, so a threaded run is deterministic for a given thread count. Rounds 1-4 used an
+ * `omp parallel for` per call, whose fork/join (and the passive wait policy the bench set) cost more than the 400 KB a call
+ * streams: 64 threads ran ten times SLOWER than one. */
+#include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define HBO_PAUSE() _mm_pause()
+#else
+#define HBO_PAUSE() ((void)0)
+#endif
+
+#define HBO_TEAM_GROUP 8
+typedef struct {
+    _Alignas(128) atomic_ulong gen;  /* generation this worker has FINISHED (written by the worker only) */
+    double part;                     /* its partial dot (groups: the leader's slot holds the group's sum in gsum) */
+    double gsum;
+    atomic_ulong ggen;               /* generation whose GROUP sum is in gsum (leaders only) */
+    char pad[128 - 2 * sizeof(atomic_ulong) - 2 * sizeof(double)];
+} team_slot_t;
+
+typedef struct {
+    int nthreads, n;
+    pthread_t *tid;
+    team_slot_t *slot;
+    _Alignas(128) atomic_ulong go;   /* generation the master has POSTED */
+    /* the posted job */
+    int op;                          /* 0 dot, 1 axpy, 2 quit */
+    const double *x;
+    const double *yc;
+    double *y;
+    double a;
+} team_t;
+
+typedef struct { team_t *t; int id; } team_arg_t;
+static team_t *g_team = NULL;
+
+static inline void team_wait(atomic_ulong *w, unsigned long want)
+{
+    for (unsigned spins = 0; atomic_load_explicit(w, memory_order_acquire) != want; spins++) {
+        if ((spins & 1023) == 1023) sched_yield();   /* oversubscribed box: let the thread we wait for run */
+        else HBO_PAUSE();
+    }
+}
+
+static inline void team_range(const team_t *t, int id, int *lo, int *hi)
+{   /* chunks in multiples of 8 doubles (one cache line), the same for every call: a worker's rows stay in ITS cache */
+    const long lines = ((long)t->n + 7) / 8;
+    const long l0 = lines * id / t->nthreads, l1 = lines * (id + 1) / t->nthreads;
+    *lo = (int)(l0 * 8);
+    *hi = (int)(l1 * 8 > t->n ? t->n : l1 * 8);
+}
+
+static double team_do(team_t *t, int id, unsigned long gen)
+{
+    int lo, hi;
+    team_range(t, id, &lo, &hi);
+    double s = 0.0;
+    if (t->op == 0) {
+        const double *x = t->x, *y = t->yc;
+#pragma omp simd reduction(+ : s)
+        for (int i = lo; i < hi; i++) s += x[i] * y[i];
+    } else if (t->op == 1) {
+        const double a = t->a, *x = t->x;
+        double *y = t->y;
+#pragma omp simd
+        for (int i = lo; i < hi; i++) y[i] += a * x[i];
+    }
+    team_slot_t *me = &t->slot[id];
+    me->part = s;
+    atomic_store_explicit(&me->gen, gen, memory_order_release);
+    if (id % HBO_TEAM_GROUP == 0) { /* group leader: its members' partial sums, in member order */
+        double g = s;
+        for (int k = id + 1; k < id + HBO_TEAM_GROUP && k < t->nthreads; k++) {
+            team_wait(&t->slot[k].gen, gen);
+            g += t->slot[k].part;
+        }
+        me->gsum = g;
+        atomic_store_explicit(&me->ggen, gen, memory_order_release);
+    }
+    return s;
+}
+
+static void *team_worker(void *p)
+{
+    team_arg_t *ta = (team_arg_t *)p;
+    team_t *t = ta->t;
+    const int id = ta->id;
+    for (unsigned long gen = 1;; gen++) {
+        team_wait(&t->go, gen);
+        if (t->op == 2) break;
+        team_do(t, id, gen);
+    }
+    return NULL;
+}
+
+static team_arg_t *g_team_args = NULL;
+static void team_start(int nthreads, int n)
+{
+    team_t *t = (team_t *)aligned_alloc(128, sizeof(team_t));
+    memset(t, 0, sizeof(*t));
+    t->nthreads = nthreads;
+    t->n = n;
+    t->slot = (team_slot_t *)aligned_alloc(128, sizeof(team_slot_t) * nthreads);
+    memset(t->slot, 0, sizeof(team_slot_t) * nthreads);
+    t->tid = (pthread_t *)calloc(nthreads, sizeof(pthread_t));
+    g_team_args = (team_arg_t *)calloc(nthreads, sizeof(team_arg_t));
+    for (int i = 1; i < nthreads; i++) {
+        g_team_args[i].t = t;
+        g_team_args[i].id = i;
+        pthread_create(&t->tid[i], NULL, team_worker, &g_team_args[i]);
+    }
+    g_team = t;
+}
+
+static double team_run(team_t *t, int op, double a, const double *x, const double *yc, double *y)
+{
+    t->op = op; t->a = a; t->x = x; t->yc = yc; t->y = y;
+    const unsigned long gen = atomic_load_explicit(&t->go, memory_order_relaxed) + 1;
+    atomic_store_explicit(&t->go, gen, memory_order_release);
+    if (op == 2) return 0.0;
+    team_do(t, 0, gen);                       /* the master is worker 0 and the leader of group 0 */
+    double s = t->slot[0].gsum;
+    for (int g = HBO_TEAM_GROUP; g < t->nthreads; g += HBO_TEAM_GROUP) {
+        team_wait(&t->slot[g].ggen, gen);     /* (also the completion barrier of an axpy) */
+        s += t->slot[g].gsum;
+    }
+    return s;
+}
+
+static void team_stop(void)
+{
+    team_t *t = g_team;
+    if (!t) return;
+    team_run(t, 2, 0.0, NULL, NULL, NULL);
+    for (int i = 1; i < t->nthreads; i++) pthread_join(t->tid[i], NULL);
+    free(t->tid); free(t->slot); free(t); free(g_team_args);
+    g_team = NULL; g_team_args = NULL;
+}
+
 double hbo_ddot(int n, const double *x, const double *y)
 {
+    if (g_team && n == g_team->n) return team_run(g_team, 0, 0.0, x, y, NULL);
     double s = 0.0;
-    if (g_threads > 1 && n >= 16384) {
-#pragma omp parallel for simd reduction(+ : s) num_threads(g_threads) schedule(static)
-        for (int i = 0; i < n; i++) s += x[i] * y[i];
-    } else {
 #pragma omp simd reduction(+ : s)
-        for (int i = 0; i < n; i++) s += x[i] * y[i];
-    }
+    for (int i = 0; i < n; i++) s += x[i] * y[i];
     return s;
 }
 
 static void hbo_daxpy(int n, double a, const double *x, double *y)
 {
-    if (g_threads > 1 && n >= 16384) {
-#pragma omp parallel for simd num_threads(g_threads) schedule(static)
-        for (int i = 0; i < n; i++) y[i] += a * x[i];
-    } else {
+    if (g_team && n == g_team->n) { team_run(g_team, 1, a, x, NULL, y); return; }
 #pragma omp simd
-        for (int i = 0; i < n; i++) y[i] += a * x[i];
-    }
+    for (int i = 0; i < n; i++) y[i] += a * x[i];
 }
 
 static double ddot_i8(int n, const int8_t *x, const double *y)
@@ -377,8 +514,21 @@ int hbo_bayes(const hbo_args *a, hbo_out *o)
     if (a->rng_kind == HBO_RNG_R) hbo_stream_init_r(&glob, (uint32_t)a->seed);
     mdraw_t md = {a->rng_kind, &glob, a->seed, 0, a->marker_offset};
 
+    /* ---- warm state (not in the reference; hbo_warm): the prior constants above stay the cold run's ---- */
+    if (a->warm) {
+        vare_ = a->warm->vare;
+        if (model_index == 1 || model_index == 4 || model_index == 6) varg = a->warm->varg;
+        if (model_index == 6) for (int j = 0; j < n_fold; j++) vara_fold[j] = varg * fold_[j];
+        if (model_index == 5) {
+            lambda2 = a->warm->lambda2;
+            lambda = sqrt(lambda2);
+            if (a->warm->vargL) for (int i = 0; i < m; i++) vargL[i] = a->warm->vargL[i];
+        }
+        if (!fixpi) for (int j = 0; j < n_fold; j++) Pi[j] = a->warm->pi[j];
+    }
+
     /* ---- :469-472 ---- */
-    double mu_, mu = arma_sum(y, n) / n;
+    double mu_, mu = a->warm ? a->warm->mu : arma_sum(y, n) / n;
     double *yadj = (double *)malloc(sizeof(double) * n);
     for (int i = 0; i < n; i++) yadj[i] = y[i] - mu;
     double *one = (double *)malloc(sizeof(double) * n);
@@ -397,6 +547,7 @@ int hbo_bayes(const hbo_args *a, hbo_out *o)
 
     double xx, oldgi, gi, gi_, rhs, lhs, logdetV, acceptProb, uhat, v, vargi;
     int indistflag;
+    if (g_threads > 1 && n >= 16384) team_start(g_threads, n); /* the threaded-BLAS stand-in: one team for the whole loop */
     double t_start = now_sec();
     int iter;
 
@@ -722,7 +873,14 @@ int hbo_bayes(const hbo_args *a, hbo_out *o)
         if (count == n_records) { iter++; break; }
     }
     o->loop_seconds = now_sec() - t_start;
+    team_stop();
     o->iters_done = iter;
+    memset(&o->last, 0, sizeof(o->last));
+    o->last.mu = mu; o->last.vare = vare_; o->last.varg = varg; o->last.lambda2 = lambda2;
+    for (int j = 0; j < n_fold && j < 8; j++) o->last.pi[j] = Pi[j];
+    o->last.vargL = o->vargL_last;
+    if (o->g_last) memcpy(o->g_last, g, sizeof(double) * m);
+    if (o->vargL_last && vargL) memcpy(o->vargL_last, vargL, sizeof(double) * m);
 
     /* ============================ posterior assembly, :919-1040 ============================ */
     const double R = (double)n_records;

@@ -39,6 +39,14 @@ extern "C" {
 /* model_index as at src/Bayes.cpp:97 */
 enum { HBO_RR = 1, HBO_A = 2, HBO_B = 3, HBO_C = 4, HBO_L = 5, HBO_R = 6 };
 
+/* warm hyper-parameter state (mirrors hb_warm_state of include/hibayes_gpu.h field for field; not in the reference): the scalars
+ * the loop at src/Bayes.cpp:477 carries between iterations, for a chain CONTINUED from (g_init, warm) */
+typedef struct {
+    double mu, vare, varg, lambda2;
+    double pi[8];
+    const double *vargL;      /* BayesL: m, or NULL */
+} hbo_warm;
+
 typedef struct {
     /* --- data: mirrors the Bayes() argument list, src/Bayes.cpp:60-88 --- */
     int32_t n, m;
@@ -70,6 +78,7 @@ typedef struct {
     /* warm start (mirrors hb_bayes_args.g_init of the GPU library; not in the reference): m effects the chain
      * starts from; entries of monomorphic markers are taken as 0 */
     const double *g_init;
+    const hbo_warm *warm;     /* NULL = the reference's start (:319-374, :469) */
 } hbo_args;
 
 typedef struct {
@@ -101,6 +110,10 @@ typedef struct {
     double loop_seconds;
     int32_t iters_done;
     char error[256];
+    /* the chain after its last iteration (mirrors hb_bayes_out.last / g_last / vargL_last): what g_init + warm of a following run take */
+    hbo_warm last;
+    double *g_last;      /* m or NULL */
+    double *vargL_last;  /* m or NULL (BayesL) */
 } hbo_out;
 
 /* Full sampler. Returns 0 on success; non-zero with out->error set to the

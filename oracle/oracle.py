@@ -34,7 +34,26 @@ class _Args(C.Structure):
         ("trace_iter", C.c_int32),
         ("trace_rhs", C.c_void_p), ("trace_cls", C.c_void_p), ("trace_g", C.c_void_p),
         ("g_init", C.c_void_p),
+        ("warm", C.c_void_p),
     ]
+
+
+class Warm(C.Structure):
+    """hbo_warm == hb_warm_state (include/hibayes_gpu.h), field for field."""
+    _fields_ = [("mu", C.c_double), ("vare", C.c_double), ("varg", C.c_double), ("lambda2", C.c_double),
+                ("pi", C.c_double * 8), ("vargL", C.c_void_p)]
+
+
+def make_warm(mu, vare, varg=0.0, pi=(), lambda2=0.0, vargL=None):
+    w = Warm()
+    w.mu, w.vare, w.varg, w.lambda2 = float(mu), float(vare), float(varg), float(lambda2)
+    for j, p in enumerate(pi):
+        w.pi[j] = float(p)
+    w._keep = None
+    if vargL is not None:
+        w._keep = np.ascontiguousarray(vargL, dtype=np.float64)
+        w.vargL = w._keep.ctypes.data
+    return w
 
 
 class _Out(C.Structure):
@@ -53,6 +72,7 @@ class _Out(C.Structure):
         ("xpx", C.c_void_p), ("vx", C.c_void_p),
         ("loop_seconds", C.c_double), ("iters_done", C.c_int32),
         ("error", C.c_char * 256),
+        ("last", Warm), ("g_last", C.c_void_p), ("vargL_last", C.c_void_p),
     ]
 
 
@@ -207,7 +227,7 @@ def _nan(v):
 def bayes(y, X, model, Pi, fold=None, Cmat=None, R=None, niter=50000, nburn=20000, thin=5,
           dfvr=None, s2vr=None, vg=None, dfvg=None, s2vg=None, ve=None, dfve=None, s2ve=None,
           windindx=None, threads=1, rng=RNG_PHILOX, seed=666666, marker_offset=0,
-          store_alpha=False, trace_iter=None, g_init=None):
+          store_alpha=False, trace_iter=None, g_init=None, warm=None):
     """Mirror of reference Bayes() (src/Bayes.cpp:60-88). X: n x m, float64 or int8."""
     L = lib()
     y = np.ascontiguousarray(y, dtype=np.float64)
@@ -263,6 +283,11 @@ def bayes(y, X, model, Pi, fold=None, Cmat=None, R=None, niter=50000, nburn=2000
         assert gi.size == m
         a.g_init = gi.ctypes.data
         keep.append(gi)
+    if warm is not None:   # a Warm (make_warm) or a dict of its arguments
+        if isinstance(warm, dict):
+            warm = make_warm(**warm)
+        a.warm = C.addressof(warm)
+        keep.append(warm)
     a.rng_kind, a.seed, a.marker_offset = rng, seed, marker_offset
     nrec = max((niter - nburn) // thin, 0)
     o = _Out()
@@ -289,6 +314,9 @@ def bayes(y, X, model, Pi, fold=None, Cmat=None, R=None, niter=50000, nburn=2000
     o.s_pi = buf("s_pi", (Pi.size, nrec))
     o.s_Vr = buf("s_Vr", (nr, nrec)) if nr else None
     o.xpx, o.vx = buf("xpx", m), buf("vx", m)
+    o.g_last = buf("g_last", m)
+    if model == "BayesL":
+        o.vargL_last = buf("vargL_last", m)
     if trace_iter is not None:
         a.trace_iter = trace_iter
         a.trace_rhs = buf("trace_rhs", m)
@@ -303,6 +331,10 @@ def bayes(y, X, model, Pi, fold=None, Cmat=None, R=None, niter=50000, nburn=2000
         res[k] = getattr(o, k)
     if nr:
         res["r"] = res["r"][: o.n_levels]
+    lw = {"mu": o.last.mu, "vare": o.last.vare, "varg": o.last.varg, "lambda2": o.last.lambda2, "pi": [o.last.pi[j] for j in range(Pi.size)]}
+    if model == "BayesL":
+        lw["vargL"] = res.pop("vargL_last")
+    res["last"] = {"g": res.pop("g_last"), "warm": lw}   # bayes(..., g_init=last["g"], warm=last["warm"]) continues the chain
     del keep
     return res
 

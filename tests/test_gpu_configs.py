@@ -89,6 +89,19 @@ def test_config2_bayescpi_n10k_m100k_pipeline_vs_serial():
         assert a["timing"]["mean_events"] > 100
 
 
+def test_config2_bayescpi_n10k_m100k_against_live_oracle():
+    """BASELINE.json configs[1] at its own size against the LIVE oracle (rounds 1-4 compared the pipeline with the per-panel kernels
+    there, i.e. HIP with HIP): 12 sweeps from cold on the library's default geometry, 2-bit genotypes, geometry by regime."""
+    _full_size_vs_oracle(10000, 100000, "BayesCpi", [0.95, 0.05], None, (1, 3, 7), 0, niter=12, bits=2, adaptive=True)
+
+
+def test_config4_shard_bayescpi_n50k_m250k_offset_750k_against_live_oracle():
+    """BASELINE.json configs[3], rank 3 of 8: global markers [750 000, 1 000 000) of m_global = 2M — the per-marker Philox streams are
+    addressed by the GLOBAL marker index (hb_ctx_params.m_offset / hbo_args.marker_offset), which only this case exercises at size
+    against the oracle. 2 sweeps from cold, int8 columns, the library's default geometry for them."""
+    _full_size_vs_oracle(50000, 250000, "BayesCpi", [0.95, 0.05], None, (1, 2, 7), 750000, niter=2)
+
+
 def test_config4_shard_shape_bayescpi_n50k_m250k_pipeline_vs_serial():
     # rank 3 of 8 of config 4: global markers [750000, 1000000) of m_global = 2M (RNG addressed by global index)
     n, m = 50000, 250000
@@ -116,10 +129,14 @@ def c3():
     c.close()
 
 
-def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=2, dense=0.0, shared=None, bits=8):
+def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=2, dense=0.0, shared=None, bits=8, adaptive=False, stationary=0):
     """dense > 0: the chain starts from an installed state with that fraction of the markers in the model (g_init on both
     sides): crowded rounds, row-cache misses and band folds of hundreds of moves per mat-vec group from the first panel on.
-    bits = 2: the sweep runs on the 2-bit resident layout with the int8 copy dropped after the Gram build, as bench.py's headline does."""
+    bits = 2: the sweep runs on the 2-bit resident layout with the int8 copy dropped after the Gram build, as bench.py's headline does.
+    stationary = S > 0: the GPU first runs S sweeps on its own (no oracle: hundreds of sweeps at this size are minutes of CPU), then
+    BOTH sides start from the state it reports — effects, mu, vare, varg, pi (hb_bayes_out.last -> g_init + hb_warm_state / hbo_warm) —
+    and run `niter` sweeps under a new seed: draw-for-draw parity IN the regime a long run lives in and bench.py times (few markers in
+    the model, the wide geometry, hot list and row cache shaped by history), not from a synthetic start."""
     kw = dict(fold=fold, niter=niter, nburn=0, thin=1, seed=20240901)
     if shared is None:
         need = n * m / 1e9 + 8
@@ -137,14 +154,26 @@ def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=
             c.build_gram()
             c.set_layout(2, keep_int8=False)
             assert c.layout() == (2, False)
+        if adaptive:
+            c.set_adaptive(True)
         if dense > 0:
             rs = np.random.default_rng(23)
             g0 = np.zeros(m)
             on = rs.choice(m, int(dense * m), replace=False)
             g0[on] = rs.normal(0, 0.01, on.size)
             kw["g_init"] = g0
+        if stationary > 0:
+            pre = H.Bayes(y, None, model, Pi, verbose=False, precise=precise, ctx=c, store_alpha=False,
+                          **dict(kw, niter=stationary, nburn=stationary - 1, seed=777))
+            kw["g_init"], kw["warm"] = pre["last"]["g"], pre["last"]["warm"]
+            nnz_pre = int((pre["last"]["g"] != 0).sum())
+            print("%s n=%d m=%d: state after %d GPU sweeps: %d markers in the model, pi %s, varg %.3g, vare %.4f, %.0f moves per sweep"
+                  % (model, n, m, stationary, nnz_pre, np.round(pre["last"]["warm"]["pi"], 5), pre["last"]["warm"]["varg"],
+                     pre["last"]["warm"]["vare"], pre["timing"]["mean_events"]))
         r = H.Bayes(y, None, model, Pi, verbose=False, precise=precise, ctx=c, store_alpha=False, **kw)
-        assert c.pipeline()[:3] == geo and c.layout()[0] == bits
+        assert (adaptive or c.pipeline()[:3] == geo) and c.layout()[0] == bits
+        if adaptive:
+            c.set_adaptive(False)
         invariants(c, y, r)
         g_gpu, trk, _ = c.get_effects()
         if X is None:
@@ -176,6 +205,14 @@ def test_config3_bayesr_n50k_m500k_draw_for_draw_against_live_oracle(c3):
     """BASELINE.json configs[2] is BayesR at n=50k, m=500k: its own model, at its own size and default geometry, against the
     live oracle (reference src/Bayes.cpp:743-815) — 2 sweeps from cold, ~47 moves per panel."""
     _full_size_vs_oracle(50000, 500000, "BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 0, shared=c3)
+
+
+@pytest.mark.parametrize("model,Pi,fold,geo,bits,sweeps", [("BayesCpi", [0.95, 0.05], None, (1, 3, 7), 2, 300),
+                                                           ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 8, 150)])
+def test_config3_stationary_state_against_live_oracle(c3, model, Pi, fold, geo, bits, sweeps):
+    """n = 50k, m = 500k IN the regime `value` is measured in: 300 sweeps of burn-in on the GPU (bench.py's own --burnin; BayesR 150),
+    then 2 sweeps on both sides from the reported state."""
+    _full_size_vs_oracle(50000, 500000, model, Pi, fold, geo, 0, niter=2, shared=c3, bits=bits, adaptive=(bits == 2), stationary=sweeps)
 
 
 @pytest.mark.parametrize("model,Pi,fold,geo", [("BayesCpi", [0.95, 0.05], None, (1, 3, 7)),

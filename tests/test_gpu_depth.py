@@ -305,3 +305,70 @@ def test_dense_update_rows_are_the_old_update_rows_bit_for_bit(big, monkeypatch)
         assert np.array_equal(np.asarray(r_new[k]), np.asarray(r_old[k])), k
     assert np.array_equal(r_new["MCMCsamples"]["alpha"], r_old["MCMCsamples"]["alpha"])
     np.testing.assert_allclose(r_new["e"], r_old["e"], rtol=0, atol=1e-10)   # (X * alpha sums its column blocks with atomics: last bits)
+
+
+LONG = [  # model, Pi, fold, geometry, resident bits, adaptive geometry, markers, sweeps, tolerance
+    ("BayesCpi", [0.95, 0.05], None, (1, 3, 7), 2, True, 32768, 200, 1e-7),
+    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 8, False, 32768, 200, 1e-7),
+    ("BayesRR", [0.95, 0.05], None, (1, 2, 2), 8, False, 8192 + 100, 100, 1e-7),
+]
+
+
+@pytest.mark.parametrize("model,Pi,fold,geo,bits,adaptive,mcols,niter,tol", LONG)
+def test_long_chain_draw_for_draw_at_pipeline_depth(big, model, Pi, fold, geo, bits, adaptive, mcols, niter, tol):
+    """The reference runs 20 000 iterations by default (R/bayes.r:264-269, the loop at src/Bayes.cpp:477); rounds 1-4 compared at
+    most 16 sweeps at pipeline depth. Here 200 (the dense model: 100) at n = 2 048 x m = 32 768, panel 512, against the live oracle
+    draw for draw: BayesCpi on 2-bit genotypes with the geometry chosen by regime — the cold start's narrow band, the switch to
+    (3, 7), then 150+ sweeps in the stationary regime the bench's `value` is measured in (k_chain_group + k_fwd, the wrap of the
+    correction ring hundreds of times over); BayesR under its hot list / row cache / k_warm as the model empties (entry
+    prediction, cache churn); BayesRR on k_chain_dense + k_fold_dense. Every stored record (nburn = niter / 2, thin 5), the PIP
+    counters of every post-burn iteration, and the final state."""
+    X, y = big["X"][:, :mcols], big["y"]
+    m = X.shape[1]
+    kw = dict(fold=fold, niter=niter, nburn=niter // 2, thin=5, seed=8086)
+    ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, **kw)
+    with H.Context(X.shape[0], m, panel=512, seed=8086) as c:
+        c.upload(X)
+        c.set_pipeline(*geo)
+        c.build_gram()
+        if adaptive:
+            c.set_adaptive(True)
+        if bits == 2:
+            c.set_layout(2, keep_int8=False)
+        r = H.Bayes(y, None, model, Pi, verbose=False, ctx=c, **kw)
+        geo_end = c.pipeline()[:3]
+        assert c.layout()[0] == bits
+    assert r["MCMCsamples"]["alpha"].shape[1] == niter // 2 // 5
+    _compare(r, ref, tol=tol)
+    np.testing.assert_allclose(r["last"]["g"], ref["last"]["g"], rtol=tol, atol=1e-13)
+    for k in ("mu", "vare", "varg"):
+        assert r["last"]["warm"][k] == pytest.approx(ref["last"]["warm"][k], rel=tol), k
+    np.testing.assert_allclose(r["last"]["warm"]["pi"], ref["last"]["warm"]["pi"], rtol=tol)
+    err = np.max(np.abs(r["MCMCsamples"]["alpha"] - ref["s_alpha"])) / np.max(np.abs(ref["s_alpha"]))
+    print("%s: %d sweeps, %d records, max |alpha - oracle| / max |alpha| = %.2e, %.1f moves per sweep, geometry at the end %s"
+          % (model, niter, niter // 2 // 5, err, r["timing"]["mean_events"], geo_end))
+    if adaptive:
+        assert geo_end == geo          # the run ended in the wide geometry: the stationary regime was reached and run in
+
+
+@pytest.mark.parametrize("model,Pi,fold", [("BayesCpi", [0.95, 0.05], None), ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2]),
+                                            ("BayesL", [0.95, 0.05], None)])
+def test_continued_chain_is_the_oracles_continued_chain(big, model, Pi, fold):
+    """hb_bayes_args.warm + g_init (ABI 6): a run continued from the state another run reported. Both sides run 30 sweeps, hand
+    their OWN last state (effects, mu, vare, varg, pi, BayesL's lambda2 and per-marker variances) to a second run of 6 sweeps under a
+    new seed: the second runs agree draw for draw, i.e. the state crosses the boundary completely on both sides."""
+    mc = 8192 + 100
+    X, y = big["X"][:, :mc], big["y"]
+    tol = 1e-6 if model == "BayesL" else 1e-9
+    k1 = dict(fold=fold, niter=30, nburn=29, thin=1, seed=4004)
+    k2 = dict(fold=fold, niter=6, nburn=0, thin=1, seed=6502)
+    ref1 = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, **k1)
+    ref2 = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, g_init=ref1["last"]["g"], warm=ref1["last"]["warm"], **k2)
+    r1 = H.Bayes(y, X, model, Pi, verbose=False, **k1)
+    _compare(r1, ref1, tol=tol)
+    r2 = H.Bayes(y, X, model, Pi, verbose=False, g_init=r1["last"]["g"], warm=r1["last"]["warm"], **k2)
+    _compare(r2, ref2, tol=10 * tol)
+    # and it IS a continuation: the first sweep of the second run moves about as many markers as the last of the first
+    if model == "BayesCpi":
+        nnz1 = int((r1["last"]["g"] != 0).sum())
+        assert abs(int((r2["MCMCsamples"]["alpha"][:, 0] != 0).sum()) - nnz1) < max(20, nnz1)

@@ -181,3 +181,66 @@ def test_oracle_reproduces_the_fit_printed_in_the_reference_readme(demo):
     assert sig(np.quantile(r["e"], [0, .25, .5, .75, 1]), 5) == [-8.6113, -2.2907, 0.17169, 2.3326, 9.7695]
     assert sig(np.quantile(r["alpha"], [0, .25, .5, .75, 1]), 6) == [-1.98438, -0.0242465, 0.0, 0.0253073, 1.9202]
     assert len(r["r"]) == 50 + 150 and r["alpha"].size == 1000              # "group: loc, 50; dam, 150", "Number of markers: 1000"
+
+
+def _arma_mean(y):
+    # arma::mean's two interleaved accumulators (the start value of mu, src/Bayes.cpp:469)
+    return (y[0::2].cumsum()[-1] + y[1::2].cumsum()[-1]) / y.size
+
+
+WARM_MODELS = [("BayesCpi", [0.95, 0.05], None), ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2]), ("BayesL", [0.95, 0.05], None),
+               ("BayesRR", [0.95, 0.05], None), ("BayesA", [0.95, 0.05], None), ("BayesB", [0.9, 0.1], None)]
+
+
+@pytest.mark.parametrize("model,Pi,fold", WARM_MODELS)
+def test_warm_state_equal_to_the_prior_defaults_is_the_cold_chain(demo, model, Pi, fold):
+    """hbo_args.warm (the oracle's side of hb_warm_state) only replaces the START values of the scalars the loop carries
+    (src/Bayes.cpp:319-374, :469); handing it exactly the cold run's start values must reproduce the cold chain bit for bit —
+    which pins that nothing else (the prior constants s2varg_, rate0 ...) moved."""
+    y, X = demo["y"], demo["M"][:, :300]
+    kw = dict(fold=fold, niter=6, nburn=0, thin=1, seed=3, store_alpha=True)
+    a = O.bayes(y, X, model, Pi, **kw)
+    w = dict(mu=_arma_mean(y), vare=a["vare0"], varg=a["varg0"], pi=Pi, lambda2=a["lambda2_0"])
+    b = O.bayes(y, X, model, Pi, warm=w, **kw)
+    assert np.array_equal(a["s_alpha"], b["s_alpha"])
+    for k in ("Vg", "Ve", "h2", "mu"):
+        assert a[k] == b[k]
+
+
+def test_a_continued_chain_starts_where_the_first_one_stopped(demo):
+    """`last` (effects + scalars after the final iteration) handed back as g_init + warm: the continued run's first sweep sees the
+    same markers in the model and the same pi / varg / vare — not the prior's pi = 0.95 that re-admits 5 % of the markers."""
+    y, X = demo["y"], demo["M"]
+    a = O.bayes(y, X, "BayesCpi", [0.95, 0.05], niter=400, nburn=399, thin=1, seed=11, store_alpha=True)
+    lw = a["last"]["warm"]
+    assert 0 < lw["pi"][0] < 1 and lw["vare"] > 0 and lw["varg"] > 0
+    assert lw["vare"] == a["Ve"] and lw["mu"] == a["mu"]        # one stored record, the last iteration: its scalars ARE the last state
+    assert lw["pi"][0] == a["pi"][0]
+    assert np.array_equal(a["last"]["g"], a["s_alpha"][:, -1])
+    kw = dict(niter=1, nburn=0, thin=1, seed=12, store_alpha=True, g_init=a["last"]["g"])
+    cont = O.bayes(y, X, "BayesCpi", [0.95, 0.05], warm=lw, **kw)
+    cold = O.bayes(y, X, "BayesCpi", [0.95, 0.05], **kw)
+    # same effects, same draws, different hyper-parameters in the first sweep: the two differ, and the continued one is the one
+    # whose first intercept draw started from the reported mu
+    assert not np.array_equal(cont["s_alpha"], cold["s_alpha"])
+    assert cont["last"]["warm"]["mu"] != lw["mu"]
+
+
+def test_threaded_team_is_the_serial_sampler():
+    """threads > 1: the BLAS-1 calls of n >= 16384 run on ONE persistent team of row-chunk workers (hb_oracle.c team_*), partial sums
+    combined in a fixed two-level order — the same chain as one thread up to the summation order of a dot product."""
+    rng = np.random.default_rng(4)
+    n, m = 16400, 60
+    p = rng.uniform(0.05, 0.5, m)
+    X = np.asfortranarray(((rng.random((n, m)) < p).astype(np.float64) + (rng.random((n, m)) < p)))
+    beta = np.zeros(m)
+    beta[:6] = rng.normal(0, 1, 6)
+    y = X @ beta + rng.normal(0, 1, n)
+    kw = dict(niter=5, nburn=0, thin=1, seed=5, store_alpha=True)
+    one = O.bayes(y, X, "BayesCpi", [0.9, 0.1], threads=1, **kw)
+    for thr in (3, 11):          # 11 threads: two groups of the tree, more threads than this container has cores
+        t = O.bayes(y, X, "BayesCpi", [0.9, 0.1], threads=thr, **kw)
+        assert np.array_equal(t["s_alpha"] != 0, one["s_alpha"] != 0)
+        np.testing.assert_allclose(t["s_alpha"], one["s_alpha"], rtol=1e-9, atol=1e-12)
+        again = O.bayes(y, X, "BayesCpi", [0.9, 0.1], threads=thr, **kw)
+        assert np.array_equal(again["s_alpha"], t["s_alpha"])   # deterministic for a given thread count
