@@ -25,10 +25,13 @@
 #define HBG_STAMP(i) do { if (v.dbg && t == 0) v.dbg[(size_t)gcount * 32 + (i)] = clock64(); } while (0)
 #define HBG_STAMP_ONCE(i) do { if (v.dbg && t == 0 && nround == 0) v.dbg[(size_t)gcount * 32 + (i)] = clock64(); } while (0)
 #define HBG_STAMP_VAL(i, x) do { if (v.dbg && t == 0) v.dbg[(size_t)gcount * 32 + (i)] = (x); } while (0)
+// per wave (round 5: which wave the others wait for at the first barrier of a group): words i .. i + 7
+#define HBG_WSTAMP(i) do { if (v.dbg && lane == 0) v.dbg[(size_t)gcount * 32 + (i) + wave] = clock64(); } while (0)
 #else
 #define HBG_STAMP(i) do { } while (0)
 #define HBG_STAMP_ONCE(i) do { } while (0)
 #define HBG_STAMP_VAL(i, x) do { } while (0)
+#define HBG_WSTAMP(i) do { } while (0)
 #endif
 // Template shape: HBG_DM = panels per group the register arrays are sized for (>= D), HBG_FW = panels ahead a move is folded into
 // (>= Lv * D), HBG_CH = moves whose rows are requested together — HBG_CH * (HBG_DM + HBG_FW) loads per lane and trip, ~60: a narrow
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         HBG_STAMP(1);
+        HBG_WSTAMP(24); // every wave: its dots are in hand
         const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP; // block l = 0 of the group's first panel
         const size_t pstep = (size_t)(pv.Lg + 2) * PP;                   // block l of panel p -> block l + 1 of panel p + 1
         // panels ahead that are owed the corrections by THIS workgroup (with k_fwd beside it: the next group's only)
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (lane == 0) wcnt[i * 8 + wave] = __popcll(cm);
             }
             if (t == 0) misc[1] = Dg * P;
+            if (nround == 0) HBG_WSTAMP(16); // every wave: at the group's first barrier
             __syncthreads(); // B1
             if (misc[2]) { ok = false; break; }
             int total, myscan;

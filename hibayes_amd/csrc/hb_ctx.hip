@@ -50,6 +50,27 @@ static int dev_alloc(T **p, size_t count, bool zero = true)
     return HB_OK;
 }
 
+// The few MB of words that one workgroup publishes write-through while workgroups on OTHER XCDs poll them (dots, correction sums,
+// changes of effect, move counts and lists, bounds, the flag block). HB_HANDOFF_ALLOC selects what kind of device memory they
+// live in: 0 = plain hipMalloc (coarse-grained: cached in every XCD's L2 — the polls and stores carry sc1 to get past it),
+// 1 = hipDeviceMallocUncached (MTYPE UC: no L2 copy anywhere, a store goes straight to the memory side), 2 = fine-grained
+// (coherent across agents). Round 5's experiment on the lost store of DESIGN.md §9.0; the arrays are small, the genotypes, Gram
+// blocks and everything streamed stay plain.
+static int g_handoff_kind = -1;
+template <typename T>
+static int dev_alloc_handoff(T **p, size_t count)
+{
+    if (g_handoff_kind < 0) {
+        const char *e = getenv("HB_HANDOFF_ALLOC");
+        g_handoff_kind = e ? std::max(0, std::min(2, atoi(e))) : 0;
+    }
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (g_handoff_kind == 0) HB_HIP(hipMalloc(reinterpret_cast<void **>(p), bytes));
+    else HB_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(p), bytes, g_handoff_kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
+    HB_HIP(hipMemset(*p, 0, bytes));
+    return HB_OK;
+}
+
 // normalise (pipeline, Lv, D) and derive the Gram band / version ring sizes
 static void hb_pipeline_geometry(hb_ctx *c)
 {
@@ -198,25 +219,25 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->rq, (size_t)c->ld * 8 * HB_ND));
     TRY(dev_alloc(&c->vexp, 8));
     TRY(dev_alloc(&c->gexp, (size_t)c->npanels + 1));
-    TRY(dev_alloc(&c->mb, ((size_t)c->npanels + 2) * HB_MBS));
+    TRY(dev_alloc_handoff(&c->mb, ((size_t)c->npanels + 2) * HB_MBS));
     TRY(dev_alloc(&c->accq, (size_t)HB_ND * mp));
     TRY(dev_alloc(&c->xinfo, 2));
     TRY(dev_alloc(&c->thr, mp * (HB_MAX_FOLD - 1)));
     TRY(dev_alloc(&c->invv, mp * (HB_MAX_FOLD - 1)));
     TRY(dev_alloc(&c->sdz, mp * (HB_MAX_FOLD - 1)));
     TRY(dev_alloc(&c->partial, mp * (size_t)c->nsplit));
-    TRY(dev_alloc(&c->dsum, mp));
-    TRY(dev_alloc(&c->fcorr, mp));
-    TRY(dev_alloc(&c->ddense, mp));
-    TRY(dev_alloc(&c->fcorr2, mp));
+    TRY(dev_alloc_handoff(&c->dsum, mp));
+    TRY(dev_alloc_handoff(&c->fcorr, mp));
+    TRY(dev_alloc_handoff(&c->ddense, mp));
+    TRY(dev_alloc_handoff(&c->fcorr2, mp));
     TRY(dev_alloc(&c->dots, mp));
-    TRY(dev_alloc(&c->ev_count, (size_t)c->npanels * HB_EVS));
-    TRY(dev_alloc(&c->ev_idx, mp));
-    TRY(dev_alloc(&c->ev_delta, mp));
+    TRY(dev_alloc_handoff(&c->ev_count, (size_t)c->npanels * HB_EVS));
+    TRY(dev_alloc_handoff(&c->ev_idx, mp));
+    TRY(dev_alloc_handoff(&c->ev_delta, mp));
     TRY(dev_alloc(&c->acc, HB_ACC_N));
     TRY(dev_alloc(&c->d_in, 1));
     TRY(dev_alloc(&c->scratch, 8192));
-    TRY(dev_alloc(&c->flags, (size_t)4096));
+    TRY(dev_alloc_handoff(&c->flags, (size_t)4096));
     TRY(dev_alloc(&c->hot_slot, mp));
     TRY(dev_alloc(&c->hot_list, (size_t)(c->npanels + 1) * 256));
     TRY(dev_alloc(&c->thr0f, mp + 1024));

@@ -13,7 +13,7 @@
  * The serial marker loop and the BLAS-1 shaped dot/axpy are kept on purpose: this file is
  * also the "port" CPU baseline that bench.py times beside the GPU.
  */
-#define _POSIX_C_SOURCE 200809L
+#define _GNU_SOURCE
 #include "hb_oracle.h"
 #include <math.h>
 #include <stdio.h>
@@ -46,34 +46,42 @@ static int g_threads = 1;
 #endif
 
 #define HBO_TEAM_GROUP 8
+/* one cache line per worker: what it hands back */
 typedef struct {
     _Alignas(128) atomic_ulong gen;  /* generation this worker has FINISHED (written by the worker only) */
-    double part;                     /* its partial dot (groups: the leader's slot holds the group's sum in gsum) */
-    double gsum;
-    atomic_ulong ggen;               /* generation whose GROUP sum is in gsum (leaders only) */
+    double part;                     /* its partial dot */
+    double gsum;                     /* leaders: the group's sum ... */
+    atomic_ulong ggen;               /* ... of this generation */
     char pad[128 - 2 * sizeof(atomic_ulong) - 2 * sizeof(double)];
 } team_slot_t;
-
+/* one cache line per GROUP: the posted job, copied down the tree (the master posts to the root line, the eight-or-so group leaders
+ * spin on that, each leader re-posts to its own line, its seven members spin on that: nobody's store has to invalidate 63 readers) */
 typedef struct {
-    int nthreads, n;
-    pthread_t *tid;
-    team_slot_t *slot;
-    _Alignas(128) atomic_ulong go;   /* generation the master has POSTED */
-    /* the posted job */
+    _Alignas(128) atomic_ulong go;   /* generation posted */
     int op;                          /* 0 dot, 1 axpy, 2 quit */
+    double a;
     const double *x;
     const double *yc;
     double *y;
-    double a;
+    char pad[128 - sizeof(atomic_ulong) - sizeof(int) - sizeof(double) - 3 * sizeof(void *) - 4];
+} team_job_t;
+
+typedef struct {
+    int nthreads, n, ngroups;
+    pthread_t *tid;
+    team_slot_t *slot;
+    team_job_t *job;                 /* [0] the root line, [1 + g] group g's line */
+    int pinned;
+    cpu_set_t master_mask;
 } team_t;
 
-typedef struct { team_t *t; int id; } team_arg_t;
+typedef struct { team_t *t; int id; int cpu; } team_arg_t;
 static team_t *g_team = NULL;
 
 static inline void team_wait(atomic_ulong *w, unsigned long want)
 {
     for (unsigned spins = 0; atomic_load_explicit(w, memory_order_acquire) != want; spins++) {
-        if ((spins & 1023) == 1023) sched_yield();   /* oversubscribed box: let the thread we wait for run */
+        if ((spins & 4095) == 4095) sched_yield();   /* oversubscribed box: let the thread we wait for run */
         else HBO_PAUSE();
     }
 }
@@ -86,34 +94,39 @@ static inline void team_range(const team_t *t, int id, int *lo, int *hi)
     *hi = (int)(l1 * 8 > t->n ? t->n : l1 * 8);
 }
 
-static double team_do(team_t *t, int id, unsigned long gen)
+/* worker `id` runs its share of job `jb` (generation gen); a leader first re-posts the job to its group */
+static void team_do(team_t *t, int id, unsigned long gen, const team_job_t *jb)
 {
+    const int leader = id % HBO_TEAM_GROUP == 0;
+    if (leader && id + 1 < t->nthreads) {
+        team_job_t *gl = &t->job[1 + id / HBO_TEAM_GROUP];
+        gl->op = jb->op; gl->a = jb->a; gl->x = jb->x; gl->yc = jb->yc; gl->y = jb->y;
+        atomic_store_explicit(&gl->go, gen, memory_order_release);
+    }
+    if (jb->op == 2) return;
     int lo, hi;
     team_range(t, id, &lo, &hi);
     double s = 0.0;
-    if (t->op == 0) {
-        const double *x = t->x, *y = t->yc;
+    if (jb->op == 0) {
+        const double *x = jb->x, *y = jb->yc;
 #pragma omp simd reduction(+ : s)
         for (int i = lo; i < hi; i++) s += x[i] * y[i];
-    } else if (t->op == 1) {
-        const double a = t->a, *x = t->x;
-        double *y = t->y;
+    } else {
+        const double a = jb->a, *x = jb->x;
+        double *y = jb->y;
 #pragma omp simd
         for (int i = lo; i < hi; i++) y[i] += a * x[i];
     }
     team_slot_t *me = &t->slot[id];
     me->part = s;
-    atomic_store_explicit(&me->gen, gen, memory_order_release);
-    if (id % HBO_TEAM_GROUP == 0) { /* group leader: its members' partial sums, in member order */
-        double g = s;
-        for (int k = id + 1; k < id + HBO_TEAM_GROUP && k < t->nthreads; k++) {
-            team_wait(&t->slot[k].gen, gen);
-            g += t->slot[k].part;
-        }
-        me->gsum = g;
-        atomic_store_explicit(&me->ggen, gen, memory_order_release);
+    if (!leader) { atomic_store_explicit(&me->gen, gen, memory_order_release); return; }
+    double g = s;       /* group leader: its members' partial sums, in member order */
+    for (int k = id + 1; k < id + HBO_TEAM_GROUP && k < t->nthreads; k++) {
+        team_wait(&t->slot[k].gen, gen);
+        g += t->slot[k].part;
     }
-    return s;
+    me->gsum = g;
+    atomic_store_explicit(&me->ggen, gen, memory_order_release);
 }
 
 static void *team_worker(void *p)
@@ -121,10 +134,18 @@ static void *team_worker(void *p)
     team_arg_t *ta = (team_arg_t *)p;
     team_t *t = ta->t;
     const int id = ta->id;
+    if (ta->cpu >= 0) {
+        cpu_set_t cs;
+        CPU_ZERO(&cs);
+        CPU_SET(ta->cpu, &cs);
+        pthread_setaffinity_np(pthread_self(), sizeof(cs), &cs);
+    }
+    /* a leader listens to the root line, a member to its leader's line */
+    team_job_t *src = (id % HBO_TEAM_GROUP == 0) ? &t->job[0] : &t->job[1 + id / HBO_TEAM_GROUP];
     for (unsigned long gen = 1;; gen++) {
-        team_wait(&t->go, gen);
-        if (t->op == 2) break;
-        team_do(t, id, gen);
+        team_wait(&src->go, gen);
+        team_do(t, id, gen, src);
+        if (src->op == 2) break;
     }
     return NULL;
 }
@@ -132,17 +153,37 @@ static void *team_worker(void *p)
 static team_arg_t *g_team_args = NULL;
 static void team_start(int nthreads, int n)
 {
-    team_t *t = (team_t *)aligned_alloc(128, sizeof(team_t));
+    team_t *t = (team_t *)aligned_alloc(128, (sizeof(team_t) + 127) / 128 * 128);
     memset(t, 0, sizeof(*t));
     t->nthreads = nthreads;
     t->n = n;
+    t->ngroups = (nthreads + HBO_TEAM_GROUP - 1) / HBO_TEAM_GROUP;
     t->slot = (team_slot_t *)aligned_alloc(128, sizeof(team_slot_t) * nthreads);
     memset(t->slot, 0, sizeof(team_slot_t) * nthreads);
+    t->job = (team_job_t *)aligned_alloc(128, sizeof(team_job_t) * (1 + t->ngroups));
+    memset(t->job, 0, sizeof(team_job_t) * (1 + t->ngroups));
     t->tid = (pthread_t *)calloc(nthreads, sizeof(pthread_t));
     g_team_args = (team_arg_t *)calloc(nthreads, sizeof(team_arg_t));
+    /* one worker per CPU of the process's affinity mask, in mask order (on the usual numbering the first cores of one socket, no
+     * SMT siblings) — a spinning team that the scheduler may stack on sibling threads or migrate is what made 64 threads slower
+     * than one. Not pinned when there are fewer CPUs than workers (the yield in team_wait then keeps it live). */
+    int cpus[1024], ncpu = 0;
+    cpu_set_t cs;
+    if (sched_getaffinity(0, sizeof(cs), &cs) == 0)
+        for (int c = 0; c < CPU_SETSIZE && ncpu < 1024; c++)
+            if (CPU_ISSET(c, &cs)) cpus[ncpu++] = c;
+    t->pinned = ncpu >= nthreads && !getenv("HBO_TEAM_NOPIN");
+    if (t->pinned) {
+        pthread_getaffinity_np(pthread_self(), sizeof(t->master_mask), &t->master_mask);
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(cpus[0], &one);
+        pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+    }
     for (int i = 1; i < nthreads; i++) {
         g_team_args[i].t = t;
         g_team_args[i].id = i;
+        g_team_args[i].cpu = t->pinned ? cpus[i] : -1;
         pthread_create(&t->tid[i], NULL, team_worker, &g_team_args[i]);
     }
     g_team = t;
@@ -150,11 +191,12 @@ static void team_start(int nthreads, int n)
 
 static double team_run(team_t *t, int op, double a, const double *x, const double *yc, double *y)
 {
-    t->op = op; t->a = a; t->x = x; t->yc = yc; t->y = y;
-    const unsigned long gen = atomic_load_explicit(&t->go, memory_order_relaxed) + 1;
-    atomic_store_explicit(&t->go, gen, memory_order_release);
+    team_job_t *root = &t->job[0];
+    root->op = op; root->a = a; root->x = x; root->yc = yc; root->y = y;
+    const unsigned long gen = atomic_load_explicit(&root->go, memory_order_relaxed) + 1;
+    atomic_store_explicit(&root->go, gen, memory_order_release);
+    team_do(t, 0, gen, root);                 /* the master is worker 0 and the leader of group 0 */
     if (op == 2) return 0.0;
-    team_do(t, 0, gen);                       /* the master is worker 0 and the leader of group 0 */
     double s = t->slot[0].gsum;
     for (int g = HBO_TEAM_GROUP; g < t->nthreads; g += HBO_TEAM_GROUP) {
         team_wait(&t->slot[g].ggen, gen);     /* (also the completion barrier of an axpy) */
@@ -169,7 +211,8 @@ static void team_stop(void)
     if (!t) return;
     team_run(t, 2, 0.0, NULL, NULL, NULL);
     for (int i = 1; i < t->nthreads; i++) pthread_join(t->tid[i], NULL);
-    free(t->tid); free(t->slot); free(t); free(g_team_args);
+    if (t->pinned) pthread_setaffinity_np(pthread_self(), sizeof(t->master_mask), &t->master_mask);
+    free(t->tid); free(t->slot); free(t->job); free(t); free(g_team_args);
     g_team = NULL; g_team_args = NULL;
 }
 

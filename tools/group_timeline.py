@@ -62,6 +62,15 @@ for name, sel in (("quiet", cand == 0), ("candidates, no move", (cand > 0) & (nm
         name, k, per[sel].mean(), 100 * per[sel].sum() / cyc, 100 * s[:, 11].mean(), rounds[sel].mean(), cand[sel].mean()))
     print("      dots %6.0f | rank %6.0f | exact data %6.0f | gram gather %6.0f | serial %6.0f | fold+verify %6.0f | commit+publish %6.0f | forward %6.0f | later rounds+end %6.0f" % (
         seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4), seg(4, 5), seg(5, 6), seg(6, 7), seg(7, 8), seg(8, 9)))
+if st[:, 16:32].any():   # per-wave stamps (round 5): when each wave had its dots (24..31) and reached the first barrier (16..23), after stamp 1 of wave 0
+    sel = nmv >= 5
+    for name, base in (("dots in hand", 24), ("at barrier B1", 16)):
+        d = st[sel][:, base:base + 8] - st[sel][:, 1:2]
+        print("  groups with >= 5 moves: wave w %-14s minus wave 0's stamp 1, mean cycles: %s" % (name, " ".join("%7.0f" % x for x in d.mean(axis=0))))
+    late = (st[sel][:, 24:32]).argmax(axis=1)
+    print("  the LAST wave to have its dots: histogram over waves 0..7 %s" % np.bincount(late, minlength=8).tolist())
+    d0 = st[sel][:, 24:32] - st[sel][:, 0:1]
+    print("  dots in hand minus stamp 0 (group opened), mean per wave: %s" % " ".join("%7.0f" % x for x in d0.mean(axis=0)))
 print("moves/sweep %.0f" % info.mean_events)
 busy = st[:, 9] - st[:, 1]   # the group's work once its dots are in hand
 opening = st[:, 1] - st[:, 0]
