@@ -411,6 +411,7 @@ def measure(H, L, ctx, y, model, K, W, args, rank, local_rank, world, m_offset, 
     del keep
     ev = (info.mean_events * info.iter - info0.mean_events * info0.iter) / max(1, K)   # over the timed sweeps only
     ms = (info.mean_misses * info.iter - info0.mean_misses * info0.iter) / max(1, K)
+    measure.redo = (info.mean_redo * info.iter - info0.mean_redo * info0.iter) / max(1, K)   # speculative chain rounds rolled back and repeated, per sweep
     measure.curve = curve
     return elapsed, ev, info.nnz, ms
 
@@ -546,6 +547,7 @@ def main():
     elapsed, mean_events, nnz, misses = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
                                         m_global, comm, torch, note, burn=args.burnin)
     replayed_main = getattr(measure, "replayed", 0)
+    redo_main = getattr(measure, "redo", None)
     per_rank_main = getattr(measure, "per_rank_ms", None)
     g_main, warm_main = measure.final     # the state the side legs of this model continue from
     state_main = dict(measure.state)
@@ -579,6 +581,7 @@ def main():
                    "collective": comm.rccl_note if comm is not None else "none",
                    "mcmc_burn_in_sweeps_before_warmup": args.burnin,
                    "mean_changed_markers_per_sweep": mean_events, "row_cache_misses_per_sweep": misses, "NumNZSnp_last": nnz,
+                   "chain_rounds_rolled_back_per_sweep": redo_main,
                    "sweeps_replayed_after_a_device_time_out": replayed_main,
                    "matvec_kernel": roof["kernel"],
                    "resident_genotype_bits": bits, "setup_seconds": {"generate": gen_s, "gram": gram_s, "pack_2bit": pack_s}},
@@ -608,6 +611,7 @@ def main():
              "sweeps_replayed_after_a_device_time_out": getattr(measure, "replayed", 0),
              "pipeline": {"persistent_chain": geo_x[0], "lookahead_groups": geo_x[1], "panels_per_matvec": geo_x[2]}}
         b.update(regime_tag(el / Kx * 1e3, ins))
+        b["chain_rounds_rolled_back_per_sweep"] = getattr(measure, "redo", None)
         b["state_after"] = dict(getattr(measure, "state", {}))
         if curve is not None:
             b["regime_curve"] = curve

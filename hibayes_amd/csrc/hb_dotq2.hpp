@@ -19,7 +19,7 @@
 #pragma once
 
 #ifndef Q2_DIAG
-#define Q2_DIAG 0 /* timing diagnostics only (wrong results): 1 = no atomics at the tile's end, 2 = no dot4 (loads + reduction only) */
+#define Q2_DIAG 0 /* timing diagnostics only (wrong results): 1 = no atomics at the tile's end, 2 = no dot4 (loads + reduction only), 3 = plain stores instead of the atomics */
 #endif
 #define Q2_RS 512   /* individuals per stage of the default shape (the padded column length is a multiple of it) */
 // Q2_SCALED (round 4): the four genotypes of a byte are masked WITHOUT shifting them down — w & 0x03030303, w & 0x0c0c0c0c,
@@ -183,6 +183,9 @@ __device__ __forceinline__ void dotq2_tile(const dq_view &v, char *smem, int b)
 #pragma unroll
         for (int k = 0; k < HB_ND; k++) {
             const int tot = Q2_SCALED ? acc[c][k][0] + (acc[c][k][NSC > 1 ? 1 : 0] >> 2) + (acc[c][k][NSC > 2 ? 2 : 0] >> 4) + (acc[c][k][NSC > 3 ? 3 : 0] >> 5) : acc[c][k][0];
+            if (Q2_DIAG == 1) { if (tot == 0x12345678) v.accq[0] = 1; } // (timing diagnostic: the tile without its closing atomics)
+            else if (Q2_DIAG == 3) v.accq[(int64_t)k * v.accstride + cg * (64 * CPL) + c * 64 + lane] = (long long)tot; // (... plain stores in their place)
+            else
             __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * (64 * CPL) + c * 64 + lane, (long long)tot, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -249,6 +252,7 @@ static constexpr int q2_lds(int cpl, int rs) { return 2 * ((64 * cpl / (4096 / r
 #ifndef Q2M_NBUF
 #define Q2M_NBUF 3 /* stage buffers: NBUF - 1 stages in flight ahead of the one being multiplied (a stage computes in ~0.3 us, a loaded round trip takes ~2) */
 #endif
+static_assert(Q2M_NBUF >= 2 && Q2M_NBUF <= 6, "the counted waits of dotq2m_tile cover up to five stages in flight");
 static constexpr int q2m_lds() { return Q2M_NBUF * Q2M_BUF; }
 
 __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
@@ -298,7 +302,9 @@ __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
         if (st + Q2M_NBUF - 1 < st1) issue(st + Q2M_NBUF - 1, (buf + Q2M_NBUF - 1) % Q2M_NBUF);
         // stages still in flight behind this one: the counted wait lets exactly those stay outstanding
         const int ahead = min(Q2M_NBUF - 1, st1 - 1 - st);
-        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * Q2M_PER) : "memory");
+        if (ahead >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(5 * Q2M_PER) : "memory");
+        else if (ahead == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * Q2M_PER) : "memory");
+        else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * Q2M_PER) : "memory");
         else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * Q2M_PER) : "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -339,8 +345,12 @@ __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < HB_ND; k++)
+    for (int k = 0; k < HB_ND; k++) {
+        if (Q2_DIAG == 1) { if (tr[k * 64 + lane] == 0x12345678) v.accq[0] = 1; } // (timing diagnostic: the tile without its closing atomics)
+        else if (Q2_DIAG == 3) v.accq[(int64_t)k * v.accstride + cg * 64 + lane] = (long long)tr[k * 64 + lane]; // (... with plain stores in their place)
+        else
         __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * 64 + lane, (long long)tr[k * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ __launch_bounds__(64) void k_dotq2m(dq_view v, upd_view uq)
