@@ -155,7 +155,21 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
         return q.get() * (mc / float(args.m)) if not q.empty() else "no result"
 
     slow = {}
-    for thr in sorted(set([min(cores, 8), min(cores, 16), min(cores, 64)]) - {1}):
+    # the container's CPU-time quota (cgroup cpu.max): a team with more runnable (spinning) threads than the quota allows is throttled by the
+    # scheduler — on the round-5 box (2 x EPYC 9575F, 256 logical CPUs visible, quota 16) 32 threads still ran, 64 ran ten times slower
+    # than one — so the thread counts stop at the quota
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    cap = cores if quota is None else max(1, min(cores, int(quota)))
+    for thr in sorted(set([min(cap, 4), min(cap, 8), min(cap, 16), min(cap, 64)]) - {1}):
         v = timed(thr)
         if isinstance(v, float):
             out[thr] = v
@@ -175,7 +189,7 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
                       "markers, n=%d, %d sweeps, scaled by m_sample/m" % (mc, args.m, args.n, 1 + args.cpu_sweeps),
             "value_1thread": out[1], "by_threads": {str(k): v for k, v in sorted(out.items())}, "not_finished": slow,
             "regime": "warm start from the GPU chain's effects after its timed region" if gi is not None else "cold start",
-            "host_cores": cores,
+            "host_cores": cores, "host_cpu_quota": quota,
             "cpu_model": cpu_model}
 
 

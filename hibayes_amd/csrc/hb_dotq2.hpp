@@ -246,24 +246,31 @@ static constexpr int q2_lds(int cpl, int rs) { return 2 * ((64 * cpl / (4096 / r
 // ---------------------------------------------------------------------------------------------
 #define Q2M_RS 256
 #define Q2M_DSTRIDE 1088
-#define Q2M_XB (4 * HBQ_SLOT)
-#define Q2M_BUF (Q2M_XB + 2 * Q2M_DSTRIDE)
-#define Q2M_PER 6
 #ifndef Q2M_NBUF
-#define Q2M_NBUF 3 /* stage buffers: NBUF - 1 stages in flight ahead of the one being multiplied (a stage computes in ~0.3 us, a loaded round trip takes ~2) */
+#define Q2M_NBUF 3 /* stage buffers: NBUF - 1 (super-)stages in flight ahead of the one being multiplied (a stage computes in ~0.3 us, a loaded round trip takes ~2) */
 #endif
 static_assert(Q2M_NBUF >= 2 && Q2M_NBUF <= 6, "the counted waits of dotq2m_tile cover up to five stages in flight");
-static constexpr int q2m_lds() { return Q2M_NBUF * Q2M_BUF; }
+// Shape (round 5). CT = column tiles of 16 per wave (4: 64 columns, the round-4 shape; 8: 128; 16: 256) — the stage's digit planes
+// (1.75 KB, re-read from L2 by every wave) then serve CT * 16 columns, and what the launch moves through the compute units'
+// LDS-DMA path, the genotypes PLUS those digit bytes, is what bounds it: 63 MB per 3584-column launch at CT = 4 (44.8 + 18.4),
+// 54 at CT = 8, 49 at CT = 16. G = 256-individual stages requested together (2: both halves of every 128-byte line of a column
+// are asked for back to back). One accumulator set per scale (SC = true, 16 registers per column tile) or one in all (SC = false:
+// the genotypes shifted down to one scale, 7 mask / shift operations per register instead of 5, 4 registers per column tile).
+template <int CT, int G>
+static constexpr int q2m_lds() { return Q2M_NBUF * G * (CT * HBQ_SLOT + 2 * Q2M_DSTRIDE); }
 
+template <int CT, int G, bool SC>
 __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
 {
+    constexpr int XB = CT * HBQ_SLOT, BUF = XB + 2 * Q2M_DSTRIDE, PER = G * (CT + 2), NSC = SC ? 4 : 1;
+    static_assert((Q2M_NBUF - 1) * PER <= 63, "the in-flight DMA pieces must fit the 6-bit vmcnt");
     const int lane = threadIdx.x;
     const int cg = b % v.ncg, sp = b / v.ncg;
     if (b == 0 && lane == 0) *v.gexp_out = *v.vexp_in;
     const int st0 = sp * v.NS, st1 = min(v.nstages, st0 + v.NS);
     if (st0 >= st1) return;
     const int64_t ld2 = v.ld2, ld = v.ld;
-    const uint8_t *xg = v.X2 + (int64_t)cg * 64 * ld2;
+    const uint8_t *xg = v.X2 + (int64_t)cg * (16 * CT) * ld2;
     const int m = lane & 15, kb = lane >> 4;
     // DMA sources: tile piece i = columns 16 i + m, 16-byte chunk kb of the stage's 64 bytes; digit piece j = plane 4 j + (lane & 3)
     // (clamped to the last plane), 16-byte chunk lane >> 2 of the stage's 256 digit bytes
@@ -277,54 +284,74 @@ __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
         return reinterpret_cast<const int8_t *>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
                                                             (unsigned)__builtin_amdgcn_readfirstlane((int)u)));
     };
-    auto issue = [&](int st, int buf) {
-        const int8_t *xs = uni_p(reinterpret_cast<const int8_t *>(xg) + (int64_t)st * (Q2M_RS / 4));
-        const int8_t *ds = uni_p(v.rq + (int64_t)st * Q2M_RS);
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)buf * Q2M_BUF));
+    // super-stage ss = stages st0 + G ss .. + G - 1 (the last may be short: its missing stages re-request the tile's last stage, so
+    // that every super-stage is exactly PER pieces and the counted waits stay exact; they are not multiplied)
+    const int nss = (st1 - st0 + G - 1) / G;
+    auto issue = [&](int ss, int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) hbq_dma16<true>(voff, xs + (int64_t)(16 * i) * ld2, dst + i * HBQ_SLOT);
+        for (int g = 0; g < G; g++) {
+            const int st = min(st0 + ss * G + g, st1 - 1);
+            const int8_t *xs = uni_p(reinterpret_cast<const int8_t *>(xg) + (int64_t)st * (Q2M_RS / 4));
+            const int8_t *ds = uni_p(v.rq + (int64_t)st * Q2M_RS);
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(buf * G + g) * BUF));
 #pragma unroll
-        for (int j = 0; j < 2; j++) hbq_dma16<false>(doff[j], ds, dst + Q2M_XB + j * Q2M_DSTRIDE);
+            for (int i = 0; i < CT; i++) hbq_dma16<true>(voff, xs + (int64_t)(16 * i) * ld2, dst + i * HBQ_SLOT);
+#pragma unroll
+            for (int j = 0; j < 2; j++) hbq_dma16<false>(doff[j], ds, dst + XB + j * Q2M_DSTRIDE);
+        }
     };
-    hb_v4i C[4][4]; // [column tile][scale 4^k, k = 3: 32]
+    hb_v4i C[CT][NSC]; // [column tile][scale 4^k, k = 3: 32]
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++)
+    for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) C[ct][k] = hb_v4i{0, 0, 0, 0};
+        for (int k = 0; k < NSC; k++) C[ct][k] = hb_v4i{0, 0, 0, 0};
     // this lane's digit reads: plane n = min(lane & 15, 6) (the output columns 7..15 of the instruction are never looked at)
     const int n = min(m, HB_ND - 1);
     const unsigned dlane = (unsigned)((n >> 2) * Q2M_DSTRIDE + (kb * 16 + (n & 3)) * 16); // + 64 r: chunk 4 kb + r
 #pragma unroll
     for (int a = 0; a < Q2M_NBUF - 1; a++)
-        if (st0 + a < st1) issue(st0 + a, a);
+        if (a < nss) issue(a, a);
     int buf = 0;
-    for (int st = st0; st < st1; ++st) {
-        if (st + Q2M_NBUF - 1 < st1) issue(st + Q2M_NBUF - 1, (buf + Q2M_NBUF - 1) % Q2M_NBUF);
-        // stages still in flight behind this one: the counted wait lets exactly those stay outstanding
-        const int ahead = min(Q2M_NBUF - 1, st1 - 1 - st);
-        if (ahead >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(5 * Q2M_PER) : "memory");
-        else if (ahead == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * Q2M_PER) : "memory");
-        else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * Q2M_PER) : "memory");
-        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * Q2M_PER) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_PER) : "memory");
+    for (int ss = 0; ss < nss; ++ss) {
+        if (ss + Q2M_NBUF - 1 < nss) issue(ss + Q2M_NBUF - 1, (buf + Q2M_NBUF - 1) % Q2M_NBUF);
+        // super-stages still in flight behind this one: the counted wait lets exactly those stay outstanding
+        const int ahead = min(Q2M_NBUF - 1, nss - 1 - ss);
+        if (ahead >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_NBUF > 5 ? 5 * PER : 0) : "memory");
+        else if (ahead == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_NBUF > 4 ? 4 * PER : 0) : "memory");
+        else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_NBUF > 3 ? 3 * PER : 0) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_NBUF > 2 ? 2 * PER : 0) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const char *bp = smem + buf * Q2M_BUF;
-        hb_v4i D[4], X[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) D[r] = *reinterpret_cast<const hb_v4i *>(bp + Q2M_XB + dlane + r * 64);
+        for (int g = 0; g < G; g++) {
+            if (st0 + ss * G + g >= st1) break;
+            const char *bp = smem + (buf * G + g) * BUF;
+            hb_v4i D[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++) X[ct] = *reinterpret_cast<const hb_v4i *>(bp + ct * HBQ_SLOT + lane * 16);
-        const hb_v4i B0 = hb_v4i{D[0].x, D[1].x, D[2].x, D[3].x}, B1 = hb_v4i{D[0].y, D[1].y, D[2].y, D[3].y},
-                     B2 = hb_v4i{D[0].z, D[1].z, D[2].z, D[3].z}, B3 = hb_v4i{D[0].w, D[1].w, D[2].w, D[3].w};
+            for (int r = 0; r < 4; r++) D[r] = *reinterpret_cast<const hb_v4i *>(bp + XB + dlane + r * 64);
+            const hb_v4i B0 = hb_v4i{D[0].x, D[1].x, D[2].x, D[3].x}, B1 = hb_v4i{D[0].y, D[1].y, D[2].y, D[3].y},
+                         B2 = hb_v4i{D[0].z, D[1].z, D[2].z, D[3].z}, B3 = hb_v4i{D[0].w, D[1].w, D[2].w, D[3].w};
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++) {
-            const hb_v4i w = X[ct];
-            const hb_v4i a0 = w & 0x03030303, a1 = w & 0x0c0c0c0c, a2 = w & 0x30303030;
-            const hb_v4i a3 = hb_v4i{(int)((unsigned)w.x >> 1), (int)((unsigned)w.y >> 1), (int)((unsigned)w.z >> 1), (int)((unsigned)w.w >> 1)} & 0x60606060;
-            C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, B0, C[ct][0], 0, 0, 0);
-            C[ct][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, B1, C[ct][1], 0, 0, 0);
-            C[ct][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, B2, C[ct][2], 0, 0, 0);
-            C[ct][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, B3, C[ct][3], 0, 0, 0);
+            for (int ct = 0; ct < CT; ct++) {
+                const hb_v4i w = *reinterpret_cast<const hb_v4i *>(bp + ct * HBQ_SLOT + lane * 16);
+                if (SC) {
+                    const hb_v4i a0 = w & 0x03030303, a1 = w & 0x0c0c0c0c, a2 = w & 0x30303030;
+                    const hb_v4i a3 = hb_v4i{(int)((unsigned)w.x >> 1), (int)((unsigned)w.y >> 1), (int)((unsigned)w.z >> 1), (int)((unsigned)w.w >> 1)} & 0x60606060;
+                    C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, B0, C[ct][0], 0, 0, 0);
+                    C[ct][NSC > 1 ? 1 : 0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, B1, C[ct][NSC > 1 ? 1 : 0], 0, 0, 0);
+                    C[ct][NSC > 2 ? 2 : 0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, B2, C[ct][NSC > 2 ? 2 : 0], 0, 0, 0);
+                    C[ct][NSC > 3 ? 3 : 0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, B3, C[ct][NSC > 3 ? 3 : 0], 0, 0, 0);
+                } else {
+                    auto shr = [](const hb_v4i &x, int sh) {
+                        return hb_v4i{(int)((unsigned)x.x >> sh), (int)((unsigned)x.y >> sh), (int)((unsigned)x.z >> sh), (int)((unsigned)x.w >> sh)};
+                    };
+                    const hb_v4i a0 = w & 0x03030303, a1 = shr(w, 2) & 0x03030303, a2 = shr(w, 4) & 0x03030303, a3 = shr(w, 6) & 0x03030303;
+                    C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, B0, C[ct][0], 0, 0, 0);
+                    C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, B1, C[ct][0], 0, 0, 0);
+                    C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, B2, C[ct][0], 0, 0, 0);
+                    C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, B3, C[ct][0], 0, 0, 0);
+                }
+            }
         }
         // (the next iteration's DMA overwrites the buffer read here: every LDS read of it has returned — the MFMAs consumed them)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -332,27 +359,31 @@ __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
     }
     // the instruction's result layout: lane l, register r = C[row 4 (l / 16) + r][column l % 16], i.e. genotype column
     // 4 kb + r of the tile, plane m. The sums of scale 4^k are multiples of it: the shifts are exact.
-    // Turned through LDS (the tile buffers are free now; one wave: no barrier) so that a lane ends up with ONE column and the seven
+    // Turned through LDS (the tile buffers are free now; one wave: no barrier) so that a lane ends up with ONE column and the
     // closing atomics of the wave each cover 64 consecutive columns — straight from the result layout an atomic instruction
     // would touch 28 separate lines (7 planes x 4 lane groups): measured 44 us per launch against 22 with a quarter of the tiles.
-    int *tr = reinterpret_cast<int *>(smem); // [plane][64 columns]
+    int *tr = reinterpret_cast<int *>(smem); // [plane][16 CT columns]
     if (m < HB_ND) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++) {
-            const hb_v4i tot = C[ct][0] + (C[ct][1] >> 2) + (C[ct][2] >> 4) + (C[ct][3] >> 5);
-            *reinterpret_cast<hb_v4i *>(tr + m * 64 + ct * 16 + 4 * kb) = tot;
+        for (int ct = 0; ct < CT; ct++) {
+            const hb_v4i tot = SC ? C[ct][0] + (C[ct][NSC > 1 ? 1 : 0] >> 2) + (C[ct][NSC > 2 ? 2 : 0] >> 4) + (C[ct][NSC > 3 ? 3 : 0] >> 5) : C[ct][0];
+            *reinterpret_cast<hb_v4i *>(tr + m * (16 * CT) + ct * 16 + 4 * kb) = tot;
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < HB_ND; k++) {
-        if (Q2_DIAG == 1) { if (tr[k * 64 + lane] == 0x12345678) v.accq[0] = 1; } // (timing diagnostic: the tile without its closing atomics)
-        else if (Q2_DIAG == 3) v.accq[(int64_t)k * v.accstride + cg * 64 + lane] = (long long)tr[k * 64 + lane]; // (... with plain stores in their place)
-        else
-        __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * 64 + lane, (long long)tr[k * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int k = 0; k < HB_ND; k++)
+#pragma unroll
+        for (int q = 0; q < CT / 4; q++) {
+            const int tv = tr[k * (16 * CT) + q * 64 + lane];
+            if (Q2_DIAG == 1) { if (tv == 0x12345678) v.accq[0] = 1; } // (timing diagnostic: the tile without its closing atomics)
+            else if (Q2_DIAG == 3) v.accq[(int64_t)k * v.accstride + cg * (16 * CT) + q * 64 + lane] = (long long)tv; // (... with plain stores in their place)
+            else
+            __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * (16 * CT) + q * 64 + lane, (long long)tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 }
 
+template <int CT, int G, bool SC>
 __global__ __launch_bounds__(64) void k_dotq2m(dq_view v, upd_view uq)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -366,7 +397,7 @@ __global__ __launch_bounds__(64) void k_dotq2m(dq_view v, upd_view uq)
         b -= v.nfin;
         update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096), v.ldiag ? v.ldiag + 3 : nullptr);
     } else {
-        dotq2m_tile(v, smem, b - v.nupd - v.nfin);
+        dotq2m_tile<CT, G, SC>(v, smem, b - v.nupd - v.nfin);
     }
     if (v.stamp && threadIdx.x == 0) {
         v.stamp[2 * (size_t)blockIdx.x] = t0;

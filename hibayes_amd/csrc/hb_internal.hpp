@@ -94,6 +94,7 @@ struct hb_ctx {
     size_t gram_cap = 0; // ints allocated
     bool env_pinned = false;
     int dot_lds = 0;     // dynamic LDS bytes requested by each mat-vec workgroup: caps the workgroups resident per CU
+    int q2m_ct = 4, q2m_g = 1, q2m_sc = 1; // k_dotq2m's shape (HB_Q2M_CT / _G / _SC): column tiles of 16 per wave, stages requested together, per-scale accumulators
     double candf = 1.0;  // chain candidates: markers at zero with q >= candf * thr0 (tuning knob; <= 1)
     double kappa = 3.0; // row-cache prediction: markers with thr0 <= kappa * xx * vare get their Gram row prefetched
     bool gram_ready = false, stats_ready = false;

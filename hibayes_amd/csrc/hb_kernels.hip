@@ -244,7 +244,11 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     int cpl = (ncols % 128 == 0 && !mfma && c->dotq2_rs != 128) ? c->dotq2_cpl : 1;
     const int RS = mfma ? Q2M_RS : c->dotq2_rs;
     const int nst = (int)((c->ld + RS - 1) / RS);
-    const int ncg = ncols / (64 * cpl);
+    // the matrix-core kernel's shape (hb_dotq2.hpp): column tiles of 16 per wave, stages requested together, one accumulator set per scale or one
+    int q2m_ct = c->q2m_ct, q2m_g = c->q2m_g;
+    while (mfma && q2m_ct > 4 && ncols % (16 * q2m_ct)) q2m_ct /= 2;
+    if (q2m_ct == 16) q2m_g = 1;
+    const int ncg = mfma ? ncols / (16 * q2m_ct) : ncols / (64 * cpl);
     // (a tile is at least four stages: its first stage's load latency and its closing atomics are paid per tile)
     // (the matrix-core kernel streams best with few, long tiles — its per-stage work is an eighth of the v_dot4 kernel's, so a tile's fixed
     // costs weigh more: ~800 tiles per 3584-column launch)
@@ -283,7 +287,16 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
         c->lstamp_cols[gidx] = ncols;
     }
     // (the update rows stage their lists in the tile buffers: 6152 bytes, below the smallest shape's 12416)
-    if (mfma) hipLaunchKernelGGL(k_dotq2m, dim3(nblk), dim3(64), q2m_lds(), st, v, uq);
+    if (mfma) {
+#define HB_Q2M_LAUNCH(CT, G, SC) hipLaunchKernelGGL((k_dotq2m<CT, G, SC>), dim3(nblk), dim3(64), (q2m_lds<CT, G>()), st, v, uq)
+        const bool sc = c->q2m_sc != 0;
+        if (q2m_ct == 16) { if (sc) HB_Q2M_LAUNCH(16, 1, true); else HB_Q2M_LAUNCH(16, 1, false); }
+        else if (q2m_ct == 8 && q2m_g == 2) { if (sc) HB_Q2M_LAUNCH(8, 2, true); else HB_Q2M_LAUNCH(8, 2, false); }
+        else if (q2m_ct == 8) { if (sc) HB_Q2M_LAUNCH(8, 1, true); else HB_Q2M_LAUNCH(8, 1, false); }
+        else if (q2m_g == 2) { if (sc) HB_Q2M_LAUNCH(4, 2, true); else HB_Q2M_LAUNCH(4, 2, false); }
+        else { if (sc) HB_Q2M_LAUNCH(4, 1, true); else HB_Q2M_LAUNCH(4, 1, false); }
+#undef HB_Q2M_LAUNCH
+    }
     else if (cpl == 2 && RS == 512) hipLaunchKernelGGL((k_dotq2<2, 512>), dim3(nblk), dim3(64), q2_lds(2, 512), st, v, uq);
     else if (cpl == 2) hipLaunchKernelGGL((k_dotq2<2, 256>), dim3(nblk), dim3(64), q2_lds(2, 256), st, v, uq);
     else if (RS == 512) hipLaunchKernelGGL((k_dotq2<1, 512>), dim3(nblk), dim3(64), q2_lds(1, 512), st, v, uq);
