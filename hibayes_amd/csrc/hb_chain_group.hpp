@@ -54,12 +54,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     double *res_g = cs_d + (2 + 3 * K1) * 64;                   // ... their new effects
     double *ev_del = res_g + 64;                                // the round's moves: change of effect
     double *red = ev_del + 64;                                  // [16]
-    int *cs_pos = reinterpret_cast<int *>(red + 16);            // candidate -> position in the group (panel * P + marker)
+    double *spre = red + 16;                                    // [65] drift pre-check: spre[k] = sum of (column sum x change) over the round's candidates before candidate k
+    double *cs_s1 = spre + 66;                                  // [64] the candidates' column sums
+    int *cs_pos = reinterpret_cast<int *>(cs_s1 + 64);          // candidate -> position in the group (panel * P + marker)
     int *res_c = cs_pos + 64;                                   // ... new classes
     int *ev_pos = res_c + 64;                                   // the round's moves: position
     int *cg = ev_pos + 64;                                      // [64][64] Gram entries among the round's candidates (k < c)
     int *wcnt = cg + 64 * 64;                                   // [HBG_DM][8] candidates per (panel of the group, wave)
-    int *misc = wcnt + 64;                                      // [0] moves of the round, [1] position the round ends at, [2] abort, [8..15] violations per wave, [16..23] moves published per panel
+    int *misc = wcnt + 64;                                      // [0] moves of the round, [1] position the round ends at, [2] abort, [8..15] violations per wave, [16..23] moves published per panel, [24..31] predicted crossings per wave
     for (int l = 0; l < R; l++) corr[(size_t)l * P + t] = 0.0;
     if (t < 64) { wcnt[t] = 0; if (t < 32) misc[t] = 0; }
 
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- (1) the group's dots, filter words and owed corrections ----
         double r0[HBG_DM];
         float fl[HBG_DM];
+        float muj[HBG_DM]; // mean genotype of marker (i, t) (drift pre-check; 0 without it)
         {
             double dj[HBG_DM], fc[HBG_DM];
             // (k_fwd writes the corrections the moves of the group before the last owe this one: sentinel-prefilled like the dots)
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 dj[i] = ld_sc1(&v.dsum[j]);
                 fl[i] = pv.thr0f[j];
                 fc[i] = ld_sc1(&fcp[j]);
+                muj[i] = v.s1 ? (float)(v.s1[j] * v.inv_n) : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) fl[i] = i < Dg ? fl[i] : __int_as_float(0x7fc00000);
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         cs_d[(2 + 2 * K1 + c) * 64 + rank] = v.sdz[(size_t)c * v.m_pad + j];
                     }
                     cs_pos[rank] = i * P + t;
+                    cs_s1[rank] = v.s1 ? v.s1[j] : 0.0;
                     rk |= (unsigned long long)rank << (8 * i);
                     inrm |= 1u << i;
                 }
@@ -296,10 +301,55 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 res_c[lane] = cls;
                 res_g[lane] = gn;
                 if (lane == 0) misc[0] = __popcll(moved);
+                if (v.s1) { // drift pre-check: inclusive scan of (column sum x change) over the candidates, in marker order
+                    double w = lv ? cs_s1[lane] * dmine : 0.0;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const double up = __shfl_up(w, o, 64);
+                        if (lane >= o) w += up;
+                    }
+                    spre[lane + 1] = w;
+                    if (lane == 0) spre[0] = 0.0;
+                }
             }
             __syncthreads(); // B4
             HBG_STAMP_ONCE(5);
             const int nmoves = misc[0];
+            // ---- (4b) drift pre-check (round 5). A move changes every later marker's right-hand side by G[k][j] d_k, and G[k][j] is n mean_k mean_j
+            // up to the (centred) covariance: the round's moves shift the right-hand sides of ALL later markers by mean_j * sum_k s1_k d_k — with
+            // a handful of moves by a third of the distance between a typical right-hand side and its threshold, so that more than half of the
+            // groups with moves had a marker pushed over its threshold and the whole round — exact data, gather, serial pass and the FOLD, the
+            // expensive part — rolled back and repeated (69 times a sweep at n = 50k, m = 500k: a third of the chain's time). The shift is known the
+            // moment the serial pass ends: a marker whose right-hand side, moved by it, comes within 3 % of its threshold joins the candidates
+            // NOW, before the rows of the moves are fetched. A prediction only ever adds candidates (decided exactly by the next serial pass), and
+            // the exact check after the fold stays: the chain is the same exact sequential chain.
+            if (v.s1 && nmoves > 0) {
+                unsigned pvm = 0;
+#pragma unroll
+                for (int i = 0; i < HBG_DM; i++) {
+                    if (i < Dg) {
+                        const int pos = i * P + t;
+                        const int before = min(64, __shfl(myscan, i * 8 + wave, 64) + (int)((rkp >> (8 * i)) & 0xffull)); // the round's candidates before this marker
+                        const double rp = fma(-(double)muj[i], spre[before], r0[i]);
+                        const bool pviol = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && rp * rp >= 0.94 * (double)fl[i]; // (NaN filter: false)
+                        pvm |= pviol ? 1u << i : 0u;
+                    }
+                }
+                const unsigned long long pb = __ballot(pvm != 0u);
+                if (lane == 0) misc[24 + wave] = pb != 0ull;
+                __syncthreads(); // B4b
+                bool anyp = false;
+                {
+                    int w8[8];
+                    hb_read8(misc + 24, w8);
+#pragma unroll
+                    for (int w = 0; w < 8; w++) anyp |= w8[w] != 0;
+                }
+                if (anyp) { // (not counted as a rolled-back round: nothing but the serial pass is repeated)
+                    forced |= pvm;
+                    continue;
+                }
+            }
             // ---- (5) the round's moves onto the later markers of the group AND forward, all rows of up to HBG_CH moves in one
             // trip (a lone compute unit's loads take microseconds beside the streaming mat-vec: the number of dependent trips is
             // what a group costs). The forward contributions are summed in registers and reach the correction ring only when the

@@ -27,6 +27,10 @@ struct chain_view {
     // marker raises it by at most xabs * |D|; the update derives the digits' exponent from it (null: other paths)
     double *mb;
     double xabs;
+    // round 5, k_chain_group's drift pre-check: column sums (k_stats) and 1 / n — the mean genotype of a marker is s1 * inv_n. Null /
+    // zero: no pre-check (the exact violation check after the fold still catches everything).
+    const double *s1;
+    double inv_n;
 };
 
 // Cycle stamps of the chain kernels (tools/chain_timeline.py): compiled in only with -DHB_STAMPS=1 (tools/build_variant.sh) —

@@ -249,6 +249,9 @@ static constexpr int q2_lds(int cpl, int rs) { return 2 * ((64 * cpl / (4096 / r
 #ifndef Q2M_NBUF
 #define Q2M_NBUF 3 /* stage buffers: NBUF - 1 (super-)stages in flight ahead of the one being multiplied (a stage computes in ~0.3 us, a loaded round trip takes ~2) */
 #endif
+#ifndef Q2M_NT
+#define Q2M_NT 1 /* the genotype tile's DMA pieces carry the non-temporal hint (k_dotq: so that the digit planes and the chain's rows stay in L2) */
+#endif
 static_assert(Q2M_NBUF >= 2 && Q2M_NBUF <= 6, "the counted waits of dotq2m_tile cover up to five stages in flight");
 // Shape (round 5). CT = column tiles of 16 per wave (4: 64 columns, the round-4 shape; 8: 128; 16: 256) — the stage's digit planes
 // (1.75 KB, re-read from L2 by every wave) then serve CT * 16 columns, and what the launch moves through the compute units'
@@ -295,7 +298,7 @@ __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
             const int8_t *ds = uni_p(v.rq + (int64_t)st * Q2M_RS);
             const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(buf * G + g) * BUF));
 #pragma unroll
-            for (int i = 0; i < CT; i++) hbq_dma16<true>(voff, xs + (int64_t)(16 * i) * ld2, dst + i * HBQ_SLOT);
+            for (int i = 0; i < CT; i++) hbq_dma16<Q2M_NT != 0>(voff, xs + (int64_t)(16 * i) * ld2, dst + i * HBQ_SLOT);
 #pragma unroll
             for (int j = 0; j < 2; j++) hbq_dma16<false>(doff[j], ds, dst + XB + j * Q2M_DSTRIDE);
         }
@@ -383,6 +386,113 @@ __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
         }
 }
 
+// The same product on 512-individual stages whose DMA pieces are WHOLE 128-byte lines (round 5 A/B, shape G = 0): dotq2m_tile above asks
+// for a column in 64-byte halves, the second half one stage after the first; here a piece is 8 columns x 128 bytes (lane l: column l / 8,
+// 16-byte chunk l % 8 — k_dotq2's mapping) and a stage is multiplied in two halves of 256 individuals. The operand read of lane (m, kb), half h,
+// is chunk 4 h + kb of column m of the column tile: a 4-way bank conflict on the read (eight 128-byte rows 128 bytes apart), paid for with LDS
+// cycles the kernel does not need. 64 columns per wave.
+template <bool SC>
+__device__ __forceinline__ void dotq2m512_tile(const dq_view &v, char *smem, int b)
+{
+    constexpr int NXP = 8, NDP = 4, XB = NXP * HBQ_SLOT, BUF = XB + NDP * 1024, PER = NXP + NDP, NSC = SC ? 4 : 1;
+    static_assert((Q2M_NBUF - 1) * PER <= 63, "the in-flight DMA pieces must fit the 6-bit vmcnt");
+    const int lane = threadIdx.x;
+    const int cg = b % v.ncg, sp = b / v.ncg;
+    if (b == 0 && lane == 0) *v.gexp_out = *v.vexp_in;
+    const int st0 = sp * v.NS, st1 = min(v.nstages, st0 + v.NS);
+    if (st0 >= st1) return;
+    const int64_t ld2 = v.ld2, ld = v.ld;
+    const uint8_t *xg = v.X2 + (int64_t)cg * 64 * ld2;
+    const int m = lane & 15, kb = lane >> 4;
+    const unsigned voff = (unsigned)((lane >> 3) * ld2 + (lane & 7) * 16);             // tile piece i: columns 8 i + lane / 8, chunk lane % 8 of the stage's 128 bytes
+    unsigned doff[NDP];                                                                // digit piece j: planes 2 j + lane / 32 (clamped), chunk lane % 32 of the stage's 512 bytes
+#pragma unroll
+    for (int j = 0; j < NDP; j++) doff[j] = (unsigned)(min(2 * j + (lane >> 5), HB_ND - 1) * ld + (lane & 31) * 16);
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    auto uni_p = [](const int8_t *p) {
+        const unsigned long long u = (unsigned long long)(uintptr_t)p;
+        return reinterpret_cast<const int8_t *>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                                            (unsigned)__builtin_amdgcn_readfirstlane((int)u)));
+    };
+    auto issue = [&](int st, int buf) {
+        const int8_t *xs = uni_p(reinterpret_cast<const int8_t *>(xg) + (int64_t)st * 128);
+        const int8_t *ds = uni_p(v.rq + (int64_t)st * 512);
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)buf * BUF));
+#pragma unroll
+        for (int i = 0; i < NXP; i++) hbq_dma16<Q2M_NT != 0>(voff, xs + (int64_t)(8 * i) * ld2, dst + i * HBQ_SLOT);
+#pragma unroll
+        for (int j = 0; j < NDP; j++) hbq_dma16<false>(doff[j], ds, dst + XB + j * 1024);
+    };
+    hb_v4i C[4][NSC];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int k = 0; k < NSC; k++) C[ct][k] = hb_v4i{0, 0, 0, 0};
+    const int n = min(m, HB_ND - 1);
+    // operand reads: column 16 ct + m = piece 2 ct + (m >> 3), row (m & 7) of it, chunk 4 h + kb; digits of plane n: piece n / 2, lane slot (n & 1) * 32 + 16 h + 4 kb + r
+    const unsigned xlane = (unsigned)((m >> 3) * HBQ_SLOT + ((m & 7) * 8 + kb) * 16);
+    const unsigned dlane = (unsigned)(XB + (n >> 1) * 1024 + ((n & 1) * 32 + 4 * kb) * 16);
+#pragma unroll
+    for (int a = 0; a < Q2M_NBUF - 1; a++)
+        if (st0 + a < st1) issue(st0 + a, a);
+    int buf = 0;
+    for (int st = st0; st < st1; ++st) {
+        if (st + Q2M_NBUF - 1 < st1) issue(st + Q2M_NBUF - 1, (buf + Q2M_NBUF - 1) % Q2M_NBUF);
+        const int ahead = min(Q2M_NBUF - 1, st1 - 1 - st);
+        if (ahead >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_NBUF > 5 ? 5 * PER : 0) : "memory");
+        else if (ahead == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_NBUF > 4 ? 4 * PER : 0) : "memory");
+        else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_NBUF > 3 ? 3 * PER : 0) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(Q2M_NBUF > 2 ? 2 * PER : 0) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char *bp = smem + buf * BUF;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            hb_v4i D[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) D[r] = *reinterpret_cast<const hb_v4i *>(bp + dlane + (16 * h + r) * 16);
+            const hb_v4i B0 = hb_v4i{D[0].x, D[1].x, D[2].x, D[3].x}, B1 = hb_v4i{D[0].y, D[1].y, D[2].y, D[3].y},
+                         B2 = hb_v4i{D[0].z, D[1].z, D[2].z, D[3].z}, B3 = hb_v4i{D[0].w, D[1].w, D[2].w, D[3].w};
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) {
+                const hb_v4i w = *reinterpret_cast<const hb_v4i *>(bp + 2 * ct * HBQ_SLOT + xlane + 4 * h * 16);
+                if (SC) {
+                    const hb_v4i a0 = w & 0x03030303, a1 = w & 0x0c0c0c0c, a2 = w & 0x30303030;
+                    const hb_v4i a3 = hb_v4i{(int)((unsigned)w.x >> 1), (int)((unsigned)w.y >> 1), (int)((unsigned)w.z >> 1), (int)((unsigned)w.w >> 1)} & 0x60606060;
+                    C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, B0, C[ct][0], 0, 0, 0);
+                    C[ct][NSC > 1 ? 1 : 0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, B1, C[ct][NSC > 1 ? 1 : 0], 0, 0, 0);
+                    C[ct][NSC > 2 ? 2 : 0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, B2, C[ct][NSC > 2 ? 2 : 0], 0, 0, 0);
+                    C[ct][NSC > 3 ? 3 : 0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, B3, C[ct][NSC > 3 ? 3 : 0], 0, 0, 0);
+                } else {
+                    auto shr = [](const hb_v4i &x, int sh) {
+                        return hb_v4i{(int)((unsigned)x.x >> sh), (int)((unsigned)x.y >> sh), (int)((unsigned)x.z >> sh), (int)((unsigned)x.w >> sh)};
+                    };
+                    const hb_v4i a0 = w & 0x03030303, a1 = shr(w, 2) & 0x03030303, a2 = shr(w, 4) & 0x03030303, a3 = shr(w, 6) & 0x03030303;
+                    C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, B0, C[ct][0], 0, 0, 0);
+                    C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, B1, C[ct][0], 0, 0, 0);
+                    C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, B2, C[ct][0], 0, 0, 0);
+                    C[ct][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, B3, C[ct][0], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        buf = (buf + 1 == Q2M_NBUF) ? 0 : buf + 1;
+    }
+    int *tr = reinterpret_cast<int *>(smem); // [plane][64 columns]
+    if (m < HB_ND) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) {
+            const hb_v4i tot = SC ? C[ct][0] + (C[ct][NSC > 1 ? 1 : 0] >> 2) + (C[ct][NSC > 2 ? 2 : 0] >> 4) + (C[ct][NSC > 3 ? 3 : 0] >> 5) : C[ct][0];
+            *reinterpret_cast<hb_v4i *>(tr + m * 64 + ct * 16 + 4 * kb) = tot;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < HB_ND; k++)
+        __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * 64 + lane, (long long)tr[k * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static constexpr int q2m512_lds() { return Q2M_NBUF * (8 * HBQ_SLOT + 4 * 1024); }
+
 template <int CT, int G, bool SC>
 __global__ __launch_bounds__(64) void k_dotq2m(dq_view v, upd_view uq)
 {
@@ -397,7 +507,8 @@ __global__ __launch_bounds__(64) void k_dotq2m(dq_view v, upd_view uq)
         b -= v.nfin;
         update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096), v.ldiag ? v.ldiag + 3 : nullptr);
     } else {
-        dotq2m_tile<CT, G, SC>(v, smem, b - v.nupd - v.nfin);
+        if constexpr (G == 0) dotq2m512_tile<SC>(v, smem, b - v.nupd - v.nfin);
+        else dotq2m_tile<CT, G, SC>(v, smem, b - v.nupd - v.nfin);
     }
     if (v.stamp && threadIdx.x == 0) {
         v.stamp[2 * (size_t)blockIdx.x] = t0;

@@ -242,12 +242,14 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     }
     const bool mfma = c->dotq2_kind == 2; // (A/B: the digit-plane product on the matrix cores, k_dotq2m; 256-individual stages, 64 columns per wave)
     int cpl = (ncols % 128 == 0 && !mfma && c->dotq2_rs != 128) ? c->dotq2_cpl : 1;
-    const int RS = mfma ? Q2M_RS : c->dotq2_rs;
-    const int nst = (int)((c->ld + RS - 1) / RS);
     // the matrix-core kernel's shape (hb_dotq2.hpp): column tiles of 16 per wave, stages requested together, one accumulator set per scale or one
     int q2m_ct = c->q2m_ct, q2m_g = c->q2m_g;
     while (mfma && q2m_ct > 4 && ncols % (16 * q2m_ct)) q2m_ct /= 2;
-    if (q2m_ct == 16) q2m_g = 1;
+    if (q2m_ct == 16 && q2m_g == 2) q2m_g = 1;
+    if (q2m_g == 0 && (c->ld % 512 != 0 || ncols % 64)) q2m_g = 1; // (the 512-individual stages read whole stages of digits: the padded length must be a multiple)
+    if (q2m_g == 0) q2m_ct = 4;
+    const int RS = mfma ? (q2m_g == 0 ? 512 : Q2M_RS) : c->dotq2_rs;
+    const int nst = (int)((c->ld + RS - 1) / RS);
     const int ncg = mfma ? ncols / (16 * q2m_ct) : ncols / (64 * cpl);
     // (a tile is at least four stages: its first stage's load latency and its closing atomics are paid per tile)
     // (the matrix-core kernel streams best with few, long tiles — its per-stage work is an eighth of the v_dot4 kernel's, so a tile's fixed
@@ -290,7 +292,10 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     if (mfma) {
 #define HB_Q2M_LAUNCH(CT, G, SC) hipLaunchKernelGGL((k_dotq2m<CT, G, SC>), dim3(nblk), dim3(64), (q2m_lds<CT, G>()), st, v, uq)
         const bool sc = c->q2m_sc != 0;
-        if (q2m_ct == 16) { if (sc) HB_Q2M_LAUNCH(16, 1, true); else HB_Q2M_LAUNCH(16, 1, false); }
+        if (q2m_g == 0) {
+            if (sc) hipLaunchKernelGGL((k_dotq2m<4, 0, true>), dim3(nblk), dim3(64), q2m512_lds(), st, v, uq);
+            else hipLaunchKernelGGL((k_dotq2m<4, 0, false>), dim3(nblk), dim3(64), q2m512_lds(), st, v, uq);
+        } else if (q2m_ct == 16) { if (sc) HB_Q2M_LAUNCH(16, 1, true); else HB_Q2M_LAUNCH(16, 1, false); }
         else if (q2m_ct == 8 && q2m_g == 2) { if (sc) HB_Q2M_LAUNCH(8, 2, true); else HB_Q2M_LAUNCH(8, 2, false); }
         else if (q2m_ct == 8) { if (sc) HB_Q2M_LAUNCH(8, 1, true); else HB_Q2M_LAUNCH(8, 1, false); }
         else if (q2m_g == 2) { if (sc) HB_Q2M_LAUNCH(4, 2, true); else HB_Q2M_LAUNCH(4, 2, false); }
@@ -653,6 +658,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->Lg, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
+    if (c->drift_check) { cv.s1 = c->s1; cv.inv_n = 1.0 / (double)c->n; }
     const int last_panels = np - (g0 + ngroups - 1) * D;
     persist_view pv{np, D, Lv, c->L, c->Lg, pb, c->flags,
                     c->hot_slot, c->hot_list, c->thr0f, c->candf, nullptr};
