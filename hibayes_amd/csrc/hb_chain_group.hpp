@@ -22,16 +22,21 @@
 #pragma once
 
 #if HB_STAMPS
-#define HBG_STAMP(i) do { if (v.dbg && t == 0) v.dbg[(size_t)gcount * 32 + (i)] = clock64(); } while (0)
-#define HBG_STAMP_ONCE(i) do { if (v.dbg && t == 0 && nround == 0) v.dbg[(size_t)gcount * 32 + (i)] = clock64(); } while (0)
-#define HBG_STAMP_VAL(i, x) do { if (v.dbg && t == 0) v.dbg[(size_t)gcount * 32 + (i)] = (x); } while (0)
-// per wave (round 5: which wave the others wait for at the first barrier of a group): words i .. i + 7
-#define HBG_WSTAMP(i) do { if (v.dbg && lane == 0) v.dbg[(size_t)gcount * 32 + (i) + wave] = clock64(); } while (0)
+// Stamped build (tools/group_timeline.py): per mat-vec group 32 words — [0..9] cycles ACCUMULATED per phase over all rounds of the group, rolled-back
+// and repeated ones included (round 4 kept one stamp per phase, overwritten by every repetition of the first round, which made the
+// candidate ranking look like the longest phase: it was the roll-backs) — 0 opening (waiting for the dots), 1 ranking, 2 exact data,
+// 3 gather, 4 serial pass, 5 fold + verify, 6 commit + publish, 7 forward, 8 end of group, 9 drift pre-check; counters: 10 moves, 11 waited for
+// dots, 12 candidates of the first round, 13 committed rounds, 14 rolled-back rounds, 15 rounds repeated by the pre-check; 16 / 17 clock at
+// the group's start / end.
+#define HBG_BEGIN() do { if (v.dbg && t == 0) { for (int z_ = 0; z_ < 32; z_++) v.dbg[(size_t)gcount * 32 + z_] = 0; hbg_tl = clock64(); v.dbg[(size_t)gcount * 32 + 16] = hbg_tl; } } while (0)
+#define HBG_ACC(k) do { if (v.dbg && t == 0) { const long long now_ = clock64(); v.dbg[(size_t)gcount * 32 + (k)] += now_ - hbg_tl; hbg_tl = now_; } } while (0)
+#define HBG_CNT(k, x) do { if (v.dbg && t == 0) v.dbg[(size_t)gcount * 32 + (k)] += (x); } while (0)
+#define HBG_END() do { if (v.dbg && t == 0) v.dbg[(size_t)gcount * 32 + 17] = clock64(); } while (0)
 #else
-#define HBG_STAMP(i) do { } while (0)
-#define HBG_STAMP_ONCE(i) do { } while (0)
-#define HBG_STAMP_VAL(i, x) do { } while (0)
-#define HBG_WSTAMP(i) do { } while (0)
+#define HBG_BEGIN() do { } while (0)
+#define HBG_ACC(k) do { } while (0)
+#define HBG_CNT(k, x) do { } while (0)
+#define HBG_END() do { } while (0)
 #endif
 // Template shape: HBG_DM = panels per group the register arrays are sized for (>= D), HBG_FW = panels ahead a move is folded into
 // (>= Lv * D), HBG_CH = moves whose rows are requested together — HBG_CH * (HBG_DM + HBG_FW) loads per lane and trip, ~60: a narrow
@@ -82,10 +87,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();
 
+    long long hbg_tl = 0;
+    (void)hbg_tl;
     int gslot = 0; // ring slot of the group's first panel
     for (int gp0 = pv.p0; ok && gp0 < np; gp0 += D) {
         const int Dg = min(D, np - gp0);
-        HBG_STAMP(0);
+        HBG_BEGIN();
         // ---- (1) the group's dots, filter words and owed corrections ----
         double r0[HBG_DM];
         float fl[HBG_DM];
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++)
                 bad |= (i < Dg) && (__double_as_longlong(dj[i]) == -1ll || (far_in && __double_as_longlong(fc[i]) == -1ll));
-            HBG_STAMP_VAL(11, bad ? 1 : 0);
+            HBG_CNT(11, bad ? 1 : 0);
             if (__any(bad)) { // the mat-vec (or k_fwd) has not delivered (all of) this group yet: look again
                 const unsigned long long t0 = wall_clock64();
                 for (unsigned looks = 0;; looks++) {
@@ -157,8 +164,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        HBG_STAMP(1);
-        HBG_WSTAMP(24); // every wave: its dots are in hand
+        HBG_ACC(0);
         const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP; // block l = 0 of the group's first panel
         const size_t pstep = (size_t)(pv.Lg + 2) * PP;                   // block l of panel p -> block l + 1 of panel p + 1
         // panels ahead that are owed the corrections by THIS workgroup (with k_fwd beside it: the next group's only)
@@ -166,6 +172,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool have_fw = nfw > 0;
         int nround = 0, nmv_grp = 0;
         (void)nround; (void)nmv_grp;
+        bool hbg_first = true;
+        (void)hbg_first;
         int pos_lo = 0;      // markers of the group before this position are decided
         unsigned forced = 0; // (bit i: marker i * P + t was pushed over its threshold by a move of a rolled-back round)
         double absd_grp = 0.0;
@@ -186,7 +194,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (lane == 0) wcnt[i * 8 + wave] = __popcll(cm);
             }
             if (t == 0) misc[1] = Dg * P;
-            if (nround == 0) HBG_WSTAMP(16); // every wave: at the group's first barrier
             __syncthreads(); // B1
             if (misc[2]) { ok = false; break; }
             int total, myscan;
@@ -201,8 +208,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 total = __builtin_amdgcn_readlane(inc, 63);
                 myscan = inc - cnt;
             }
-            HBG_STAMP_ONCE(2);
-            if (nround == 0) HBG_STAMP_VAL(12, total);
+            HBG_ACC(1);
+            if (hbg_first) { HBG_CNT(12, total); hbg_first = false; }
             if (total == 0) break; // nobody (left) in the group can move
             const int ncr = min(total, 64);
             unsigned inrm = 0;
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
             __syncthreads(); // B2
-            HBG_STAMP_ONCE(3);
+            HBG_ACC(2);
             const int pos_hi = misc[1];
             // ---- (3) Gram entries among the round's candidates: cg[k][c] = x_k . x_c for k < c, zero elsewhere ----
             for (int idx = t; idx < ncr * 64; idx += P) {
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 cg[idx] = gval;
             }
             __syncthreads(); // B3
-            HBG_STAMP_ONCE(4);
+            HBG_ACC(3);
             // ---- (4) the exact serial chain over the round's candidates: wave 0, one candidate per lane, in marker order ----
             if (wave == 0) {
                 const bool lv = lane < ncr;
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
             __syncthreads(); // B4
-            HBG_STAMP_ONCE(5);
+            HBG_ACC(4);
             const int nmoves = misc[0];
             // ---- (4b) drift pre-check (round 5). A move changes every later marker's right-hand side by G[k][j] d_k, and G[k][j] is n mean_k mean_j
             // up to the (centred) covariance: the round's moves shift the right-hand sides of ALL later markers by mean_j * sum_k s1_k d_k — with
@@ -347,8 +354,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 if (anyp) { // (not counted as a rolled-back round: nothing but the serial pass is repeated)
                     forced |= pvm;
+                    HBG_ACC(9);
+                    HBG_CNT(15, 1);
                     continue;
                 }
+                HBG_ACC(9);
             }
             // ---- (5) the round's moves onto the later markers of the group AND forward, all rows of up to HBG_CH moves in one
             // trip (a lone compute unit's loads take microseconds beside the streaming mat-vec: the number of dependent trips is
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (lane == 0) misc[8 + wave] = vm != 0ull;
             }
             __syncthreads(); // B5
-            HBG_STAMP_ONCE(6);
+            HBG_ACC(5);
             bool anyv = false;
             {
                 int w8[8];
@@ -431,6 +441,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (anyv) { // roll the round back: the markers that crossed join the candidates
                 forced |= violm;
                 if (t == 0) redoacc++;
+                HBG_CNT(14, 1);
                 continue;
             }
             // ---- (7) commit the round ----
@@ -479,7 +490,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (lane < HBG_DM) misc[16 + lane] += addme;
                 absd_grp += wave_sum(fabs(dlt));
             }
-            HBG_STAMP_ONCE(7);
+            HBG_ACC(6);
             // ---- (8) ... and the forward sums into the corrections owed to the panels of the next Lv groups ----
             if (nmoves > 0) {
                 int sl = gslot + D;
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     sl = (sl + 1 == R) ? 0 : sl + 1;
                 }
             }
-            HBG_STAMP_ONCE(8);
+            HBG_ACC(7);
             nmv_grp += nmoves;
             nround++;
             pos_lo = pos_hi;
@@ -513,9 +524,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // the next group's first barrier the whole workgroup, ~25 000 cycles per group: profiles/r04_group_timeline_*.txt)
             if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(gp0 + Dg));
         }
-        HBG_STAMP(9);
-        HBG_STAMP_VAL(10, nmv_grp);
-        HBG_STAMP_VAL(13, nround);
+        HBG_ACC(8);
+        HBG_CNT(10, nmv_grp);
+        HBG_CNT(13, nround);
+        HBG_END();
         gcount++;
         gslot += D;
         gslot = gslot >= R ? gslot - R : gslot;

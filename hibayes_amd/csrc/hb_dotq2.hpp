@@ -391,10 +391,15 @@ __device__ __forceinline__ void dotq2m_tile(const dq_view &v, char *smem, int b)
 // 16-byte chunk l % 8 — k_dotq2's mapping) and a stage is multiplied in two halves of 256 individuals. The operand read of lane (m, kb), half h,
 // is chunk 4 h + kb of column m of the column tile: a 4-way bank conflict on the read (eight 128-byte rows 128 bytes apart), paid for with LDS
 // cycles the kernel does not need. 64 columns per wave.
-template <bool SC>
+template <bool SC, bool SWZ>
 __device__ __forceinline__ void dotq2m512_tile(const dq_view &v, char *smem, int b)
 {
-    constexpr int NXP = 8, NDP = 4, XB = NXP * HBQ_SLOT, BUF = XB + NDP * 1024, PER = NXP + NDP, NSC = SC ? 4 : 1;
+    // SWZ: the DMA lanes are dealt so that the operand reads are bank-conflict free — tile piece: lane l = column l % 8, chunk l / 8 (slot = chunk * 8 + column:
+    // the 16 lanes of a read group take two runs of 128 consecutive bytes, the pieces 1152 bytes apart = 32 banks); digit piece j: lane l = plane l % 8,
+    // chunk 8 j + l / 8 (slot = chunk * 8 + plane: the seven planes of a read group are neighbours). The eight lanes that share a 128-byte line are then
+    // eight apart; without SWZ they are neighbours and the reads conflict four- and seven-fold.
+    constexpr int XSL = SWZ ? 1152 : HBQ_SLOT;
+    constexpr int NXP = 8, NDP = 4, XB = NXP * XSL, BUF = XB + NDP * 1024, PER = NXP + NDP, NSC = SC ? 4 : 1;
     static_assert((Q2M_NBUF - 1) * PER <= 63, "the in-flight DMA pieces must fit the 6-bit vmcnt");
     const int lane = threadIdx.x;
     const int cg = b % v.ncg, sp = b / v.ncg;
@@ -404,10 +409,11 @@ __device__ __forceinline__ void dotq2m512_tile(const dq_view &v, char *smem, int
     const int64_t ld2 = v.ld2, ld = v.ld;
     const uint8_t *xg = v.X2 + (int64_t)cg * 64 * ld2;
     const int m = lane & 15, kb = lane >> 4;
-    const unsigned voff = (unsigned)((lane >> 3) * ld2 + (lane & 7) * 16);             // tile piece i: columns 8 i + lane / 8, chunk lane % 8 of the stage's 128 bytes
+    const unsigned voff = SWZ ? (unsigned)((lane & 7) * ld2 + (lane >> 3) * 16) : (unsigned)((lane >> 3) * ld2 + (lane & 7) * 16); // tile piece i: 8 columns x the stage's 128 bytes
     unsigned doff[NDP];                                                                // digit piece j: planes 2 j + lane / 32 (clamped), chunk lane % 32 of the stage's 512 bytes
 #pragma unroll
-    for (int j = 0; j < NDP; j++) doff[j] = (unsigned)(min(2 * j + (lane >> 5), HB_ND - 1) * ld + (lane & 31) * 16);
+    for (int j = 0; j < NDP; j++)
+        doff[j] = SWZ ? (unsigned)(min(lane & 7, HB_ND - 1) * ld + (8 * j + (lane >> 3)) * 16) : (unsigned)(min(2 * j + (lane >> 5), HB_ND - 1) * ld + (lane & 31) * 16);
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
     auto uni_p = [](const int8_t *p) {
         const unsigned long long u = (unsigned long long)(uintptr_t)p;
@@ -419,7 +425,7 @@ __device__ __forceinline__ void dotq2m512_tile(const dq_view &v, char *smem, int
         const int8_t *ds = uni_p(v.rq + (int64_t)st * 512);
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)buf * BUF));
 #pragma unroll
-        for (int i = 0; i < NXP; i++) hbq_dma16<Q2M_NT != 0>(voff, xs + (int64_t)(8 * i) * ld2, dst + i * HBQ_SLOT);
+        for (int i = 0; i < NXP; i++) hbq_dma16<Q2M_NT != 0>(voff, xs + (int64_t)(8 * i) * ld2, dst + i * XSL);
 #pragma unroll
         for (int j = 0; j < NDP; j++) hbq_dma16<false>(doff[j], ds, dst + XB + j * 1024);
     };
@@ -430,8 +436,9 @@ __device__ __forceinline__ void dotq2m512_tile(const dq_view &v, char *smem, int
         for (int k = 0; k < NSC; k++) C[ct][k] = hb_v4i{0, 0, 0, 0};
     const int n = min(m, HB_ND - 1);
     // operand reads: column 16 ct + m = piece 2 ct + (m >> 3), row (m & 7) of it, chunk 4 h + kb; digits of plane n: piece n / 2, lane slot (n & 1) * 32 + 16 h + 4 kb + r
-    const unsigned xlane = (unsigned)((m >> 3) * HBQ_SLOT + ((m & 7) * 8 + kb) * 16);
-    const unsigned dlane = (unsigned)(XB + (n >> 1) * 1024 + ((n & 1) * 32 + 4 * kb) * 16);
+    // (+ 4 h chunks for the second half; SWZ: a chunk step is 8 slots)
+    const unsigned xlane = SWZ ? (unsigned)((m >> 3) * XSL + (kb * 8 + (m & 7)) * 16) : (unsigned)((m >> 3) * XSL + ((m & 7) * 8 + kb) * 16);
+    const unsigned dlane = SWZ ? (unsigned)(XB + n * 16) : (unsigned)(XB + (n >> 1) * 1024 + ((n & 1) * 32 + 4 * kb) * 16);
 #pragma unroll
     for (int a = 0; a < Q2M_NBUF - 1; a++)
         if (st0 + a < st1) issue(st0 + a, a);
@@ -450,12 +457,15 @@ __device__ __forceinline__ void dotq2m512_tile(const dq_view &v, char *smem, int
         for (int h = 0; h < 2; h++) {
             hb_v4i D[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) D[r] = *reinterpret_cast<const hb_v4i *>(bp + dlane + (16 * h + r) * 16);
+            for (int r = 0; r < 4; r++) {
+                const int ch = 16 * h + 4 * kb + r; // SWZ: chunk ch of the stage = piece ch / 8, slot (ch % 8) * 8 + plane
+                D[r] = SWZ ? *reinterpret_cast<const hb_v4i *>(bp + dlane + (ch >> 3) * 1024 + (ch & 7) * 128) : *reinterpret_cast<const hb_v4i *>(bp + dlane + (16 * h + r) * 16);
+            }
             const hb_v4i B0 = hb_v4i{D[0].x, D[1].x, D[2].x, D[3].x}, B1 = hb_v4i{D[0].y, D[1].y, D[2].y, D[3].y},
                          B2 = hb_v4i{D[0].z, D[1].z, D[2].z, D[3].z}, B3 = hb_v4i{D[0].w, D[1].w, D[2].w, D[3].w};
 #pragma unroll
             for (int ct = 0; ct < 4; ct++) {
-                const hb_v4i w = *reinterpret_cast<const hb_v4i *>(bp + 2 * ct * HBQ_SLOT + xlane + 4 * h * 16);
+                const hb_v4i w = *reinterpret_cast<const hb_v4i *>(bp + 2 * ct * XSL + xlane + (SWZ ? 4 * h * 128 : 4 * h * 16));
                 if (SC) {
                     const hb_v4i a0 = w & 0x03030303, a1 = w & 0x0c0c0c0c, a2 = w & 0x30303030;
                     const hb_v4i a3 = hb_v4i{(int)((unsigned)w.x >> 1), (int)((unsigned)w.y >> 1), (int)((unsigned)w.z >> 1), (int)((unsigned)w.w >> 1)} & 0x60606060;
@@ -491,7 +501,8 @@ __device__ __forceinline__ void dotq2m512_tile(const dq_view &v, char *smem, int
     for (int k = 0; k < HB_ND; k++)
         __hip_atomic_fetch_add(v.accq + (int64_t)k * v.accstride + cg * 64 + lane, (long long)tr[k * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-static constexpr int q2m512_lds() { return Q2M_NBUF * (8 * HBQ_SLOT + 4 * 1024); }
+template <bool SWZ>
+static constexpr int q2m512_lds() { return Q2M_NBUF * (8 * (SWZ ? 1152 : HBQ_SLOT) + 4 * 1024); }
 
 template <int CT, int G, bool SC>
 __global__ __launch_bounds__(64) void k_dotq2m(dq_view v, upd_view uq)
@@ -507,7 +518,8 @@ __global__ __launch_bounds__(64) void k_dotq2m(dq_view v, upd_view uq)
         b -= v.nfin;
         update_rows(v.ld, uq, b, reinterpret_cast<int *>(smem), reinterpret_cast<double *>(smem + 2048), reinterpret_cast<int *>(smem + 2048 + 4096), v.ldiag ? v.ldiag + 3 : nullptr);
     } else {
-        if constexpr (G == 0) dotq2m512_tile<SC>(v, smem, b - v.nupd - v.nfin);
+        if constexpr (G == 0) dotq2m512_tile<SC, false>(v, smem, b - v.nupd - v.nfin);
+        else if constexpr (G == 3) dotq2m512_tile<SC, true>(v, smem, b - v.nupd - v.nfin);
         else dotq2m_tile<CT, G, SC>(v, smem, b - v.nupd - v.nfin);
     }
     if (v.stamp && threadIdx.x == 0) {

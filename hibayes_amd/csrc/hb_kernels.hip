@@ -246,9 +246,9 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     int q2m_ct = c->q2m_ct, q2m_g = c->q2m_g;
     while (mfma && q2m_ct > 4 && ncols % (16 * q2m_ct)) q2m_ct /= 2;
     if (q2m_ct == 16 && q2m_g == 2) q2m_g = 1;
-    if (q2m_g == 0 && (c->ld % 512 != 0 || ncols % 64)) q2m_g = 1; // (the 512-individual stages read whole stages of digits: the padded length must be a multiple)
-    if (q2m_g == 0) q2m_ct = 4;
-    const int RS = mfma ? (q2m_g == 0 ? 512 : Q2M_RS) : c->dotq2_rs;
+    if ((q2m_g == 0 || q2m_g == 3) && (c->ld % 512 != 0 || ncols % 64)) q2m_g = 1; // (the 512-individual stages read whole stages of digits: the padded length must be a multiple)
+    if (q2m_g == 0 || q2m_g == 3) q2m_ct = 4;
+    const int RS = mfma ? ((q2m_g == 0 || q2m_g == 3) ? 512 : Q2M_RS) : c->dotq2_rs;
     const int nst = (int)((c->ld + RS - 1) / RS);
     const int ncg = mfma ? ncols / (16 * q2m_ct) : ncols / (64 * cpl);
     // (a tile is at least four stages: its first stage's load latency and its closing atomics are paid per tile)
@@ -293,8 +293,11 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
 #define HB_Q2M_LAUNCH(CT, G, SC) hipLaunchKernelGGL((k_dotq2m<CT, G, SC>), dim3(nblk), dim3(64), (q2m_lds<CT, G>()), st, v, uq)
         const bool sc = c->q2m_sc != 0;
         if (q2m_g == 0) {
-            if (sc) hipLaunchKernelGGL((k_dotq2m<4, 0, true>), dim3(nblk), dim3(64), q2m512_lds(), st, v, uq);
-            else hipLaunchKernelGGL((k_dotq2m<4, 0, false>), dim3(nblk), dim3(64), q2m512_lds(), st, v, uq);
+            if (sc) hipLaunchKernelGGL((k_dotq2m<4, 0, true>), dim3(nblk), dim3(64), q2m512_lds<false>(), st, v, uq);
+            else hipLaunchKernelGGL((k_dotq2m<4, 0, false>), dim3(nblk), dim3(64), q2m512_lds<false>(), st, v, uq);
+        } else if (q2m_g == 3) {
+            if (sc) hipLaunchKernelGGL((k_dotq2m<4, 3, true>), dim3(nblk), dim3(64), q2m512_lds<true>(), st, v, uq);
+            else hipLaunchKernelGGL((k_dotq2m<4, 3, false>), dim3(nblk), dim3(64), q2m512_lds<true>(), st, v, uq);
         } else if (q2m_ct == 16) { if (sc) HB_Q2M_LAUNCH(16, 1, true); else HB_Q2M_LAUNCH(16, 1, false); }
         else if (q2m_ct == 8 && q2m_g == 2) { if (sc) HB_Q2M_LAUNCH(8, 2, true); else HB_Q2M_LAUNCH(8, 2, false); }
         else if (q2m_ct == 8) { if (sc) HB_Q2M_LAUNCH(8, 1, true); else HB_Q2M_LAUNCH(8, 1, false); }

@@ -47,33 +47,25 @@ L.hb_ctx_debug_stamps.argtypes = [ct.c_void_p, ct.c_void_p]
 check(L.hb_ctx_debug_stamps(ctx.h, st.ctypes.data))
 st = st.reshape(npan, 32)[:ng]
 info = RunInfo(); check(L.hb_run_state(run, ct.byref(info)))
-nmv, cand, rounds = st[:, 10], st[:, 12], st[:, 13]
-per = np.append(st[1:, 0] - st[:-1, 0], st[-1, 9] - st[-1, 0])
-cyc = float(st[-1, 9] - st[0, 0])
-print("%s geometry %s: %d groups, %d moves, %d candidates; chain span %d cycles" % (model, ctx.pipeline(), ng, nmv.sum(), cand.sum(), cyc))
+nmv, cand, rounds, redo, rep = st[:, 10], st[:, 12], st[:, 13], st[:, 14], st[:, 15]
+per = np.append(st[1:, 16] - st[:-1, 16], st[-1, 17] - st[-1, 16])
+cyc = float(st[-1, 17] - st[0, 16])
+names = ["dots (waiting)", "ranking", "exact data", "gram gather", "serial pass", "fold+verify", "commit+publish", "forward", "end of group", "drift pre-check"]
+print("%s geometry %s: %d groups, %d moves, %d candidates (first rounds), %d committed rounds, %d rolled back, %d repeated by the pre-check; chain span %d cycles" % (
+    model, ctx.pipeline(), ng, nmv.sum(), cand.sum(), rounds.sum(), redo.sum(), rep.sum(), cyc))
+print("  whole sweep, cycles by phase (accumulated over all rounds): " + " | ".join("%s %d" % (names[k], st[:, k].sum()) for k in range(10)))
 for name, sel in (("quiet", cand == 0), ("candidates, no move", (cand > 0) & (nmv == 0)), ("1-4 moves", (nmv >= 1) & (nmv <= 4)),
                   ("5-12 moves", (nmv >= 5) & (nmv <= 12)), (">12 moves", nmv > 12)):
     k = sel.sum()
     if not k:
         continue
     s = st[sel]
-    seg = lambda a, b: np.where((s[:, a] > 0) & (s[:, b] > 0), s[:, b] - s[:, a], 0).mean()
-    print("  %-20s groups %4d period %7.0f cyc (%.1f %% of the sweep) waited for dots %3.0f %% rounds %.2f cand %.1f" % (
-        name, k, per[sel].mean(), 100 * per[sel].sum() / cyc, 100 * s[:, 11].mean(), rounds[sel].mean(), cand[sel].mean()))
-    print("      dots %6.0f | rank %6.0f | exact data %6.0f | gram gather %6.0f | serial %6.0f | fold+verify %6.0f | commit+publish %6.0f | forward %6.0f | later rounds+end %6.0f" % (
-        seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4), seg(4, 5), seg(5, 6), seg(6, 7), seg(7, 8), seg(8, 9)))
-if st[:, 16:32].any():   # per-wave stamps (round 5): when each wave had its dots (24..31) and reached the first barrier (16..23), after stamp 1 of wave 0
-    sel = nmv >= 5
-    for name, base in (("dots in hand", 24), ("at barrier B1", 16)):
-        d = st[sel][:, base:base + 8] - st[sel][:, 1:2]
-        print("  groups with >= 5 moves: wave w %-14s minus wave 0's stamp 1, mean cycles: %s" % (name, " ".join("%7.0f" % x for x in d.mean(axis=0))))
-    late = (st[sel][:, 24:32]).argmax(axis=1)
-    print("  the LAST wave to have its dots: histogram over waves 0..7 %s" % np.bincount(late, minlength=8).tolist())
-    d0 = st[sel][:, 24:32] - st[sel][:, 0:1]
-    print("  dots in hand minus stamp 0 (group opened), mean per wave: %s" % " ".join("%7.0f" % x for x in d0.mean(axis=0)))
+    print("  %-20s groups %4d period %7.0f cyc (%.1f %% of the sweep) waited for dots %3.0f %% committed rounds %.2f rolled back %.2f repeated %.2f cand %.1f" % (
+        name, k, per[sel].mean(), 100 * per[sel].sum() / cyc, 100 * (s[:, 11] > 0).mean(), rounds[sel].mean(), redo[sel].mean(), rep[sel].mean(), cand[sel].mean()))
+    print("      " + " | ".join("%s %.0f" % (names[q], s[:, q].mean()) for q in range(10)))
 print("moves/sweep %.0f" % info.mean_events)
-busy = st[:, 9] - st[:, 1]   # the group's work once its dots are in hand
-opening = st[:, 1] - st[:, 0]
+busy = st[:, 1:10].sum(axis=1)   # the group's work once its dots are in hand
+opening = st[:, 0]
 q = lambda a: "mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (a.mean(), *np.percentile(a, [50, 90, 99]), a.max())
 print("busy cycles per group:   ", q(busy))
 print("opening (dots, waiting): ", q(opening))
