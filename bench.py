@@ -7,8 +7,9 @@ BayesR (configs[2]) is measured on the same genotypes and reported under "second
 One step = one iteration of the reference's MCMC loop (src/Bayes.cpp:477-917): intercept draw,
 the full m-marker sweep on the device, the end-of-sweep reductions and the host hyper-parameter
 draws — on synthetic genotypes already resident in HBM (SURVEY.md §8 d). `value` is measured on the 2-bit resident layout
-(--bits 2) with the default v_dot4 mat-vec; the same invocation also measures and reports the int8-column layout
-of SURVEY §8 a1 (`int8`: the HBM-bound kernel north_star's 40 % target is stated for) and the matrix-core A/B kernel (`mfma_ab`).
+(--bits 2) with the library's default mat-vec for that layout (k_dotq2m since round 5); the same invocation also measures
+and reports the int8-column layout of SURVEY §8 a1 (`int8`: the HBM-bound v_dot4 kernel north_star's 40 % target is stated for) and the
+other 2-bit kernel (`vdot4_ab`: k_dotq2, north_star's literal "no MFMA" formulation).
 
   python bench.py --gpus 1 --steps K --warmup W            single GPU
   python bench.py --gpus N ...                             starts N ranks itself (torch.distributed.run, one per GPU)
@@ -73,6 +74,9 @@ def parse():
     ap.add_argument("--bits", type=int, default=int(os.environ.get("HB_BENCH_BITS", "2")), choices=[2, 8],
                     help="resident genotype layout the sweep reads: 8 = int8 columns (SURVEY §8 a1), 2 = 2 bits per genotype (§8 f1: "
                          "PLINK's density, expanded in registers inside the mat-vec; a quarter of the bytes; same chain bit for bit)")
+    ap.add_argument("--matvec-kernel", type=int, default=int(os.environ.get("HB_DOTQ2_KIND", "2")), choices=[0, 1, 2],
+                    help="2-bit layout: which kernel computes the panel mat-vec for the headline `value` — 2 = k_dotq2m (matrix cores; the library "
+                         "default since round 5), 0 = k_dotq2 (v_dot4), 1 = k_dotq2r; the other of {2, 0} is measured as the `vdot4_ab` / `mfma_ab` side leg")
     ap.add_argument("--seed", type=int, default=20240901)
     ap.add_argument("--cpu-m", type=int, default=8000, help="markers of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-sweeps", type=int, default=4)
@@ -234,6 +238,8 @@ def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8, kin
     ach = res / (avg_ms * 1e-3) / 1e9
     kernel = ("k_dotq2m" if kind == 2 else "k_dotq2r" if kind == 1 else "k_dotq2") if (bits == 2 and args.precise == 2) else ("k_dotq" if args.precise == 2 else "k_dot")
     bound = "hbm" if kernel in ("k_dotq", "k_dot", "k_dotq2m") else "valu"
+    # (k_dotq2m: priced against HBM — what its launch would be bound by if nothing else were; in situ its update rows wait for the chain
+    # workgroup, isolated it is limited by how fast 64-column tiles of 512 individuals arrive per compute unit: see DESIGN.md section 6)
     r = {"bound": bound, "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": res, "avg_launch_ms": avg_ms,
          "launches_per_sweep": insitu["launches_per_sweep"] if insitu else launches, "columns_per_launch": cols,
@@ -556,6 +562,9 @@ def main():
         pack_s = time.time() - t0
         note("genotypes packed to 2 bits, int8 copy dropped (%.2fs)" % pack_s)
     bits = ctx.layout()[0]
+    kind_main = args.matvec_kernel if (bits == 2 and args.precise == 2) else 0
+    if bits == 2 and args.precise == 2:
+        ctx.set_matvec_kernel(kind_main)
 
     K, W = args.steps, args.warmup
     elapsed, mean_events, nnz, misses = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
@@ -572,8 +581,8 @@ def main():
     # update rows and without the chain, back to back, HIP events on their stream
     ctx.time_matvec(reps=1)                                   # (untimed: clocks and TLBs as in the steady state of a run)
     iso_ms, launches, cols = ctx.time_matvec(reps=5)
-    kernel_main = ("k_dotq2" if bits == 2 else "k_dotq") if args.precise == 2 else "k_dot"
-    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, pmc_traffic(n, cols, kernel_main), bits)
+    kernel_main = (("k_dotq2m" if kind_main == 2 else "k_dotq2r" if kind_main == 1 else "k_dotq2") if bits == 2 else "k_dotq") if args.precise == 2 else "k_dot"
+    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, pmc_traffic(n, cols, kernel_main), bits, kind_main)
     note("mat-vec timing pass done")
 
     # one unit = one pass over m_ref markers (the metric's m = 500k); all ranks together pass over m_global markers per step
@@ -632,22 +641,25 @@ def main():
         return b
 
     single = world == 1
-    # ---- A/B: the same sweep with the digit-plane product on the matrix cores (k_dotq2m; not the default) ----
+    # ---- A/B: the same sweep with the OTHER 2-bit mat-vec kernel (headline on the matrix-core k_dotq2m: the v_dot4 k_dotq2, north_star's literal
+    # "no MFMA" formulation and the default until round 4; headline on k_dotq2: k_dotq2m). Same exact integers, same chain. ----
+    ab_key, ab_kind = ("vdot4_ab", 0) if kind_main == 2 else ("mfma_ab", 2)
     if single and bits == 2 and args.precise == 2 and not args.no_ab:
         try:
-            ctx.set_matvec_kernel(2)
+            ctx.set_matvec_kernel(ab_kind)
             Wm = SIDE_WARMUP
             elm, evm, nnzm, missm = measure(H, L, ctx, y, args.model, K, Wm, args, rank, local_rank, world, m_offset, m_global, comm, torch, note,
                                             burn=0, g_init=g_main, warm=warm_main)
             insm = measure.insitu
             ctx.time_matvec(reps=1)
             isom, lm, cm = ctx.time_matvec(reps=3)
-            res["mfma_ab"] = leg_block(args.model, elm, K, Wm, evm, nnzm, missm, insm, isom, lm, cm, 2, 2, geo, 0)
-            res["mfma_ab"]["note"] = ("A/B, not the headline: the seven digit planes as a skinny int8 GEMM on the matrix cores (v_mfma_i32_16x16x64_i8), "
-                                      "same exact integers and the same chain; warm-started from the headline run's effects")
+            res[ab_key] = leg_block(args.model, elm, K, Wm, evm, nnzm, missm, insm, isom, lm, cm, 2, ab_kind, geo, 0)
+            res[ab_key]["note"] = ("A/B, not the headline: the same sweep with the 2-bit mat-vec on %s; same exact integers and the same chain; continued from the "
+                                   "headline run's effects and hyper-parameters" % ("k_dotq2 (v_dot4_i32_i8, lane = column: no MFMA)" if ab_kind == 0 else
+                                                                                     "k_dotq2m (v_mfma_i32_16x16x64_i8: the seven digit planes as a skinny int8 GEMM)"))
         except Exception as e:
-            res["mfma_ab"] = {"error": repr(e)}
-        ctx.set_matvec_kernel(0)
+            res[ab_key] = {"error": repr(e)}
+        ctx.set_matvec_kernel(kind_main)
     # ---- the int8-column layout of SURVEY 8 a1 (north_star's own layout, the library's default): HBM-bound k_dotq ----
     if single and bits == 2 and args.precise == 2 and not args.no_ab:
         try:
@@ -718,7 +730,7 @@ def main():
             else:
                 res[key] = {"model": side, "error": repr(e)}
     # scalars of the side legs inside `roofline` (the driver's parsed record keeps the scalar keys of this block only)
-    for key, pre in (("int8", "int8"), ("mfma_ab", "mfma")):
+    for key, pre in (("int8", "int8"), ("mfma_ab", "mfma"), ("vdot4_ab", "vdot4")):
         b = res.get(key)
         if isinstance(b, dict) and "roofline" in b:
             roof[pre + "_value"] = b["value"]

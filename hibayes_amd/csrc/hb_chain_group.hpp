@@ -332,15 +332,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // the exact check after the fold stays: the chain is the same exact sequential chain.
             if (v.s1 && nmoves > 0) {
                 unsigned pvm = 0;
+                // (two steps: which of this thread's markers are near enough to their thresholds to be reachable at all — eight compares on
+                // registers, true for a fraction of a percent of the markers — and only for those the look-up of the shift; a wave runs the
+                // second step as often as its busiest lane has near markers, mostly once or not at all)
+                unsigned near = 0;
 #pragma unroll
                 for (int i = 0; i < HBG_DM; i++) {
                     if (i < Dg) {
                         const int pos = i * P + t;
-                        const int before = min(64, __shfl(myscan, i * 8 + wave, 64) + (int)((rkp >> (8 * i)) & 0xffull)); // the round's candidates before this marker
-                        const double rp = fma(-(double)muj[i], spre[before], r0[i]);
-                        const bool pviol = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && rp * rp >= 0.94 * (double)fl[i]; // (NaN filter: false)
-                        pvm |= pviol ? 1u << i : 0u;
+                        const bool nr = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && r0[i] * r0[i] >= 0.3 * (double)fl[i]; // (NaN filter: false)
+                        near |= nr ? 1u << i : 0u;
                     }
+                }
+                for (unsigned left = near; __any(left != 0u); left &= left - 1u) {
+                    const bool mine = left != 0u;
+                    const int i = mine ? __ffs((int)left) - 1 : 0;
+                    double r0i = r0[0];
+                    float fli = fl[0], mui = muj[0];
+#pragma unroll
+                    for (int x = 1; x < HBG_DM; x++) {
+                        r0i = (i == x) ? r0[x] : r0i;
+                        fli = (i == x) ? fl[x] : fli;
+                        mui = (i == x) ? muj[x] : mui;
+                    }
+                    const int before = min(64, __shfl(myscan, i * 8 + wave, 64) + (int)((rkp >> (8 * i)) & 0xffull)); // the round's candidates before this marker
+                    const double rp = fma(-(double)mui, spre[before], r0i);
+                    if (mine && rp * rp >= 0.94 * (double)fli) pvm |= 1u << i;
                 }
                 const unsigned long long pb = __ballot(pvm != 0u);
                 if (lane == 0) misc[24 + wave] = pb != 0ull;

@@ -75,7 +75,10 @@ struct hb_ctx {
     int64_t ld2 = 0;     // bytes per column of X2 = 128 * ceil(ld / 512)
     int layout = 8;      // 8: int8 columns, 2: 2-bit columns
     int dotq2_cpl = 1, dotq2_tiles = 1600, dotq2_rs = 256; // (tiles per full-width k_dotq2 launch, HB_DOTQ2_TILES: 1568 of seven stages at n = 50k — with two waves per SIMD (Q2_TWO_PER_SIMD) 2048 waves are resident, and tiles + update rows + the chain's and k_fwd's compute units must fit; until that cap 2000 -> 1848 tiles of six stages: 296 against 300 sweeps/s)
-    int dotq2_kind = 0, dotq2_nc = 16;    // (measured: 23.3 us per 3584-column launch for kind 0 at these defaults, 26.1 for kind 1) 1: individuals across the lanes, no LDS (k_dotq2r), NC columns per tile; 0: lane = column through LDS (k_dotq2) // k_dotq2 launch shape (HB_DOTQ2_CPL, HB_DOTQ2_TILES)
+    // which kernel computes the panel mat-vec on 2-bit resident genotypes (HB_DOTQ2_KIND / hb_ctx_set_matvec_kernel; all three give the same exact integers):
+    // 2 (default since round 5) k_dotq2m, the seven digit planes as a skinny int8 GEMM on the matrix cores — 12.0 us per 3584-column launch isolated; 0 k_dotq2,
+    // lane = column through LDS, v_dot4 (22 us: VALU-issue-bound; the default until round 4); 1 k_dotq2r, individuals across the lanes, no LDS, NC columns per tile (26 us)
+    int dotq2_kind = 2, dotq2_nc = 16;
     double *xpx = nullptr, *vx = nullptr, *g = nullptr, *vargL = nullptr;
     double *s1 = nullptr; // column sums of the resident rows (k_stats), for the row-sharded mode's global statistics
     double *alpha_sum = nullptr, *alpha_sq = nullptr;
@@ -94,7 +97,8 @@ struct hb_ctx {
     size_t gram_cap = 0; // ints allocated
     bool env_pinned = false;
     int dot_lds = 0;     // dynamic LDS bytes requested by each mat-vec workgroup: caps the workgroups resident per CU
-    int q2m_ct = 4, q2m_g = 1, q2m_sc = 1; // k_dotq2m's shape (HB_Q2M_CT / _G / _SC): column tiles of 16 per wave, stages requested together, per-scale accumulators
+    int q2m_ct = 4, q2m_g = 0, q2m_sc = 1; // k_dotq2m's shape (HB_Q2M_CT / _G / _SC): column tiles of 16 per wave; stages requested together (1, 2) or 512-individual stages of whole-line
+                                           // DMA pieces (0, the default since round 5: 12.3 against 15.3 us per launch; 3: the same with conflict-free lane order); per-scale accumulators
     bool drift_check = false; // k_chain_group: predicted threshold crossings from the round's mean drift join the candidates before the fold (HB_DRIFT=1; measured: no rolled-back rounds left, 3-5 % slower — the repeats of the serial pass cost what the roll-backs did)
     double candf = 1.0;  // chain candidates: markers at zero with q >= candf * thr0 (tuning knob; <= 1)
     double kappa = 3.0; // row-cache prediction: markers with thr0 <= kappa * xx * vare get their Gram row prefetched

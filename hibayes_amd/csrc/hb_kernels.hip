@@ -254,7 +254,7 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     // (a tile is at least four stages: its first stage's load latency and its closing atomics are paid per tile)
     // (the matrix-core kernel streams best with few, long tiles — its per-stage work is an eighth of the v_dot4 kernel's, so a tile's fixed
     // costs weigh more: ~800 tiles per 3584-column launch)
-    int ns = std::max(1, std::min(std::max(1, nst / 4), (int)((double)(mfma && !getenv("HB_DOTQ2_TILES") ? 800 : c->dotq2_tiles) / ncg + 0.5)));
+    int ns = std::max(1, std::min(std::max(1, nst / 4), (int)((double)(mfma && !getenv("HB_DOTQ2_TILES") ? ((q2m_g == 0 || q2m_g == 3) ? 900 : 800) : c->dotq2_tiles) / ncg + 0.5)));
     // (int32 accumulators of genotypes scaled by up to 32 — Q2_SCALED, k_dotq2m: rows x 96 x 128 < 2^31 bounds a tile at 174 000 individuals)
     ns = std::max(ns, (int)(((int64_t)nst * RS + 131071) / 131072));
     const int NS = (nst + ns - 1) / ns, nsplit = (nst + NS - 1) / NS;

@@ -362,10 +362,13 @@ int hb_ctx_download_genotype(hb_ctx *c, int8_t *X, int64_t ld, int32_t col0, int
  * rebuild unpacks panel by panel into a scratch buffer). bits = 8 on a context that dropped its int8 copy unpacks it again. */
 int hb_ctx_set_layout(hb_ctx *c, int32_t bits, int32_t keep_int8);
 int hb_ctx_get_layout(const hb_ctx *c, int32_t *bits, int32_t *int8_resident);
-/* Which kernel computes the panel mat-vec on 2-bit resident genotypes (ABI 5; all three produce the same exact integers):
- * 0 = k_dotq2, lane = column, v_dot4_i32_i8 (the default: north_star's "coalesced loads with LDS-staged wavefront reductions,
- * no MFMA"); 1 = k_dotq2r, individuals across the lanes; 2 = k_dotq2m, the seven digit planes as a skinny int8 GEMM on the
- * matrix cores (v_mfma_i32_16x16x64_i8) — a measured A/B, selected here or with HB_DOTQ2_KIND=2. */
+/* Which kernel computes the panel mat-vec on 2-bit resident genotypes (ABI 5; all three produce the same exact integers, hence the same
+ * chain bit for bit): 2 = k_dotq2m, the seven digit planes of the residual as a skinny int8 GEMM on the matrix cores
+ * (v_mfma_i32_16x16x64_i8) — THE DEFAULT since round 5 (12 us per 3584-column launch at n = 50k against 22: with the residual held as
+ * seven int8 planes the product [columns x individuals] x [individuals x 7] is a dense integer contraction, and the v_dot4 form is bound
+ * by vector-ALU issue, not by memory); 0 = k_dotq2, lane = column, v_dot4_i32_i8 (north_star's literal "coalesced loads with LDS-staged
+ * wavefront reductions, no MFMA"; the default until round 4, kept selectable and measured beside the default by bench.py); 1 = k_dotq2r,
+ * individuals across the lanes. Also HB_DOTQ2_KIND. The int8-column layout (the library's default layout) always runs k_dotq: v_dot4, no MFMA. */
 int hb_ctx_set_matvec_kernel(hb_ctx *c, int32_t kind);
 
 /* xpx_i = sum x^2, vx_i = var(x_i) (N-1), reference src/Bayes.cpp:310-317; integer-exact */
