@@ -41,7 +41,10 @@
 // Template shape: HBG_DM = panels per group the register arrays are sized for (>= D), HBG_FW = panels ahead a move is folded into
 // (>= Lv * D), HBG_CH = moves whose rows are requested together — HBG_CH * (HBG_DM + HBG_FW) loads per lane and trip, ~60: a narrow
 // geometry (few rows per move) takes many moves per trip, the wide one of the stationary point-mass sweep three.
-template <int K1, int HBG_DM, int HBG_FW, int HBG_CH>
+// G16 (round 5): the rows of a move come from the compact band (hb_ctx.gram16: int16 residuals of G - ga (x) gB, half the bytes) and the rank-one
+// part is added once per marker and fold, from the sum of ga[k] * delta_k over the moves the marker takes: sum_k G[k][j] d_k = sum_k g16[k][j] d_k
+// + gB[j] * sum_k ga[k] d_k. Same products in another grouping: effects agree with the int32 fold to the last bits' rounding.
+template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
                                                                                                  persist_view pv)
 {
@@ -61,7 +64,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     double *red = ev_del + 64;                                  // [16]
     double *spre = red + 16;                                    // [65] drift pre-check: spre[k] = sum of (column sum x change) over the round's candidates before candidate k
     double *cs_s1 = spre + 66;                                  // [64] the candidates' column sums
-    int *cs_pos = reinterpret_cast<int *>(cs_s1 + 64);          // candidate -> position in the group (panel * P + marker)
+    double *cs_a = cs_s1 + 64;                                  // [64] G16: the candidates' ga[]
+    double *ev_ak = cs_a + 64;                                  // [64] G16: the round's moves: ga[mover] * change
+    int *cs_pos = reinterpret_cast<int *>(ev_ak + 64);          // candidate -> position in the group (panel * P + marker)
     int *res_c = cs_pos + 64;                                   // ... new classes
     int *ev_pos = res_c + 64;                                   // the round's moves: position
     int *cg = ev_pos + 64;                                      // [64][64] Gram entries among the round's candidates (k < c)
@@ -97,6 +102,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         double r0[HBG_DM];
         float fl[HBG_DM];
         float muj[HBG_DM]; // mean genotype of marker (i, t) (drift pre-check; 0 without it)
+        int gBi[G16 ? HBG_DM : 1], gBf[G16 ? HBG_FW : 1]; // G16: gB of this thread's markers in the group and in the panels ahead
+        (void)gBi; (void)gBf;
+        if constexpr (G16) {
+#pragma unroll
+            for (int i = 0; i < HBG_DM; i++) gBi[i] = v.gB[(size_t)(gp0 + min(i, Dg - 1)) * P + t];
+#pragma unroll
+            for (int x = 0; x < HBG_FW; x++) gBf[x] = v.gB[(size_t)min(gp0 + D + x, np - 1) * P + t];
+        }
         {
             double dj[HBG_DM], fc[HBG_DM];
             // (k_fwd writes the corrections the moves of the group before the last owe this one: sentinel-prefilled like the dots)
@@ -106,13 +119,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // trip per look. Re-reading only what is missing puts each load behind a branch — a dozen dependent trips per look,
             // most of them after the values have arrived)
             const double *fcp = far_in ? pv.fcorr : v.dsum; // (without k_fwd's share: any readable words, not looked at)
+            const double *s1p = v.s1 ? v.s1 : v.xpx;        // (without the drift pre-check: inv_n is 0)
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) {
                 const size_t j = (size_t)(gp0 + min(i, Dg - 1)) * P + t;
                 dj[i] = ld_sc1(&v.dsum[j]);
                 fl[i] = pv.thr0f[j];
                 fc[i] = ld_sc1(&fcp[j]);
-                muj[i] = v.s1 ? (float)(v.s1[j] * v.inv_n) : 0.f;
+                muj[i] = (float)(s1p[j] * v.inv_n); // (unconditional: a load behind a uniform branch is waited for on the spot)
             }
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) fl[i] = i < Dg ? fl[i] : __int_as_float(0x7fc00000);
@@ -238,7 +252,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         cs_d[(2 + 2 * K1 + c) * 64 + rank] = v.sdz[(size_t)c * v.m_pad + j];
                     }
                     cs_pos[rank] = i * P + t;
-                    cs_s1[rank] = v.s1 ? v.s1[j] : 0.0;
+                    cs_s1[rank] = (v.s1 ? v.s1 : v.xpx)[j]; // (unconditional load; unused without the pre-check)
+                    if constexpr (G16) cs_a[rank] = (double)v.ga[j];
                     rk |= (unsigned long long)rank << (8 * i);
                     inrm |= 1u << i;
                 }
@@ -304,6 +319,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int pos = __popcll(moved & lt);
                     ev_pos[pos] = cp;
                     ev_del[pos] = dmine;
+                    if constexpr (G16) ev_ak[pos] = cs_a[lane] * dmine;
                 }
                 res_c[lane] = cls;
                 res_g[lane] = gn;
@@ -386,12 +402,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < HBG_DM; i++) rnew[i] = r0[i];
 #pragma unroll
             for (int x = 0; x < HBG_FW; x++) fw[x] = 0.0;
+            double ra[G16 ? HBG_DM : 1], rA = 0.0; // G16: sum of ga[k] * delta_k over the moves marker (i, t) takes / over all moves of the round
+            (void)ra; (void)rA;
+            if constexpr (G16) {
+#pragma unroll
+                for (int i = 0; i < HBG_DM; i++) ra[i] = 0.0;
+            }
             // (row addresses are "wave-uniform pointer"[t]: scalar base + one vector offset, no 64-bit vector arithmetic)
+            using gram_t = typename std::conditional<G16, int16_t, int32_t>::type;
+            const gram_t *gbase = G16 ? reinterpret_cast<const gram_t *>(v.gram16) + (size_t)gp0 * (pv.Lg + 1) * PP : reinterpret_cast<const gram_t *>(gblk0);
 #pragma unroll 1
             for (int e0 = 0; e0 < nmoves; e0 += HBG_CH) {
                 int gv[HBG_CH][HBG_DM], gf[HBG_CH][HBG_FW];
                 int pae[HBG_CH], iae[HBG_CH];
-                double dl[HBG_CH];
+                double dl[HBG_CH], akd[HBG_CH];
 #pragma unroll
                 for (int f = 0; f < HBG_CH; f++) {
                     const int e = min(e0 + f, nmoves - 1);
@@ -399,6 +423,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     pae[f] = a >> lgP;
                     iae[f] = a & (P - 1);
                     dl[f] = (e0 + f < nmoves) ? ev_del[e] : 0.0;
+                    akd[f] = (G16 && e0 + f < nmoves) ? ev_ak[e] : 0.0;
                 }
 #pragma unroll
                 for (int f = 0; f < HBG_CH; f++) {
@@ -406,14 +431,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     // gblk0 + (i (Lg + 1) + i - pae) PP = (gblk0 - pae PP) + i (Lg + 2) PP; the panels ahead continue the same walk.
                     // Branch-free: a panel before the mover's or past the group's end reads a neighbouring valid row instead (its
                     // value is not used) — behind a branch every load would be waited for on the spot.
-                    const int32_t *row = gblk0 + (size_t)iae[f] * P + (size_t)pae[f] * (pstep - PP); // i = pae
+                    const gram_t *row = gbase + (size_t)iae[f] * P + (size_t)pae[f] * (pstep - PP); // i = pae
 #pragma unroll
                     for (int i = 0; i < HBG_DM; i++) {
                         gv[f][i] = row[t];
                         row += (i >= pae[f] && i + 1 < Dg) ? pstep : 0; // (scalar select)
                     }
                     // (no panel ahead at the end of the sweep: the loads stay, on an address that exists; their values are not used)
-                    row = have_fw ? gblk0 + (size_t)iae[f] * P + (size_t)D * pstep - (size_t)pae[f] * PP : gblk0; // first panel ahead
+                    row = have_fw ? gbase + (size_t)iae[f] * P + (size_t)D * pstep - (size_t)pae[f] * PP : gbase; // first panel ahead
 #pragma unroll
                     for (int x = 0; x < HBG_FW; x++) {
                         gf[f][x] = row[t];
@@ -426,11 +451,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int i = 0; i < HBG_DM; i++) {
                         // marker (i, t) takes the move of (pae, iae) if it comes later in the order
                         const bool later = i > pae[f] || (i == pae[f] && t > iae[f]);
-                        if (i < Dg && later) rnew[i] = fma(-(double)gv[f][i], dl[f], rnew[i]);
+                        if (i < Dg && later) {
+                            rnew[i] = fma(-(double)gv[f][i], dl[f], rnew[i]);
+                            if constexpr (G16) ra[i] += akd[f];
+                        }
                     }
 #pragma unroll
                     for (int x = 0; x < HBG_FW; x++) fw[x] = (x < nfw) ? fma((double)gf[f][x], dl[f], fw[x]) : fw[x];
+                    if constexpr (G16) rA += akd[f];
                 }
+            }
+            if constexpr (G16) { // the rank-one part: gB[j] * (sum of ga[k] d_k over the moves j takes)
+#pragma unroll
+                for (int i = 0; i < HBG_DM; i++) rnew[i] = fma(-(double)gBi[i], ra[i], rnew[i]);
+#pragma unroll
+                for (int x = 0; x < HBG_FW; x++) fw[x] = (x < nfw) ? fma((double)gBf[x], rA, fw[x]) : fw[x];
             }
             // ---- (6) did every marker the round passed over really stay below its threshold? ----
             unsigned violm = 0;
@@ -587,12 +622,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // forward sums: the same chain in exact arithmetic (tests: draw for draw).
 // HBF_D = D panels per group (slot y of fs[] is panel y counted from the first panel of group g + 2), HBF_G = Lv - 1 groups.
 // ---------------------------------------------------------------------------------------------
-template <int HBF_D, int HBF_G, int HBF_CH>
+template <int HBF_D, int HBF_G, int HBF_CH, bool G16 = false>
 __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
 {
     constexpr int NF = HBF_D * HBF_G;
     __shared__ int s_pos[HBF_D * 512];    // the group's moves: panel * P + marker
     __shared__ double s_del[HBF_D * 512]; // ... and changes of effect
+    __shared__ double s_ak[G16 ? HBF_D * 512 : 1]; // G16: ga[mover] * change
     __shared__ int s_cnt[HBF_D + 1], s_ok;
     const int P = v.P, t = threadIdx.x, lgP = 31 - __clz(P);
     const int D = pv.D, np = pv.npanels, G = pv.Lv - 1;
@@ -642,10 +678,20 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
                 if (ix < 0 || __double_as_longlong(dl) == -1ll) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); ix = 0; dl = 0.0; }
                 s_pos[b + k] = i * P + ix;
                 s_del[b + k] = dl;
+                if constexpr (G16) s_ak[b + k] = (double)v.ga[(size_t)(gp0 + i) * P + ix] * dl;
             }
         }
         __syncthreads();
-        const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP;
+        using gram_t = typename std::conditional<G16, int16_t, int32_t>::type;
+        const gram_t *gblk0 = (G16 ? reinterpret_cast<const gram_t *>(v.gram16) : reinterpret_cast<const gram_t *>(v.gram)) + (size_t)gp0 * (pv.Lg + 1) * PP;
+        int gBy[G16 ? NF : 1]; // G16: gB of this thread's marker in each far panel
+        (void)gBy;
+        if constexpr (G16) {
+#pragma unroll
+            for (int y = 0; y < NF; y++) gBy[y] = v.gB[(size_t)min(gp0 + 2 * D + y, np - 1) * P + t];
+        }
+        double rA = 0.0;
+        (void)rA;
 #pragma unroll 1
         for (int e0 = 0; e0 < nev; e0 += HBF_CH) {
             int gf[HBF_CH][NF];
@@ -656,8 +702,9 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
                 const int a = __builtin_amdgcn_readfirstlane(s_pos[e]);
                 const int pa = a >> lgP, ia = a & (P - 1);
                 dl[f] = (e0 + f < nev) ? s_del[e] : 0.0;
+                if constexpr (G16) rA += (e0 + f < nev) ? s_ak[e] : 0.0;
                 // panel y (counted from the first panel of group g + 2) meets the mover in block l = 2 D + y - pa: the chain's walk, 2 D panels on
-                const int32_t *row = gblk0 + (size_t)ia * P + (size_t)(2 * D) * pstep - (size_t)pa * PP;
+                const gram_t *row = gblk0 + (size_t)ia * P + (size_t)(2 * D) * pstep - (size_t)pa * PP;
 #pragma unroll
                 for (int y = 0; y < NF; y++) {
                     gf[f][y] = row[t];
@@ -668,6 +715,10 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
             for (int f = 0; f < HBF_CH; f++)
 #pragma unroll
                 for (int y = 0; y < NF; y++) fs[y] = (y < nfar) ? fma((double)gf[f][y], dl[f], fs[y]) : fs[y];
+        }
+        if constexpr (G16) { // the rank-one part of this group's moves, once per far marker
+#pragma unroll
+            for (int y = 0; y < NF; y++) fs[y] = (y < nfar) ? fma((double)gBy[y], rA, fs[y]) : fs[y];
         }
         // group g + 2 has now heard from every group that owes it: publish, and shift what the later ones have so far
 #pragma unroll

@@ -31,6 +31,9 @@ struct chain_view {
     // zero: no pre-check (the exact violation check after the fold still catches everything).
     const double *s1;
     double inv_n;
+    // round 5: the band as rank one + int16 residual (hb_ctx.gram16): G[k][j] = ga[k] * gB[j] + gram16[k][j]; null: not built
+    const int16_t *gram16;
+    const int32_t *ga, *gB;
 };
 
 // Cycle stamps of the chain kernels (tools/chain_timeline.py): compiled in only with -DHB_STAMPS=1 (tools/build_variant.sh) —

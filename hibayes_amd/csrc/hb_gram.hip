@@ -145,6 +145,72 @@ static int gram_launch(hb_ctx *c, const int8_t *Xv, int pa, int pb)
     return HB_OK;
 }
 
+// ---- the compact band (round 5): G = ga (x) gB + int16 residual ----
+__global__ void k_g16_ab(const double *__restrict__ s1, int m_pad, double n, int32_t *__restrict__ ga, int32_t *__restrict__ gB)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m_pad) return;
+    const double s = s1[j];
+    ga[j] = (int32_t)rint(s / 256.0);
+    gB[j] = (int32_t)rint(s * 256.0 / n);
+}
+// one thread per four consecutive entries of a row (the band's own order: [panel][block l][row k][column t])
+__global__ __launch_bounds__(256) void k_gram16(const int32_t *__restrict__ gram, int16_t *__restrict__ g16, const int32_t *__restrict__ ga,
+                                                const int32_t *__restrict__ gB, int P, int Lg, size_t nquads, int *__restrict__ flag)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nquads) return;
+    const size_t idx = q * 4, PP = (size_t)P * P;
+    const size_t blk = idx / PP, within = idx % PP;
+    const int p = (int)(blk / (size_t)(Lg + 1)), l = (int)(blk % (size_t)(Lg + 1));
+    const int k = (int)(within / P), t = (int)(within % P);
+    const int4 gq = *reinterpret_cast<const int4 *>(gram + idx);
+    int a = 0;
+    if (p - l >= 0) a = ga[(size_t)(p - l) * P + k];
+    const int4 bq = *reinterpret_cast<const int4 *>(gB + (size_t)p * P + t);
+    const int c0 = gq.x - a * bq.x, c1 = gq.y - a * bq.y, c2 = gq.z - a * bq.z, c3 = gq.w - a * bq.w;
+    const int lo = min(min(c0, c1), min(c2, c3)), hi = max(max(c0, c1), max(c2, c3));
+    if (p - l >= 0 && (lo < -32767 || hi > 32767)) *flag = 1; // (any writer: the band then stays int32 only)
+    short4 o;
+    o.x = (short)c0; o.y = (short)c1; o.z = (short)c2; o.w = (short)c3;
+    *reinterpret_cast<short4 *>(g16 + idx) = o;
+}
+
+// after the int32 band is in place: the compact copy, if every residual fits an int16 (non-negative genotype codes only: the column
+// sums are then the scale of every product)
+int hb_build_gram16(hb_ctx *c)
+{
+    c->gram16_ok = false;
+    if (!c->gram16_on || c->xmin < 0 || c->P % 4 != 0 || c->row_reduce) return HB_OK; // (row-sharded mode: the local blocks are partial sums)
+    const size_t need = (size_t)c->m_pad * (size_t)c->P * (size_t)(c->Lg + 1);
+    if (need > c->gram16_cap) {
+        if (c->gram16) { (void)hipFree(c->gram16); c->gram16 = nullptr; }
+        c->gram16_cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&c->gram16), need * sizeof(int16_t)) != hipSuccess) { // (no room: the int32 band serves)
+            (void)hipGetLastError();
+            c->gram16 = nullptr;
+            return HB_OK;
+        }
+        c->gram16_cap = need;
+    }
+    if (!c->ga) {
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->ga), sizeof(int32_t) * (size_t)c->m_pad));
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->gB), sizeof(int32_t) * (size_t)c->m_pad));
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->g16_flag), sizeof(int)));
+    }
+    HB_HIP(hipMemsetAsync(c->g16_flag, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_g16_ab, dim3((c->m_pad + 255) / 256), dim3(256), 0, c->stream, c->s1, c->m_pad, (double)c->n, c->ga, c->gB);
+    const size_t nquads = need / 4;
+    hipLaunchKernelGGL(k_gram16, dim3((unsigned)((nquads + 255) / 256)), dim3(256), 0, c->stream, c->gram, c->gram16, c->ga, c->gB, c->P, c->Lg,
+                       nquads, c->g16_flag);
+    HB_HIP(hipGetLastError());
+    int flag = 0;
+    HB_HIP(hipMemcpyAsync(&flag, c->g16_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    c->gram16_ok = flag == 0;
+    return HB_OK;
+}
+
 int hb_build_gram_impl(hb_ctx *c)
 {
     if (c->X) return gram_launch(c, c->X, 0, c->npanels);

@@ -95,6 +95,15 @@ struct hb_ctx {
     long long *accq = nullptr;    // [HB_ND][m_pad] exact digit-plane sums of the current sweep's mat-vecs
     int32_t *gram = nullptr;
     size_t gram_cap = 0; // ints allocated
+    // Round 5: the band once more as "rank one + int16 residual" — G[k][j] = ga[k] * gB[j] + gram16[k][j] exactly, with ga = rint(s1 / 256),
+    // gB = rint(256 s1 / n) (s1: column sums): the product is the part of x_k . x_j that every pair of markers shares (n mean_k mean_j), what is
+    // left is n cov(k, j) plus rounding, a few hundred for unlinked markers and at most n var for a pair in full LD. The group chain and k_fwd
+    // fold a move's rows from it: half the bytes of the phase that is 44 % of their time. Built when every residual fits (else null: the int32 band serves).
+    int16_t *gram16 = nullptr;
+    size_t gram16_cap = 0;
+    int32_t *ga = nullptr, *gB = nullptr;
+    int *g16_flag = nullptr;
+    bool gram16_ok = false, gram16_on = true; // (HB_GRAM16=0: off)
     bool env_pinned = false;
     int dot_lds = 0;     // dynamic LDS bytes requested by each mat-vec workgroup: caps the workgroups resident per CU
     int q2m_ct = 4, q2m_g = 0, q2m_sc = 1; // k_dotq2m's shape (HB_Q2M_CT / _G / _SC): column tiles of 16 per wave; stages requested together (1, 2) or 512-individual stages of whole-line
@@ -205,6 +214,7 @@ extern "C" int hb_ctx_sweep_begin(hb_ctx *c, const hb_sweep_in *in);
 extern "C" int hb_ctx_sweep_end(hb_ctx *c, hb_sweep_out *out);
 int hb_comm_allreduce_f64(hb_comm *c, double *buf, size_t count, hipStream_t st);
 int hb_build_gram_impl(hb_ctx *c);
+int hb_build_gram16(hb_ctx *c);
 
 // device buffers of one summary-level run (hb_sbayes.hip owns them; the kernels are in hb_sbayes.hpp)
 struct hb_sb_dev {

@@ -164,8 +164,10 @@ int hbk_init_attrs()
     HB_PERSIST_ATTR(3, 0); HB_PERSIST_ATTR(3, 2);
     HB_PERSIST_ATTR(7, 0); HB_PERSIST_ATTR(7, 2);
 #define HB_GROUP_ATTR(K1, DM, FW, CH) HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<K1, DM, FW, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+#define HB_GROUP_ATTR16(K1, DM, FW, CH) HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<K1, DM, FW, CH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     HB_GROUP_ATTR(1, 8, 14, 3); HB_GROUP_ATTR(1, 8, 7, 4); HB_GROUP_ATTR(1, 2, 4, 10); HB_GROUP_ATTR(1, 1, 2, 20);
     HB_GROUP_ATTR(3, 1, 2, 20); HB_GROUP_ATTR(7, 1, 2, 20);
+    HB_GROUP_ATTR16(1, 8, 7, 4);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -662,6 +664,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
     if (c->drift_check) { cv.s1 = c->s1; cv.inv_n = 1.0 / (double)c->n; }
+    const bool g16 = c->gram16_ok && c->gram16 != nullptr; // (the compact band: only the wide group chain and its k_fwd read it)
+    if (g16) { cv.gram16 = c->gram16; cv.ga = c->ga; cv.gB = c->gB; }
     const int last_panels = np - (g0 + ngroups - 1) * D;
     persist_view pv{np, D, Lv, c->L, c->Lg, pb, c->flags,
                     c->hot_slot, c->hot_list, c->thr0f, c->candf, nullptr};
@@ -697,7 +701,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         }
         if (group_chain) {
             const size_t sm = persist_smem(c->P);
-            if (fwd) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            if (fwd && g16) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            else if (fwd) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (kp == 1 && shape == 0) hipLaunchKernelGGL((k_chain_group<1, 8, 14, 3>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (kp == 1 && shape == 1) hipLaunchKernelGGL((k_chain_group<1, 2, 4, 10>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (kp == 1) hipLaunchKernelGGL((k_chain_group<1, 1, 2, 20>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
@@ -756,7 +761,9 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     }
     if (fwd) {
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
-        if (Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+        if (Lv == 2 && g16) hipLaunchKernelGGL((k_fwd<7, 1, 8, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+        else if (Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+        else if (g16) hipLaunchKernelGGL((k_fwd<7, 2, 4, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else hipLaunchKernelGGL((k_fwd<7, 2, 4>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         HB_HIP(hipGetLastError());
     }

@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 5, eleventh GPU session: the compact band (rank one + int16 residual) in the group chain and k_fwd: parity, then sweeps/s with / without it and the drift pre-check
+cd /root/repo
+O=gpurun_out
+python -m pytest tests/test_gpu_depth.py tests/test_gpu_parity.py tests/test_gpu_recovery.py -m gpu -x -q 2>&1 | tail -2 | tee $O/r5_g16_tests.txt
+python -m pytest tests/test_gpu_configs.py -m gpu -x -q -k "config3_bayescpi or stationary or config2 or config5 or config4" 2>&1 | tail -2 | tee -a $O/r5_g16_tests.txt
+for cfg in "1 0" "0 0" "1 1"; do set -- $cfg
+  HB_GRAM16=$1 HB_DRIFT=$2 python bench.py --steps 200 --warmup 100 --no-cpu --secondary '' --tertiary '' > $O/r5_g16_$1_drift$2.json 2> $O/r5_g16_$1_drift$2.err
+  python - <<PY
+import json
+d=json.loads(open('$O/r5_g16_$1_drift$2.json').read().strip().splitlines()[-1])
+print('gram16 $1 drift $2: value %.1f [%s] (redo %.1f, launch %.2f us in situ, %.2f isolated) vdot4 %.1f (launch %.2f us) int8 %.1f; setup gram %.2f s' % (d['value'], d['roofline']['kernel'], d['config']['chain_rounds_rolled_back_per_sweep'],
+      d['roofline']['avg_launch_ms']*1e3, d['roofline']['isolated']['avg_launch_ms']*1e3, d['vdot4_ab']['value'], d['vdot4_ab']['roofline']['avg_launch_ms']*1e3, d['int8']['value'], d['config']['setup_seconds']['gram']))
+PY
+done 2>&1 | tee $O/r5_g16.txt
