@@ -25,8 +25,8 @@
 // Stamped build (tools/group_timeline.py): per mat-vec group 32 words — [0..9] cycles ACCUMULATED per phase over all rounds of the group, rolled-back
 // and repeated ones included (round 4 kept one stamp per phase, overwritten by every repetition of the first round, which made the
 // candidate ranking look like the longest phase: it was the roll-backs) — 0 opening (waiting for the dots), 1 ranking, 2 exact data,
-// 3 gather, 4 serial pass, 5 fold + verify, 6 commit + publish, 7 forward, 8 end of group, 9 drift pre-check; counters: 10 moves, 11 waited for
-// dots, 12 candidates of the first round, 13 committed rounds, 14 rolled-back rounds, 15 rounds repeated by the pre-check; 16 / 17 clock at
+// 3 gather, 4 serial pass, 5 fold + verify, 6 commit + publish, 7 forward, 8 end of group; counters: 10 moves, 11 waited for
+// dots, 12 candidates of the first round, 13 committed rounds, 14 rolled-back rounds; 16 / 17 clock at
 // the group's start / end.
 #define HBG_BEGIN() do { if (v.dbg && t == 0) { for (int z_ = 0; z_ < 32; z_++) v.dbg[(size_t)gcount * 32 + z_] = 0; hbg_tl = clock64(); v.dbg[(size_t)gcount * 32 + 16] = hbg_tl; } } while (0)
 #define HBG_ACC(k) do { if (v.dbg && t == 0) { const long long now_ = clock64(); v.dbg[(size_t)gcount * 32 + (k)] += now_ - hbg_tl; hbg_tl = now_; } } while (0)
@@ -41,9 +41,9 @@
 // Template shape: HBG_DM = panels per group the register arrays are sized for (>= D), HBG_FW = panels ahead a move is folded into
 // (>= Lv * D), HBG_CH = moves whose rows are requested together — HBG_CH * (HBG_DM + HBG_FW) loads per lane and trip, ~60: a narrow
 // geometry (few rows per move) takes many moves per trip, the wide one of the stationary point-mass sweep three.
-// G16 (round 5): the rows of a move come from the compact band (hb_ctx.gram16: int16 residuals of G - ga (x) gB, half the bytes) and the rank-one
-// part is added once per marker and fold, from the sum of ga[k] * delta_k over the moves the marker takes: sum_k G[k][j] d_k = sum_k g16[k][j] d_k
-// + gB[j] * sum_k ga[k] d_k. Same products in another grouping: effects agree with the int32 fold to the last bits' rounding.
+// G16 (round 5): the rows of a move come from the compact band (hb_ctx.gram16: int16 residuals of G - ga (x) gB, half the bytes), whole rows
+// by LDS-DMA, and every entry is rebuilt exactly, G[k][j] = g16[k][j] + ga[k] * gB[j] (one integer multiply-add), before it is used: the fold's
+// arithmetic is the int32 band's bit for bit.
 template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
                                                                                                  persist_view pv)
@@ -62,16 +62,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     double *res_g = cs_d + (2 + 3 * K1) * 64;                   // ... their new effects
     double *ev_del = res_g + 64;                                // the round's moves: change of effect
     double *red = ev_del + 64;                                  // [16]
-    double *spre = red + 16;                                    // [65] drift pre-check: spre[k] = sum of (column sum x change) over the round's candidates before candidate k
-    double *cs_s1 = spre + 66;                                  // [64] the candidates' column sums
-    double *cs_a = cs_s1 + 64;                                  // [64] G16: the candidates' ga[]
-    double *ev_ak = cs_a + 64;                                  // [64] G16: the round's moves: ga[mover] * change
-    int *cs_pos = reinterpret_cast<int *>(ev_ak + 64);          // candidate -> position in the group (panel * P + marker)
+    int *cs_pos = reinterpret_cast<int *>(red + 16);            // candidate -> position in the group (panel * P + marker)
     int *res_c = cs_pos + 64;                                   // ... new classes
     int *ev_pos = res_c + 64;                                   // the round's moves: position
     int *cg = ev_pos + 64;                                      // [64][64] Gram entries among the round's candidates (k < c)
-    int *wcnt = cg + 64 * 64;                                   // [HBG_DM][8] candidates per (panel of the group, wave)
-    int *misc = wcnt + 64;                                      // [0] moves of the round, [1] position the round ends at, [2] abort, [8..15] violations per wave, [16..23] moves published per panel, [24..31] predicted crossings per wave
+    int *cs_ga = cg + 64 * 64;                                  // [64] G16: the candidates' ga[]
+    int *ev_ga = cs_ga + 64;                                    // [64] G16: ga[] of the round's movers
+    int *wcnt = ev_ga + 64;                                     // [HBG_DM][8] candidates per (panel of the group, wave)
+    int *misc = wcnt + 64;                                      // [0] moves of the round, [1] position the round ends at, [2] abort, [8..15] violations per wave, [16..23] moves published per panel
+    // G16: the rows of a fold trip, staged through LDS — HBG_CH moves x (HBG_DM + HBG_FW) rows of P int16, brought in by LDS-DMA (one 1-KiB piece per row)
+    int16_t *rows16 = reinterpret_cast<int16_t *>((reinterpret_cast<uintptr_t>(misc + 32) + 15) & ~(uintptr_t)15);
+    (void)rows16;
     for (int l = 0; l < R; l++) corr[(size_t)l * P + t] = 0.0;
     if (t < 64) { wcnt[t] = 0; if (t < 32) misc[t] = 0; }
 
@@ -101,7 +102,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- (1) the group's dots, filter words and owed corrections ----
         double r0[HBG_DM];
         float fl[HBG_DM];
-        float muj[HBG_DM]; // mean genotype of marker (i, t) (drift pre-check; 0 without it)
         int gBi[G16 ? HBG_DM : 1], gBf[G16 ? HBG_FW : 1]; // G16: gB of this thread's markers in the group and in the panels ahead
         (void)gBi; (void)gBf;
         if constexpr (G16) {
@@ -119,14 +119,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // trip per look. Re-reading only what is missing puts each load behind a branch — a dozen dependent trips per look,
             // most of them after the values have arrived)
             const double *fcp = far_in ? pv.fcorr : v.dsum; // (without k_fwd's share: any readable words, not looked at)
-            const double *s1p = v.s1 ? v.s1 : v.xpx;        // (without the drift pre-check: inv_n is 0)
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) {
                 const size_t j = (size_t)(gp0 + min(i, Dg - 1)) * P + t;
                 dj[i] = ld_sc1(&v.dsum[j]);
                 fl[i] = pv.thr0f[j];
                 fc[i] = ld_sc1(&fcp[j]);
-                muj[i] = (float)(s1p[j] * v.inv_n); // (unconditional: a load behind a uniform branch is waited for on the spot)
             }
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) fl[i] = i < Dg ? fl[i] : __int_as_float(0x7fc00000);
@@ -252,8 +250,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         cs_d[(2 + 2 * K1 + c) * 64 + rank] = v.sdz[(size_t)c * v.m_pad + j];
                     }
                     cs_pos[rank] = i * P + t;
-                    cs_s1[rank] = (v.s1 ? v.s1 : v.xpx)[j]; // (unconditional load; unused without the pre-check)
-                    if constexpr (G16) cs_a[rank] = (double)v.ga[j];
+                    if constexpr (G16) cs_ga[rank] = v.ga[j];
                     rk |= (unsigned long long)rank << (8 * i);
                     inrm |= 1u << i;
                 }
@@ -319,80 +316,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int pos = __popcll(moved & lt);
                     ev_pos[pos] = cp;
                     ev_del[pos] = dmine;
-                    if constexpr (G16) ev_ak[pos] = cs_a[lane] * dmine;
+                    if constexpr (G16) ev_ga[pos] = cs_ga[lane];
                 }
                 res_c[lane] = cls;
                 res_g[lane] = gn;
                 if (lane == 0) misc[0] = __popcll(moved);
-                if (v.s1) { // drift pre-check: inclusive scan of (column sum x change) over the candidates, in marker order
-                    double w = lv ? cs_s1[lane] * dmine : 0.0;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const double up = __shfl_up(w, o, 64);
-                        if (lane >= o) w += up;
-                    }
-                    spre[lane + 1] = w;
-                    if (lane == 0) spre[0] = 0.0;
-                }
             }
             __syncthreads(); // B4
             HBG_ACC(4);
             const int nmoves = misc[0];
-            // ---- (4b) drift pre-check (round 5). A move changes every later marker's right-hand side by G[k][j] d_k, and G[k][j] is n mean_k mean_j
-            // up to the (centred) covariance: the round's moves shift the right-hand sides of ALL later markers by mean_j * sum_k s1_k d_k — with
-            // a handful of moves by a third of the distance between a typical right-hand side and its threshold, so that more than half of the
-            // groups with moves had a marker pushed over its threshold and the whole round — exact data, gather, serial pass and the FOLD, the
-            // expensive part — rolled back and repeated (69 times a sweep at n = 50k, m = 500k: a third of the chain's time). The shift is known the
-            // moment the serial pass ends: a marker whose right-hand side, moved by it, comes within 3 % of its threshold joins the candidates
-            // NOW, before the rows of the moves are fetched. A prediction only ever adds candidates (decided exactly by the next serial pass), and
-            // the exact check after the fold stays: the chain is the same exact sequential chain.
-            if (v.s1 && nmoves > 0) {
-                unsigned pvm = 0;
-                // (two steps: which of this thread's markers are near enough to their thresholds to be reachable at all — eight compares on
-                // registers, true for a fraction of a percent of the markers — and only for those the look-up of the shift; a wave runs the
-                // second step as often as its busiest lane has near markers, mostly once or not at all)
-                unsigned near = 0;
-#pragma unroll
-                for (int i = 0; i < HBG_DM; i++) {
-                    if (i < Dg) {
-                        const int pos = i * P + t;
-                        const bool nr = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && r0[i] * r0[i] >= 0.3 * (double)fl[i]; // (NaN filter: false)
-                        near |= nr ? 1u << i : 0u;
-                    }
-                }
-                for (unsigned left = near; __any(left != 0u); left &= left - 1u) {
-                    const bool mine = left != 0u;
-                    const int i = mine ? __ffs((int)left) - 1 : 0;
-                    double r0i = r0[0];
-                    float fli = fl[0], mui = muj[0];
-#pragma unroll
-                    for (int x = 1; x < HBG_DM; x++) {
-                        r0i = (i == x) ? r0[x] : r0i;
-                        fli = (i == x) ? fl[x] : fli;
-                        mui = (i == x) ? muj[x] : mui;
-                    }
-                    const int before = min(64, __shfl(myscan, i * 8 + wave, 64) + (int)((rkp >> (8 * i)) & 0xffull)); // the round's candidates before this marker
-                    const double rp = fma(-(double)mui, spre[before], r0i);
-                    if (mine && rp * rp >= 0.94 * (double)fli) pvm |= 1u << i;
-                }
-                const unsigned long long pb = __ballot(pvm != 0u);
-                if (lane == 0) misc[24 + wave] = pb != 0ull;
-                __syncthreads(); // B4b
-                bool anyp = false;
-                {
-                    int w8[8];
-                    hb_read8(misc + 24, w8);
-#pragma unroll
-                    for (int w = 0; w < 8; w++) anyp |= w8[w] != 0;
-                }
-                if (anyp) { // (not counted as a rolled-back round: nothing but the serial pass is repeated)
-                    forced |= pvm;
-                    HBG_ACC(9);
-                    HBG_CNT(15, 1);
-                    continue;
-                }
-                HBG_ACC(9);
-            }
             // ---- (5) the round's moves onto the later markers of the group AND forward, all rows of up to HBG_CH moves in one
             // trip (a lone compute unit's loads take microseconds beside the streaming mat-vec: the number of dependent trips is
             // what a group costs). The forward contributions are summed in registers and reach the correction ring only when the
@@ -402,20 +334,61 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < HBG_DM; i++) rnew[i] = r0[i];
 #pragma unroll
             for (int x = 0; x < HBG_FW; x++) fw[x] = 0.0;
-            double ra[G16 ? HBG_DM : 1], rA = 0.0; // G16: sum of ga[k] * delta_k over the moves marker (i, t) takes / over all moves of the round
-            (void)ra; (void)rA;
-            if constexpr (G16) {
-#pragma unroll
-                for (int i = 0; i < HBG_DM; i++) ra[i] = 0.0;
-            }
             // (row addresses are "wave-uniform pointer"[t]: scalar base + one vector offset, no 64-bit vector arithmetic)
             using gram_t = typename std::conditional<G16, int16_t, int32_t>::type;
             const gram_t *gbase = G16 ? reinterpret_cast<const gram_t *>(v.gram16) + (size_t)gp0 * (pv.Lg + 1) * PP : reinterpret_cast<const gram_t *>(gblk0);
+            if constexpr (G16) {
+                // The rows travel as WHOLE rows by LDS-DMA — one global_load_lds_dwordx4 per row of 512 int16, 64 lanes x 16 bytes — instead of one
+                // 2-byte (4-byte in the int32 band) load per lane and row: what a fold trip costs is ~15 cycles per wave-load INSTRUCTION that
+                // misses (round 5: halving the bytes alone, int16 rows fetched lane by lane, changed nothing — profiles/r05_group_phases_g16_*.txt),
+                // and a trip is 60 instructions here against 480. The 60 load registers per lane go too (the kernel sat at 253 VGPRs).
+                constexpr int NR = HBG_DM + HBG_FW, NROW = HBG_CH * NR;
+                const unsigned rows_lds = (unsigned)(uintptr_t)rows16;
+#pragma unroll 1
+                for (int e0 = 0; e0 < nmoves; e0 += HBG_CH) {
+                    if (e0 > 0) __syncthreads(); // (the previous trip's rows have been read by everybody)
+                    for (int sl = wave; sl < NROW; sl += 8) { // (uniform per wave)
+                        const int f = sl / NR, r = sl - f * NR;
+                        const int e = min(e0 + f, nmoves - 1);
+                        const int a = __builtin_amdgcn_readfirstlane(ev_pos[e]);
+                        const int pa = a >> lgP, ia = a & (P - 1);
+                        // panel i of the group meets the mover in block l = i - pa: gbase + ia P - pa PP + i pstep (i >= pa; a panel before the
+                        // mover's fetches the mover's own row again: not used); the panels ahead continue the walk at i = D + x
+                        const int step = r < HBG_DM ? min(max(r, pa), Dg - 1) : D + min(r - HBG_DM, max(nfw - 1, 0));
+                        const int16_t *row = (r < HBG_DM || have_fw) ? gbase + (size_t)ia * P + (size_t)step * pstep - (size_t)pa * PP : gbase;
+                        const unsigned long long u = (unsigned long long)(uintptr_t)row;
+                        const int8_t *rp = reinterpret_cast<const int8_t *>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                                                                        (unsigned)__builtin_amdgcn_readfirstlane((int)u)));
+                        hbq_dma16<false>((unsigned)lane * 16u, rp, (unsigned)__builtin_amdgcn_readfirstlane((int)(rows_lds + (unsigned)sl * 1024u)));
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+#pragma unroll 1
+                    for (int f = 0; f < HBG_CH; f++) { // (one move at a time: unrolled, the 60 LDS reads of a trip would all be hoisted into registers)
+                        if (e0 + f >= nmoves) break;
+                        const int e = min(e0 + f, nmoves - 1);
+                        const int a = __builtin_amdgcn_readfirstlane(ev_pos[e]);
+                        const int paf = a >> lgP, iaf = a & (P - 1);
+                        const double dlf = (e0 + f < nmoves) ? ev_del[e] : 0.0;
+                        const int gaf = __builtin_amdgcn_readfirstlane(ev_ga[e]);
+                        const int16_t *rf = rows16 + (size_t)f * NR * P + t;
+                        // G[k][j] = g16[k][j] + ga[k] gB[j], an exact integer: the fold's arithmetic is the int32 band's, bit for bit
+#pragma unroll
+                        for (int i = 0; i < HBG_DM; i++) {
+                            const bool later = i > paf || (i == paf && t > iaf);
+                            if (i < Dg && later) rnew[i] = fma(-(double)((int)rf[(size_t)i * P] + gaf * gBi[i]), dlf, rnew[i]);
+                        }
+#pragma unroll
+                        for (int x = 0; x < HBG_FW; x++)
+                            fw[x] = (x < nfw) ? fma((double)((int)rf[(size_t)(HBG_DM + x) * P] + gaf * gBf[x]), dlf, fw[x]) : fw[x];
+                    }
+                }
+            } else {
 #pragma unroll 1
             for (int e0 = 0; e0 < nmoves; e0 += HBG_CH) {
                 int gv[HBG_CH][HBG_DM], gf[HBG_CH][HBG_FW];
                 int pae[HBG_CH], iae[HBG_CH];
-                double dl[HBG_CH], akd[HBG_CH];
+                double dl[HBG_CH];
 #pragma unroll
                 for (int f = 0; f < HBG_CH; f++) {
                     const int e = min(e0 + f, nmoves - 1);
@@ -423,7 +396,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     pae[f] = a >> lgP;
                     iae[f] = a & (P - 1);
                     dl[f] = (e0 + f < nmoves) ? ev_del[e] : 0.0;
-                    akd[f] = (G16 && e0 + f < nmoves) ? ev_ak[e] : 0.0;
                 }
 #pragma unroll
                 for (int f = 0; f < HBG_CH; f++) {
@@ -451,21 +423,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int i = 0; i < HBG_DM; i++) {
                         // marker (i, t) takes the move of (pae, iae) if it comes later in the order
                         const bool later = i > pae[f] || (i == pae[f] && t > iae[f]);
-                        if (i < Dg && later) {
-                            rnew[i] = fma(-(double)gv[f][i], dl[f], rnew[i]);
-                            if constexpr (G16) ra[i] += akd[f];
-                        }
+                        if (i < Dg && later) rnew[i] = fma(-(double)gv[f][i], dl[f], rnew[i]);
                     }
 #pragma unroll
                     for (int x = 0; x < HBG_FW; x++) fw[x] = (x < nfw) ? fma((double)gf[f][x], dl[f], fw[x]) : fw[x];
-                    if constexpr (G16) rA += akd[f];
                 }
             }
-            if constexpr (G16) { // the rank-one part: gB[j] * (sum of ga[k] d_k over the moves j takes)
-#pragma unroll
-                for (int i = 0; i < HBG_DM; i++) rnew[i] = fma(-(double)gBi[i], ra[i], rnew[i]);
-#pragma unroll
-                for (int x = 0; x < HBG_FW; x++) fw[x] = (x < nfw) ? fma((double)gBf[x], rA, fw[x]) : fw[x];
             }
             // ---- (6) did every marker the round passed over really stay below its threshold? ----
             unsigned violm = 0;
@@ -628,7 +591,7 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
     constexpr int NF = HBF_D * HBF_G;
     __shared__ int s_pos[HBF_D * 512];    // the group's moves: panel * P + marker
     __shared__ double s_del[HBF_D * 512]; // ... and changes of effect
-    __shared__ double s_ak[G16 ? HBF_D * 512 : 1]; // G16: ga[mover] * change
+    __shared__ int s_ga[G16 ? HBF_D * 512 : 1]; // G16: ga[] of the movers
     __shared__ int s_cnt[HBF_D + 1], s_ok;
     const int P = v.P, t = threadIdx.x, lgP = 31 - __clz(P);
     const int D = pv.D, np = pv.npanels, G = pv.Lv - 1;
@@ -678,7 +641,7 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
                 if (ix < 0 || __double_as_longlong(dl) == -1ll) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); ix = 0; dl = 0.0; }
                 s_pos[b + k] = i * P + ix;
                 s_del[b + k] = dl;
-                if constexpr (G16) s_ak[b + k] = (double)v.ga[(size_t)(gp0 + i) * P + ix] * dl;
+                if constexpr (G16) s_ga[b + k] = v.ga[(size_t)(gp0 + i) * P + ix];
             }
         }
         __syncthreads();
@@ -690,11 +653,9 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
 #pragma unroll
             for (int y = 0; y < NF; y++) gBy[y] = v.gB[(size_t)min(gp0 + 2 * D + y, np - 1) * P + t];
         }
-        double rA = 0.0;
-        (void)rA;
 #pragma unroll 1
         for (int e0 = 0; e0 < nev; e0 += HBF_CH) {
-            int gf[HBF_CH][NF];
+            int gf[HBF_CH][NF], gaf[HBF_CH];
             double dl[HBF_CH];
 #pragma unroll
             for (int f = 0; f < HBF_CH; f++) {
@@ -702,7 +663,7 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
                 const int a = __builtin_amdgcn_readfirstlane(s_pos[e]);
                 const int pa = a >> lgP, ia = a & (P - 1);
                 dl[f] = (e0 + f < nev) ? s_del[e] : 0.0;
-                if constexpr (G16) rA += (e0 + f < nev) ? s_ak[e] : 0.0;
+                gaf[f] = G16 ? __builtin_amdgcn_readfirstlane(s_ga[G16 ? e : 0]) : 0;
                 // panel y (counted from the first panel of group g + 2) meets the mover in block l = 2 D + y - pa: the chain's walk, 2 D panels on
                 const gram_t *row = gblk0 + (size_t)ia * P + (size_t)(2 * D) * pstep - (size_t)pa * PP;
 #pragma unroll
@@ -714,11 +675,7 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
 #pragma unroll
             for (int f = 0; f < HBF_CH; f++)
 #pragma unroll
-                for (int y = 0; y < NF; y++) fs[y] = (y < nfar) ? fma((double)gf[f][y], dl[f], fs[y]) : fs[y];
-        }
-        if constexpr (G16) { // the rank-one part of this group's moves, once per far marker
-#pragma unroll
-            for (int y = 0; y < NF; y++) fs[y] = (y < nfar) ? fma((double)gBy[y], rA, fs[y]) : fs[y];
+                for (int y = 0; y < NF; y++) fs[y] = (y < nfar) ? fma((double)(G16 ? gf[f][y] + gaf[f] * gBy[G16 ? y : 0] : gf[f][y]), dl[f], fs[y]) : fs[y];
         }
         // group g + 2 has now heard from every group that owes it: publish, and shift what the later ones have so far
 #pragma unroll

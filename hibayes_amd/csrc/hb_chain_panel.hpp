@@ -27,10 +27,6 @@ struct chain_view {
     // marker raises it by at most xabs * |D|; the update derives the digits' exponent from it (null: other paths)
     double *mb;
     double xabs;
-    // round 5, k_chain_group's drift pre-check: column sums (k_stats) and 1 / n — the mean genotype of a marker is s1 * inv_n. Null /
-    // zero: no pre-check (the exact violation check after the fold still catches everything).
-    const double *s1;
-    double inv_n;
     // round 5: the band as rank one + int16 residual (hb_ctx.gram16): G[k][j] = ga[k] * gB[j] + gram16[k][j]; null: not built
     const int16_t *gram16;
     const int32_t *ga, *gB;

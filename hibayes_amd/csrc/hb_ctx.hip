@@ -151,7 +151,6 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_DOTQ2_TILES")) c->dotq2_tiles = std::max(1, atoi(e));
     if (const char *e = getenv("HB_DOTQ2_KIND")) c->dotq2_kind = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("HB_GRAM16")) c->gram16_on = atoi(e) != 0;
-    if (const char *e = getenv("HB_DRIFT")) c->drift_check = atoi(e) != 0;
     if (const char *e = getenv("HB_Q2M_CT")) c->q2m_ct = atoi(e) >= 16 ? 16 : atoi(e) >= 8 ? 8 : 4;
     if (const char *e = getenv("HB_Q2M_G")) c->q2m_g = atoi(e) == 3 ? 3 : atoi(e) >= 2 ? 2 : atoi(e) == 0 ? 0 : 1;
     if (const char *e = getenv("HB_Q2M_SC")) c->q2m_sc = atoi(e) != 0;

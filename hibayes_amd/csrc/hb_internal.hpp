@@ -108,7 +108,6 @@ struct hb_ctx {
     int dot_lds = 0;     // dynamic LDS bytes requested by each mat-vec workgroup: caps the workgroups resident per CU
     int q2m_ct = 4, q2m_g = 0, q2m_sc = 1; // k_dotq2m's shape (HB_Q2M_CT / _G / _SC): column tiles of 16 per wave; stages requested together (1, 2) or 512-individual stages of whole-line
                                            // DMA pieces (0, the default since round 5: 12.3 against 15.3 us per launch; 3: the same with conflict-free lane order); per-scale accumulators
-    bool drift_check = false; // k_chain_group: predicted threshold crossings from the round's mean drift join the candidates before the fold (HB_DRIFT=1; measured: no rolled-back rounds left, 3-5 % slower — the repeats of the serial pass cost what the roll-backs did)
     double candf = 1.0;  // chain candidates: markers at zero with q >= candf * thr0 (tuning knob; <= 1)
     double kappa = 3.0; // row-cache prediction: markers with thr0 <= kappa * xx * vare get their Gram row prefetched
     bool gram_ready = false, stats_ready = false;

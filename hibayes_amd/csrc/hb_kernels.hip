@@ -663,7 +663,6 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->Lg, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
-    if (c->drift_check) { cv.s1 = c->s1; cv.inv_n = 1.0 / (double)c->n; }
     const bool g16 = c->gram16_ok && c->gram16 != nullptr; // (the compact band: only the wide group chain and its k_fwd read it)
     if (g16) { cv.gram16 = c->gram16; cv.ga = c->ga; cv.gB = c->gB; }
     const int last_panels = np - (g0 + ngroups - 1) * D;
