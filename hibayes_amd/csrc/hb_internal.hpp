@@ -103,7 +103,7 @@ struct hb_ctx {
     size_t gram16_cap = 0;
     int32_t *ga = nullptr, *gB = nullptr;
     int *g16_flag = nullptr;
-    bool gram16_ok = false, gram16_on = true; // (HB_GRAM16=0: off)
+    bool gram16_ok = false, gram16_on = false; // (HB_GRAM16=1: on. OFF by default: measured slower than the int32 band both ways it was read)
     bool env_pinned = false;
     int dot_lds = 0;     // dynamic LDS bytes requested by each mat-vec workgroup: caps the workgroups resident per CU
     int q2m_ct = 4, q2m_g = 0, q2m_sc = 1; // k_dotq2m's shape (HB_Q2M_CT / _G / _SC): column tiles of 16 per wave; stages requested together (1, 2) or 512-individual stages of whole-line
