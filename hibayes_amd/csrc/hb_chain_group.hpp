@@ -41,9 +41,10 @@
 // Template shape: HBG_DM = panels per group the register arrays are sized for (>= D), HBG_FW = panels ahead a move is folded into
 // (>= Lv * D), HBG_CH = moves whose rows are requested together — HBG_CH * (HBG_DM + HBG_FW) loads per lane and trip, ~60: a narrow
 // geometry (few rows per move) takes many moves per trip, the wide one of the stationary point-mass sweep three.
-// G16 (round 5): the rows of a move come from the compact band (hb_ctx.gram16: int16 residuals of G - ga (x) gB, half the bytes), whole rows
-// by LDS-DMA, and every entry is rebuilt exactly, G[k][j] = g16[k][j] + ga[k] * gB[j] (one integer multiply-add), before it is used: the fold's
-// arithmetic is the int32 band's bit for bit.
+// G16 (round 5): the rows of a move come from the compact band (hb_ctx.gram16: int16 residuals of G - ga (x) gB, half the bytes), one short per
+// lane and row, and every entry is rebuilt exactly, G[k][j] = g16[k][j] + ga[k] * gB[j] (one integer multiply-add), before it is used: the fold's
+// arithmetic is the int32 band's bit for bit. (tools/rowfetch2_bench.hip: 80 cycles per row this way against 111 for int32 rows; whole rows per
+// wave-load staged through LDS, by dwordx4 loads or by LDS-DMA: 127-131 — tried in the kernel too, profiles/r05_group_phases_g16b_*.txt.)
 template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
                                                                                                  persist_view pv)
@@ -70,9 +71,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int *ev_ga = cs_ga + 64;                                    // [64] G16: ga[] of the round's movers
     int *wcnt = ev_ga + 64;                                     // [HBG_DM][8] candidates per (panel of the group, wave)
     int *misc = wcnt + 64;                                      // [0] moves of the round, [1] position the round ends at, [2] abort, [8..15] violations per wave, [16..23] moves published per panel
-    // G16: the rows of a fold trip, staged through LDS — HBG_CH moves x (HBG_DM + HBG_FW) rows of P int16, brought in by LDS-DMA (one 1-KiB piece per row)
-    int16_t *rows16 = reinterpret_cast<int16_t *>((reinterpret_cast<uintptr_t>(misc + 32) + 15) & ~(uintptr_t)15);
-    (void)rows16;
     for (int l = 0; l < R; l++) corr[(size_t)l * P + t] = 0.0;
     if (t < 64) { wcnt[t] = 0; if (t < 32) misc[t] = 0; }
 
@@ -337,57 +335,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // (row addresses are "wave-uniform pointer"[t]: scalar base + one vector offset, no 64-bit vector arithmetic)
             using gram_t = typename std::conditional<G16, int16_t, int32_t>::type;
             const gram_t *gbase = G16 ? reinterpret_cast<const gram_t *>(v.gram16) + (size_t)gp0 * (pv.Lg + 1) * PP : reinterpret_cast<const gram_t *>(gblk0);
-            if constexpr (G16) {
-                // The rows travel as WHOLE rows by LDS-DMA — one global_load_lds_dwordx4 per row of 512 int16, 64 lanes x 16 bytes — instead of one
-                // 2-byte (4-byte in the int32 band) load per lane and row: what a fold trip costs is ~15 cycles per wave-load INSTRUCTION that
-                // misses (round 5: halving the bytes alone, int16 rows fetched lane by lane, changed nothing — profiles/r05_group_phases_g16_*.txt),
-                // and a trip is 60 instructions here against 480. The 60 load registers per lane go too (the kernel sat at 253 VGPRs).
-                constexpr int NR = HBG_DM + HBG_FW, NROW = HBG_CH * NR;
-                const unsigned rows_lds = (unsigned)(uintptr_t)rows16;
-#pragma unroll 1
-                for (int e0 = 0; e0 < nmoves; e0 += HBG_CH) {
-                    if (e0 > 0) __syncthreads(); // (the previous trip's rows have been read by everybody)
-                    for (int sl = wave; sl < NROW; sl += 8) { // (uniform per wave)
-                        const int f = sl / NR, r = sl - f * NR;
-                        const int e = min(e0 + f, nmoves - 1);
-                        const int a = __builtin_amdgcn_readfirstlane(ev_pos[e]);
-                        const int pa = a >> lgP, ia = a & (P - 1);
-                        // panel i of the group meets the mover in block l = i - pa: gbase + ia P - pa PP + i pstep (i >= pa; a panel before the
-                        // mover's fetches the mover's own row again: not used); the panels ahead continue the walk at i = D + x
-                        const int step = r < HBG_DM ? min(max(r, pa), Dg - 1) : D + min(r - HBG_DM, max(nfw - 1, 0));
-                        const int16_t *row = (r < HBG_DM || have_fw) ? gbase + (size_t)ia * P + (size_t)step * pstep - (size_t)pa * PP : gbase;
-                        const unsigned long long u = (unsigned long long)(uintptr_t)row;
-                        const int8_t *rp = reinterpret_cast<const int8_t *>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
-                                                                                        (unsigned)__builtin_amdgcn_readfirstlane((int)u)));
-                        hbq_dma16<false>((unsigned)lane * 16u, rp, (unsigned)__builtin_amdgcn_readfirstlane((int)(rows_lds + (unsigned)sl * 1024u)));
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-#pragma unroll 1
-                    for (int f = 0; f < HBG_CH; f++) { // (one move at a time: unrolled, the 60 LDS reads of a trip would all be hoisted into registers)
-                        if (e0 + f >= nmoves) break;
-                        const int e = min(e0 + f, nmoves - 1);
-                        const int a = __builtin_amdgcn_readfirstlane(ev_pos[e]);
-                        const int paf = a >> lgP, iaf = a & (P - 1);
-                        const double dlf = (e0 + f < nmoves) ? ev_del[e] : 0.0;
-                        const int gaf = __builtin_amdgcn_readfirstlane(ev_ga[e]);
-                        const int16_t *rf = rows16 + (size_t)f * NR * P + t;
-                        // G[k][j] = g16[k][j] + ga[k] gB[j], an exact integer: the fold's arithmetic is the int32 band's, bit for bit
-#pragma unroll
-                        for (int i = 0; i < HBG_DM; i++) {
-                            const bool later = i > paf || (i == paf && t > iaf);
-                            if (i < Dg && later) rnew[i] = fma(-(double)((int)rf[(size_t)i * P] + gaf * gBi[i]), dlf, rnew[i]);
-                        }
-#pragma unroll
-                        for (int x = 0; x < HBG_FW; x++)
-                            fw[x] = (x < nfw) ? fma((double)((int)rf[(size_t)(HBG_DM + x) * P] + gaf * gBf[x]), dlf, fw[x]) : fw[x];
-                    }
-                }
-            } else {
+            {
 #pragma unroll 1
             for (int e0 = 0; e0 < nmoves; e0 += HBG_CH) {
                 int gv[HBG_CH][HBG_DM], gf[HBG_CH][HBG_FW];
-                int pae[HBG_CH], iae[HBG_CH];
+                int pae[HBG_CH], iae[HBG_CH], gaf[HBG_CH];
                 double dl[HBG_CH];
 #pragma unroll
                 for (int f = 0; f < HBG_CH; f++) {
@@ -396,6 +348,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     pae[f] = a >> lgP;
                     iae[f] = a & (P - 1);
                     dl[f] = (e0 + f < nmoves) ? ev_del[e] : 0.0;
+                    gaf[f] = G16 ? __builtin_amdgcn_readfirstlane(ev_ga[e]) : 0;
                 }
 #pragma unroll
                 for (int f = 0; f < HBG_CH; f++) {
@@ -423,10 +376,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int i = 0; i < HBG_DM; i++) {
                         // marker (i, t) takes the move of (pae, iae) if it comes later in the order
                         const bool later = i > pae[f] || (i == pae[f] && t > iae[f]);
-                        if (i < Dg && later) rnew[i] = fma(-(double)gv[f][i], dl[f], rnew[i]);
+                        // (G16: G[k][j] = g16[k][j] + ga[k] gB[j], an exact integer — the fold's arithmetic is the int32 band's, bit for bit)
+                        if (i < Dg && later) rnew[i] = fma(-(double)(G16 ? gv[f][i] + gaf[f] * gBi[G16 ? i : 0] : gv[f][i]), dl[f], rnew[i]);
                     }
 #pragma unroll
-                    for (int x = 0; x < HBG_FW; x++) fw[x] = (x < nfw) ? fma((double)gf[f][x], dl[f], fw[x]) : fw[x];
+                    for (int x = 0; x < HBG_FW; x++) fw[x] = (x < nfw) ? fma((double)(G16 ? gf[f][x] + gaf[f] * gBf[G16 ? x : 0] : gf[f][x]), dl[f], fw[x]) : fw[x];
                 }
             }
             }
