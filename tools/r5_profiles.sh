@@ -31,3 +31,5 @@ run_pmc fetch_2bit_mfma_d7 FETCH_SIZE HB_MV_BITS=2 HB_TIME_MATVEC_D=7
 run_pmc fetch_2bit_vdot4_d7 FETCH_SIZE HB_MV_BITS=2 HB_TIME_MATVEC_D=7 HB_DOTQ2_KIND=0
 run_pmc fetch_int8_d7 FETCH_SIZE HB_MV_BITS=8 HB_TIME_MATVEC_D=7
 run_pmc sq_k_dotq2m "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" HB_MV_BITS=2 HB_TIME_MATVEC_D=7
+# two ranks sharing the one GPU of this box over gloo (what can be checked of `bench.py --gpus N` without a node): the line's per-rank and all-reduce fields
+cd $R && HB_BENCH_M=100000 timeout 600 python bench.py --gpus 2 --backend gloo --collective torch --steps 10 --warmup 5 --burnin 30 --no-cpu > $O/r05_bench_gpus2_gloo_one_gpu_box.json 2> $O/r05_bench_gpus2_gloo_one_gpu_box.err; tail -c 1500 $O/r05_bench_gpus2_gloo_one_gpu_box.json | head -c 1500; tail -3 $O/r05_bench_gpus2_gloo_one_gpu_box.err
