@@ -275,7 +275,7 @@ def pmc_traffic(n, cols, kernel):
     """HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE passes kept under profiles/ (counters cannot be read from
     inside this process): reported only when a pass with the same kernel, n and launch width exists."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+        table = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
         for e in table["passes"]:
             if e["kernel"] == kernel and e["n"] == n and e["columns_per_launch"] == cols:
                 return e["traffic_bytes_per_launch"]
@@ -620,7 +620,7 @@ def main():
     }
     res.update(regime_tag(elapsed / K * 1e3, insitu_main))
     roof["regime"] = res["regime"]
-    roof["traffic_source"] = ("separate rocprofv3 --pmc FETCH_SIZE pass of the same launch shape, read from the tracked profiles/r04_pmc_traffic.json "
+    roof["traffic_source"] = ("separate rocprofv3 --pmc FETCH_SIZE pass of the same launch shape, read from the tracked profiles/r05_pmc_traffic.json "
                               "(counters cannot be collected inside this process)") if roof.get("traffic") is not None else "none (no counter pass on file for this launch shape)"
 
     def leg_block(model, el, Kx, Wx, ev, nnzx, missx, ins, iso, launches_x, cols_x, bits_x, kind, geo_x, burn_x, curve=None):

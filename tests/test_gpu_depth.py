@@ -372,3 +372,34 @@ def test_continued_chain_is_the_oracles_continued_chain(big, model, Pi, fold):
     if model == "BayesCpi":
         nnz1 = int((r1["last"]["g"] != 0).sum())
         assert abs(int((r2["MCMCsamples"]["alpha"][:, 0] != 0).sum()) - nnz1) < max(20, nnz1)
+
+
+def test_compact_band_is_the_int32_band_bit_for_bit(big, monkeypatch):
+    """HB_GRAM16=1 (round 5; off by default): the wide group chain and k_fwd fold a move's rows from the band stored as rank one + int16
+    residual, G[k][j] = ga[k] gB[j] + g16[k][j], every entry rebuilt exactly before it is used — the same integers, so the run must equal
+    the int32 band's BIT FOR BIT (and therefore the oracle's draw for draw), cold start with the geometry switch and a dense start."""
+    X, y = big["X"], big["y"]
+    m = X.shape[1]
+    rng = np.random.default_rng(12)
+    g0 = np.where(rng.random(m) < 0.05, rng.normal(0, 0.03, m), 0.0)
+    out = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("HB_GRAM16", on)
+        res = []
+        with H.Context(X.shape[0], m, panel=512, seed=99) as c:
+            c.upload(X)
+            c.set_pipeline(1, 3, 7)
+            c.build_gram()
+            c.set_adaptive(True)
+            c.set_layout(2, keep_int8=False)
+            res.append(H.Bayes(y, None, "BayesCpi", [0.95, 0.05], verbose=False, ctx=c, niter=30, nburn=10, thin=2, seed=99))
+            c.set_adaptive(False)
+            c.set_pipeline(1, 3, 7)
+            res.append(H.Bayes(y, None, "BayesCpi", [0.95, 0.05], verbose=False, ctx=c, niter=6, nburn=0, thin=1, seed=98, g_init=g0))
+        out.append(res)
+    for a, b in zip(out[0], out[1]):
+        for k in ("alpha", "pip", "g", "pi", "Vg", "Ve"):
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+        assert np.array_equal(a["MCMCsamples"]["alpha"], b["MCMCsamples"]["alpha"])
+    ref = O.bayes(y, X, "BayesCpi", [0.95, 0.05], rng=O.RNG_PHILOX, store_alpha=True, niter=6, nburn=0, thin=1, seed=98, g_init=g0)
+    _compare(out[1][1], ref)

@@ -266,6 +266,29 @@ def test_bigmemory_file_to_device_without_a_host_copy(tmp_path, demo):
     assert np.array_equal(r["alpha"], r2["alpha"])
 
 
+@pytest.mark.parametrize("shape", [{"HB_Q2M_G": "1"}, {"HB_Q2M_G": "2"}, {"HB_Q2M_G": "3"}, {"HB_Q2M_G": "1", "HB_Q2M_CT": "8"},
+                                   {"HB_Q2M_G": "1", "HB_Q2M_CT": "16", "HB_Q2M_SC": "0"}, {"HB_Q2M_G": "0", "HB_Q2M_SC": "0"}])
+def test_every_shape_of_the_matrix_core_matvec_gives_the_same_integers(shape, monkeypatch):
+    """k_dotq2m's template shapes (hb_dotq2.hpp; round 5): 256-individual stages singly or in pairs, 512-individual stages of whole-line DMA
+    pieces in plain and in bank-conflict-free lane order (the default is G = 0), 64 / 128 / 256 columns per wave, one accumulator set per
+    genotype scale or one in all. Integer sums in another order: every shape must give the int8 layout's dot products bit for bit, on
+    a padded length that is a multiple of 512 and on one that is not (the 512-individual shapes then fall back to 256)."""
+    for k, v in shape.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(31)
+    for n, m, panel in ((2000, 1024, 512), (1300, 640, 128), (5100, 2048, 512)):    # ld = 2048, 1536 (odd multiple of 256), 5120
+        X = rand_geno(rng, n, m)
+        r = rng.normal(0, 3.0, n)
+        r[rng.integers(0, n, 5)] *= 1e6
+        with H.Context(n, m, panel=panel, precise=2) as c:
+            c.upload(X)
+            c.set_residual(r, np.zeros(n))
+            d8 = c.dot()
+            c.set_layout(2, keep_int8=False)
+            c.set_matvec_kernel(2)
+            assert np.array_equal(c.dot(), d8), (shape, n, m)
+
+
 def test_two_bit_layout_pack_unpack_dot_and_products():
     """SURVEY §8 f1 (second half): genotypes resident at PLINK's density, 2 bits each (reference src/read_bed.cpp:116-167 is
     the format; hb_dotq2.hpp the packed word). Packing on the device, dropping the int8 copy, unpacking (genotype download),
