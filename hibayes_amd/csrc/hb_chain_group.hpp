@@ -45,7 +45,17 @@
 // lane and row, and every entry is rebuilt exactly, G[k][j] = g16[k][j] + ga[k] * gB[j] (one integer multiply-add), before it is used: the fold's
 // arithmetic is the int32 band's bit for bit. (tools/rowfetch2_bench.hip: 80 cycles per row this way against 111 for int32 rows; whole rows per
 // wave-load staged through LDS, by dwordx4 loads or by LDS-DMA: 127-131 — tried in the kernel too, profiles/r05_group_phases_g16b_*.txt.)
-template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false>
+// CERT (round 5): the violation check of a round WITHOUT the Gram rows of the group's own panels. With G[k][j] = ga[k] gB[j] + c[k][j] and
+// |c[k][j]| <= gcmax[k] (hb_ctx gcert arrays: exact integers from the band), a passed-over marker j ends the round at
+//     rhs_j - gB[j] * A_j - eps_j,   A_j = sum of ga[k] d_k over the moves before j,   |eps_j| <= E = sum_k gcmax[k] |d_k|,
+// so (|rhs_j - gB[j] A_j| + E)^2 < thr_j PROVES that j stayed below its threshold, and (|...| - E)^2 >= thr_j proves that it crossed. The rank-one
+// part is what a move does to every other marker (n mean_k mean_j: hundreds), E what is left (n cov + rounding: a few tens for a round's moves):
+// nearly every marker is decided by the certificate. A round whose passed-over markers are all proven to stay fetches only the rows of the
+// NEXT group's panels (7 of 15 per move, eight moves per trip instead of four); one with a proven crosser is repeated with it among the
+// candidates before anything is fetched; only a marker inside the +-E band sends the round through the full fold and the exact check. The
+// passed-over markers' own right-hand sides are not needed again once a round reaches the group's end, which is the only case certified.
+// Decisions, move lists and forward sums are the plain path's bit for bit (tests: HB_CERT=0 against 1).
+template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false, bool CERT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
                                                                                                  persist_view pv)
 {
@@ -63,14 +73,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     double *res_g = cs_d + (2 + 3 * K1) * 64;                   // ... their new effects
     double *ev_del = res_g + 64;                                // the round's moves: change of effect
     double *red = ev_del + 64;                                  // [16]
-    int *cs_pos = reinterpret_cast<int *>(red + 16);            // candidate -> position in the group (panel * P + marker)
+    double *spre = red + 16;                                    // [68] CERT: [k] = sum of ga * change over the round's candidates before candidate k (k = 0..64); [66] E, [67] max |prefix|
+    int *cs_pos = reinterpret_cast<int *>(spre + 68);           // candidate -> position in the group (panel * P + marker)
     int *res_c = cs_pos + 64;                                   // ... new classes
     int *ev_pos = res_c + 64;                                   // the round's moves: position
     int *cg = ev_pos + 64;                                      // [64][64] Gram entries among the round's candidates (k < c)
     int *cs_ga = cg + 64 * 64;                                  // [64] G16: the candidates' ga[]
     int *ev_ga = cs_ga + 64;                                    // [64] G16: ga[] of the round's movers
-    int *wcnt = ev_ga + 64;                                     // [HBG_DM][8] candidates per (panel of the group, wave)
-    int *misc = wcnt + 64;                                      // [0] moves of the round, [1] position the round ends at, [2] abort, [8..15] violations per wave, [16..23] moves published per panel
+    int *cs_cm = ev_ga + 64;                                    // [64] CERT: the candidates' gcmax[]
+    int *wcnt = cs_cm + 64;                                     // [HBG_DM][8] candidates per (panel of the group, wave)
+    int *misc = wcnt + 64;                                      // [0] moves of the round, [1] position the round ends at, [2] abort, [8..15] violations per wave, [16..23] moves published per panel, [24..31] CERT: per wave, bit 0 a proven crosser, bit 1 a marker the certificate cannot decide
     for (int l = 0; l < R; l++) corr[(size_t)l * P + t] = 0.0;
     if (t < 64) { wcnt[t] = 0; if (t < 32) misc[t] = 0; }
 
@@ -100,11 +112,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- (1) the group's dots, filter words and owed corrections ----
         double r0[HBG_DM];
         float fl[HBG_DM];
-        int gBi[G16 ? HBG_DM : 1], gBf[G16 ? HBG_FW : 1]; // G16: gB of this thread's markers in the group and in the panels ahead
+        int gBi[(G16 || CERT) ? HBG_DM : 1], gBf[G16 ? HBG_FW : 1]; // gB of this thread's markers in the group (G16, CERT) and in the panels ahead (G16)
         (void)gBi; (void)gBf;
-        if constexpr (G16) {
+        if constexpr (G16 || CERT) {
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) gBi[i] = v.gB[(size_t)(gp0 + min(i, Dg - 1)) * P + t];
+        }
+        if constexpr (G16) {
 #pragma unroll
             for (int x = 0; x < HBG_FW; x++) gBf[x] = v.gB[(size_t)min(gp0 + D + x, np - 1) * P + t];
         }
@@ -248,7 +262,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         cs_d[(2 + 2 * K1 + c) * 64 + rank] = v.sdz[(size_t)c * v.m_pad + j];
                     }
                     cs_pos[rank] = i * P + t;
-                    if constexpr (G16) cs_ga[rank] = v.ga[j];
+                    if constexpr (G16 || CERT) cs_ga[rank] = v.ga[j];
+                    if constexpr (CERT) cs_cm[rank] = v.gcmax[j];
                     rk |= (unsigned long long)rank << (8 * i);
                     inrm |= 1u << i;
                 }
@@ -319,10 +334,84 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 res_c[lane] = cls;
                 res_g[lane] = gn;
                 if (lane == 0) misc[0] = __popcll(moved);
+                if constexpr (CERT) { // what the certificate needs: prefix sums of ga * change in marker order, their largest magnitude, and E
+                    double w = lv ? (double)cs_ga[lane] * dmine : 0.0;
+                    const double e = lv ? (double)cs_cm[lane] * fabs(dmine) : 0.0;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const double up = __shfl_up(w, o, 64);
+                        if (lane >= o) w += up;
+                    }
+                    spre[lane + 1] = w;
+                    double am = fabs(w);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) am = fmax(am, __shfl_xor(am, o, 64));
+                    const double et = wave_sum(e);
+                    if (lane == 0) { spre[0] = 0.0; spre[66] = et; spre[67] = am; }
+                }
             }
             __syncthreads(); // B4
             HBG_ACC(4);
             const int nmoves = misc[0];
+            // ---- (4b) CERT: decide the passed-over markers from the rank-one part of the moves and the bound on the rest ----
+            bool need_full = true; // (uniform) the round goes through the full fold and the exact check
+            if constexpr (CERT) {
+                if (nmoves > 0 && pos_hi >= Dg * P) {
+                    const double E = spre[66] * (1.0 + 1e-9), Amax = spre[67] * (1.0 + 1e-9);
+                    // stage 1 (registers only): |rhs| + |gB| max|A| + E below the threshold — true for all but the few per cent of the markers that
+                    // the shift could reach at all
+                    unsigned st2 = 0, unc = 0, crs = 0;
+#pragma unroll
+                    for (int i = 0; i < HBG_DM; i++) {
+                        if (i < Dg) {
+                            const int pos = i * P + t;
+                            const double b1 = (fabs(r0[i]) + fabs((double)gBi[i]) * Amax + E) * (1.0 + 1e-9);
+                            const bool open = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && fl[i] == fl[i] && b1 * b1 >= (double)fl[i];
+                            st2 |= open ? 1u << i : 0u;
+                        }
+                    }
+                    // stage 2: the shift this marker really sees, from the prefix sum at the number of candidates before it
+                    for (unsigned left = st2; __any(left != 0u); left &= left - 1u) {
+                        const bool mine = left != 0u;
+                        const int i = mine ? __ffs((int)left) - 1 : 0;
+                        double r0i = r0[0];
+                        float fli = fl[0];
+                        int Bi = gBi[0];
+#pragma unroll
+                        for (int x = 1; x < HBG_DM; x++) {
+                            r0i = (i == x) ? r0[x] : r0i;
+                            fli = (i == x) ? fl[x] : fli;
+                            Bi = (i == x) ? gBi[x] : Bi;
+                        }
+                        const int before = min(64, __shfl(myscan, i * 8 + wave, 64) + (int)((rkp >> (8 * i)) & 0xffull)); // the round's candidates before this marker
+                        const double cc = fabs(fma(-(double)Bi, spre[before], r0i));
+                        const double hi = (cc + E) * (1.0 + 1e-9), lo = (cc - E) * (1.0 - 1e-9);
+                        if (mine && hi * hi >= (double)fli) {
+                            if (lo > 0.0 && lo * lo >= (double)fli) crs |= 1u << i;
+                            else unc |= 1u << i;
+                        }
+                    }
+                    {
+                        const unsigned long long bu = __ballot(unc != 0u), bc = __ballot(crs != 0u);
+                        if (lane == 0) misc[24 + wave] = (bu != 0ull ? 2 : 0) | (bc != 0ull ? 1 : 0);
+                    }
+                    __syncthreads(); // B4b
+                    int any = 0;
+                    {
+                        int w8[8];
+                        hb_read8(misc + 24, w8);
+#pragma unroll
+                        for (int w = 0; w < 8; w++) any |= w8[w];
+                    }
+                    HBG_ACC(9);
+                    if (any & 1) { // a proven crosser: it joins the candidates and the round is repeated — nothing was fetched for it
+                        forced |= crs;
+                        HBG_CNT(15, 1);
+                        continue;
+                    }
+                    need_full = (any & 2) != 0;
+                }
+            }
             // ---- (5) the round's moves onto the later markers of the group AND forward, all rows of up to HBG_CH moves in one
             // trip (a lone compute unit's loads take microseconds beside the streaming mat-vec: the number of dependent trips is
             // what a group costs). The forward contributions are summed in registers and reach the correction ring only when the
@@ -335,7 +424,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // (row addresses are "wave-uniform pointer"[t]: scalar base + one vector offset, no 64-bit vector arithmetic)
             using gram_t = typename std::conditional<G16, int16_t, int32_t>::type;
             const gram_t *gbase = G16 ? reinterpret_cast<const gram_t *>(v.gram16) + (size_t)gp0 * (pv.Lg + 1) * PP : reinterpret_cast<const gram_t *>(gblk0);
-            {
+            if (CERT && !need_full) {
+                // every passed-over marker is proven to stay and the round reaches the group's end: only the next group's panels need the moves
+                constexpr int CH2 = (63 / HBG_FW) < 8 ? (63 / HBG_FW) : 8;
+                if (have_fw) {
+#pragma unroll 1
+                    for (int e0 = 0; e0 < nmoves; e0 += CH2) {
+                        int gf2[CH2][HBG_FW];
+                        double dl2[CH2];
+#pragma unroll
+                        for (int f = 0; f < CH2; f++) {
+                            const int e = min(e0 + f, nmoves - 1);
+                            const int a = __builtin_amdgcn_readfirstlane(ev_pos[e]);
+                            const int pa = a >> lgP, ia = a & (P - 1);
+                            dl2[f] = (e0 + f < nmoves) ? ev_del[e] : 0.0;
+                            const int32_t *row = gblk0 + (size_t)ia * P + (size_t)D * pstep - (size_t)pa * PP; // first panel ahead
+#pragma unroll
+                            for (int x = 0; x < HBG_FW; x++) {
+                                gf2[f][x] = row[t];
+                                row += (x + 1 < nfw) ? pstep : 0;
+                            }
+                        }
+#pragma unroll
+                        for (int f = 0; f < CH2; f++)
+#pragma unroll
+                            for (int x = 0; x < HBG_FW; x++) fw[x] = (x < nfw) ? fma((double)gf2[f][x], dl2[f], fw[x]) : fw[x];
+                    }
+                }
+            } else {
 #pragma unroll 1
             for (int e0 = 0; e0 < nmoves; e0 += HBG_CH) {
                 int gv[HBG_CH][HBG_DM], gf[HBG_CH][HBG_FW];
@@ -386,27 +502,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             // ---- (6) did every marker the round passed over really stay below its threshold? ----
             unsigned violm = 0;
-#pragma unroll
-            for (int i = 0; i < HBG_DM; i++) {
-                if (i < Dg) {
-                    const int pos = i * P + t;
-                    const bool viol = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && rnew[i] * rnew[i] >= (double)fl[i]; // (NaN filter: false)
-                    violm |= viol ? 1u << i : 0u;
-                }
-            }
-            {
-                const unsigned long long vm = __ballot(violm != 0u);
-                if (lane == 0) misc[8 + wave] = vm != 0ull;
-            }
-            __syncthreads(); // B5
-            HBG_ACC(5);
             bool anyv = false;
-            {
+            if (need_full) {
+#pragma unroll
+                for (int i = 0; i < HBG_DM; i++) {
+                    if (i < Dg) {
+                        const int pos = i * P + t;
+                        const bool viol = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && rnew[i] * rnew[i] >= (double)fl[i]; // (NaN filter: false)
+                        violm |= viol ? 1u << i : 0u;
+                    }
+                }
+                {
+                    const unsigned long long vm = __ballot(violm != 0u);
+                    if (lane == 0) misc[8 + wave] = vm != 0ull;
+                }
+                __syncthreads(); // B5
                 int w8[8];
                 hb_read8(misc + 8, w8);
 #pragma unroll
                 for (int w = 0; w < 8; w++) anyv |= w8[w] != 0;
             }
+            HBG_ACC(5);
             if (anyv) { // roll the round back: the markers that crossed join the candidates
                 forced |= violm;
                 if (t == 0) redoacc++;

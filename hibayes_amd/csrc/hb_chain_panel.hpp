@@ -30,6 +30,7 @@ struct chain_view {
     // round 5: the band as rank one + int16 residual (hb_ctx.gram16): G[k][j] = ga[k] * gB[j] + gram16[k][j]; null: not built
     const int16_t *gram16;
     const int32_t *ga, *gB;
+    const int32_t *gcmax; // the certificate's bound (hb_build_gcert); null: no certificate
 };
 
 // Cycle stamps of the chain kernels (tools/chain_timeline.py): compiled in only with -DHB_STAMPS=1 (tools/build_variant.sh) —

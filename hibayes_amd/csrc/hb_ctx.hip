@@ -151,6 +151,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_DOTQ2_TILES")) c->dotq2_tiles = std::max(1, atoi(e));
     if (const char *e = getenv("HB_DOTQ2_KIND")) c->dotq2_kind = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("HB_GRAM16")) c->gram16_on = atoi(e) != 0;
+    if (const char *e = getenv("HB_CERT")) c->gcert_on = atoi(e) != 0;
     if (const char *e = getenv("HB_Q2M_CT")) c->q2m_ct = atoi(e) >= 16 ? 16 : atoi(e) >= 8 ? 8 : 4;
     if (const char *e = getenv("HB_Q2M_G")) c->q2m_g = atoi(e) == 3 ? 3 : atoi(e) >= 2 ? 2 : atoi(e) == 0 ? 0 : 1;
     if (const char *e = getenv("HB_Q2M_SC")) c->q2m_sc = atoi(e) != 0;
@@ -311,7 +312,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->s_dbg) (void)hipStreamDestroy(c->s_dbg);
     void *ptrs[] = {c->X, c->X2, c->xpx, c->vx, c->s1, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->fcorr, c->ddense, c->fcorr2, c->dots, c->ev_count, c->ev_idx,
-                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->gram16, c->ga, c->gB, c->g16_flag, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa, c->snap, c->ldiag};
+                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->gram16, c->ga, c->gB, c->gcmax, c->g16_flag, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa, c->snap, c->ldiag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     blocks_free(c);
@@ -609,6 +610,8 @@ int hb_ctx_build_gram(hb_ctx *c, double *seconds)
         return hb_fail(HB_ERR_UNSUPPORTED, "genotype codes too large for the exact int32 Gram matrix at this n");
     const auto t0 = std::chrono::steady_clock::now();
     rc = hb_build_gram_impl(c);
+    if (rc) return rc;
+    rc = hb_build_gcert(c); // (the rank-one part of the band and the bound on the rest: the group chain's certificate)
     if (rc) return rc;
     rc = hb_build_gram16(c); // (the compact copy the group chain folds from; the row-sharded mode sums int32 blocks over the ranks and never runs it)
     if (rc) return rc;

@@ -176,7 +176,53 @@ __global__ __launch_bounds__(256) void k_gram16(const int32_t *__restrict__ gram
     *reinterpret_cast<short4 *>(g16 + idx) = o;
 }
 
-// after the int32 band is in place: the compact copy, if every residual fits an int16 (non-negative genotype codes only: the column
+// cmax[k] = max over the stored band of |G[k][j] - ga[k] gB[j]|, row marker k (one 128-thread block per row of a block: P / 4 threads x 4 entries)
+__global__ __launch_bounds__(128) void k_gcmax(const int32_t *__restrict__ gram, const int32_t *__restrict__ ga, const int32_t *__restrict__ gB, int P, int Lg,
+                                               int32_t *__restrict__ gcmax)
+{
+    __shared__ int red[2];
+    const size_t rowi = blockIdx.x; // [panel][block l][row k]
+    const size_t blk = rowi / P;
+    const int k = (int)(rowi % P);
+    const int p = (int)(blk / (size_t)(Lg + 1)), l = (int)(blk % (size_t)(Lg + 1));
+    if (p - l < 0) return; // (uniform per block: no such pair of panels)
+    const size_t rm = (size_t)(p - l) * P + k;
+    const int a = ga[rm];
+    int mx = 0;
+    for (int t4 = threadIdx.x * 4; t4 < P; t4 += blockDim.x * 4) {
+        const int4 gq = *reinterpret_cast<const int4 *>(gram + rowi * P + t4);
+        const int4 bq = *reinterpret_cast<const int4 *>(gB + (size_t)p * P + t4);
+        mx = max(mx, max(max(abs(gq.x - a * bq.x), abs(gq.y - a * bq.y)), max(abs(gq.z - a * bq.z), abs(gq.w - a * bq.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(gcmax + rm, max(red[0], blockDim.x > 64 ? red[1] : 0));
+}
+
+// after the int32 band is in place: the arrays of the group chain's certificate (hb_chain_group.hpp, CERT): G[k][j] = ga[k] gB[j] + c[k][j] with
+// |c[k][j]| <= gcmax[k] for every stored pair — exact integers, whatever the genotype coding
+int hb_build_gcert(hb_ctx *c)
+{
+    c->gcert_ok = false;
+    if (!c->gcert_on || c->P % 4 != 0 || c->row_reduce) return HB_OK; // (row-sharded mode: the local blocks are partial sums)
+    if (!c->ga) {
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->ga), sizeof(int32_t) * (size_t)c->m_pad));
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->gB), sizeof(int32_t) * (size_t)c->m_pad));
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->gcmax), sizeof(int32_t) * (size_t)c->m_pad));
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->g16_flag), sizeof(int)));
+    }
+    hipLaunchKernelGGL(k_g16_ab, dim3((c->m_pad + 255) / 256), dim3(256), 0, c->stream, c->s1, c->m_pad, (double)c->n, c->ga, c->gB);
+    HB_HIP(hipMemsetAsync(c->gcmax, 0, sizeof(int32_t) * (size_t)c->m_pad, c->stream));
+    const size_t nrows = (size_t)c->npanels * (size_t)(c->Lg + 1) * (size_t)c->P;
+    hipLaunchKernelGGL(k_gcmax, dim3((unsigned)nrows), dim3(128), 0, c->stream, c->gram, c->ga, c->gB, c->P, c->Lg, c->gcmax);
+    HB_HIP(hipGetLastError());
+    c->gcert_ok = true;
+    return HB_OK;
+}
+
+// ... and the compact copy, if every residual fits an int16 (non-negative genotype codes only: the column
 // sums are then the scale of every product)
 int hb_build_gram16(hb_ctx *c)
 {
@@ -193,13 +239,8 @@ int hb_build_gram16(hb_ctx *c)
         }
         c->gram16_cap = need;
     }
-    if (!c->ga) {
-        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->ga), sizeof(int32_t) * (size_t)c->m_pad));
-        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->gB), sizeof(int32_t) * (size_t)c->m_pad));
-        HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->g16_flag), sizeof(int)));
-    }
+    if (!c->gcert_ok) return HB_OK; // (ga / gB come from hb_build_gcert)
     HB_HIP(hipMemsetAsync(c->g16_flag, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_g16_ab, dim3((c->m_pad + 255) / 256), dim3(256), 0, c->stream, c->s1, c->m_pad, (double)c->n, c->ga, c->gB);
     const size_t nquads = need / 4;
     hipLaunchKernelGGL(k_gram16, dim3((unsigned)((nquads + 255) / 256)), dim3(256), 0, c->stream, c->gram, c->gram16, c->ga, c->gB, c->P, c->Lg,
                        nquads, c->g16_flag);

@@ -101,7 +101,8 @@ struct hb_ctx {
     // fold a move's rows from it: half the bytes of the phase that is 44 % of their time. Built when every residual fits (else null: the int32 band serves).
     int16_t *gram16 = nullptr;
     size_t gram16_cap = 0;
-    int32_t *ga = nullptr, *gB = nullptr;
+    int32_t *ga = nullptr, *gB = nullptr, *gcmax = nullptr; // G[k][j] = ga[k] gB[j] + c[k][j], |c[k][j]| <= gcmax[k]: the group chain's certificate (hb_build_gcert)
+    bool gcert_ok = false, gcert_on = true;                 // (HB_CERT=0: off)
     int *g16_flag = nullptr;
     bool gram16_ok = false, gram16_on = false; // (HB_GRAM16=1: on. OFF by default: measured slower than the int32 band both ways it was read)
     bool env_pinned = false;
@@ -214,6 +215,7 @@ extern "C" int hb_ctx_sweep_end(hb_ctx *c, hb_sweep_out *out);
 int hb_comm_allreduce_f64(hb_comm *c, double *buf, size_t count, hipStream_t st);
 int hb_build_gram_impl(hb_ctx *c);
 int hb_build_gram16(hb_ctx *c);
+int hb_build_gcert(hb_ctx *c);
 
 // device buffers of one summary-level run (hb_sbayes.hip owns them; the kernels are in hb_sbayes.hpp)
 struct hb_sb_dev {

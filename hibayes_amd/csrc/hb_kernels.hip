@@ -168,6 +168,7 @@ int hbk_init_attrs()
     HB_GROUP_ATTR(1, 8, 14, 3); HB_GROUP_ATTR(1, 8, 7, 4); HB_GROUP_ATTR(1, 2, 4, 10); HB_GROUP_ATTR(1, 1, 2, 20);
     HB_GROUP_ATTR(3, 1, 2, 20); HB_GROUP_ATTR(7, 1, 2, 20);
     HB_GROUP_ATTR16(1, 8, 7, 4);
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 8, 7, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -665,6 +666,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
                   c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
     const bool g16 = c->gram16_ok && c->gram16 != nullptr; // (the compact band: only the wide group chain and its k_fwd read it)
     if (g16) { cv.gram16 = c->gram16; cv.ga = c->ga; cv.gB = c->gB; }
+    const bool cert = !g16 && c->gcert_ok && c->gcmax != nullptr; // (the wide group chain's certified violation check)
+    if (cert) { cv.ga = c->ga; cv.gB = c->gB; cv.gcmax = c->gcmax; }
     const int last_panels = np - (g0 + ngroups - 1) * D;
     persist_view pv{np, D, Lv, c->L, c->Lg, pb, c->flags,
                     c->hot_slot, c->hot_list, c->thr0f, c->candf, nullptr};
@@ -701,6 +704,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         if (group_chain) {
             const size_t sm = persist_smem(c->P);
             if (fwd && g16) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            else if (fwd && cert) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (fwd) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (kp == 1 && shape == 0) hipLaunchKernelGGL((k_chain_group<1, 8, 14, 3>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (kp == 1 && shape == 1) hipLaunchKernelGGL((k_chain_group<1, 2, 4, 10>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);

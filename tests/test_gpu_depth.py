@@ -374,17 +374,22 @@ def test_continued_chain_is_the_oracles_continued_chain(big, model, Pi, fold):
         assert abs(int((r2["MCMCsamples"]["alpha"][:, 0] != 0).sum()) - nnz1) < max(20, nnz1)
 
 
-def test_compact_band_is_the_int32_band_bit_for_bit(big, monkeypatch):
-    """HB_GRAM16=1 (round 5; off by default): the wide group chain and k_fwd fold a move's rows from the band stored as rank one + int16
-    residual, G[k][j] = ga[k] gB[j] + g16[k][j], every entry rebuilt exactly before it is used — the same integers, so the run must equal
-    the int32 band's BIT FOR BIT (and therefore the oracle's draw for draw), cold start with the geometry switch and a dense start."""
+@pytest.mark.parametrize("knob,values", [("HB_CERT", ("0", "1")), ("HB_GRAM16", ("0", "1"))])
+def test_certified_check_and_compact_band_are_the_plain_group_chain_bit_for_bit(big, monkeypatch, knob, values):
+    """Two round-5 variants of k_chain_group at (3, 7) must change NOTHING in the results:
+    HB_CERT (on by default): the violation check of a round from the rank-one part of the moves, G[k][j] = ga[k] gB[j] + c[k][j], and the bound
+    |c[k][j]| <= gcmax[k] — passed-over markers proven to stay cost no Gram rows, proven crossers join the candidates before anything is fetched,
+    the undecided ones send the round through the full fold and the exact check; HB_GRAM16 (off by default): a move's rows fetched from the band
+    stored as int16 residuals and rebuilt exactly. Decisions, move lists and every sum must be the plain path's BIT FOR BIT — a cold start with
+    the geometry switch, and a dense start (5 % of the markers in the model: rounds that do not reach the group's end, roll-backs) — and the
+    oracle's draw for draw."""
     X, y = big["X"], big["y"]
     m = X.shape[1]
     rng = np.random.default_rng(12)
     g0 = np.where(rng.random(m) < 0.05, rng.normal(0, 0.03, m), 0.0)
     out = []
-    for on in ("0", "1"):
-        monkeypatch.setenv("HB_GRAM16", on)
+    for on in values:
+        monkeypatch.setenv(knob, on)
         res = []
         with H.Context(X.shape[0], m, panel=512, seed=99) as c:
             c.upload(X)
@@ -392,7 +397,7 @@ def test_compact_band_is_the_int32_band_bit_for_bit(big, monkeypatch):
             c.build_gram()
             c.set_adaptive(True)
             c.set_layout(2, keep_int8=False)
-            res.append(H.Bayes(y, None, "BayesCpi", [0.95, 0.05], verbose=False, ctx=c, niter=30, nburn=10, thin=2, seed=99))
+            res.append(H.Bayes(y, None, "BayesCpi", [0.95, 0.05], verbose=False, ctx=c, niter=60, nburn=20, thin=4, seed=99))
             c.set_adaptive(False)
             c.set_pipeline(1, 3, 7)
             res.append(H.Bayes(y, None, "BayesCpi", [0.95, 0.05], verbose=False, ctx=c, niter=6, nburn=0, thin=1, seed=98, g_init=g0))
@@ -401,5 +406,6 @@ def test_compact_band_is_the_int32_band_bit_for_bit(big, monkeypatch):
         for k in ("alpha", "pip", "g", "pi", "Vg", "Ve"):
             assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
         assert np.array_equal(a["MCMCsamples"]["alpha"], b["MCMCsamples"]["alpha"])
+        assert a["timing"]["mean_events"] == b["timing"]["mean_events"]
     ref = O.bayes(y, X, "BayesCpi", [0.95, 0.05], rng=O.RNG_PHILOX, store_alpha=True, niter=6, nburn=0, thin=1, seed=98, g_init=g0)
     _compare(out[1][1], ref)
