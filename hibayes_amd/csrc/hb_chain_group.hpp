@@ -51,10 +51,16 @@
 // so (|rhs_j - gB[j] A_j| + E)^2 < thr_j PROVES that j stayed below its threshold, and (|...| - E)^2 >= thr_j proves that it crossed. The rank-one
 // part is what a move does to every other marker (n mean_k mean_j: hundreds), E what is left (n cov + rounding: a few tens for a round's moves):
 // nearly every marker is decided by the certificate. A round whose passed-over markers are all proven to stay fetches only the rows of the
-// NEXT group's panels (7 of 15 per move, eight moves per trip instead of four); one with a proven crosser is repeated with it among the
-// candidates before anything is fetched; only a marker inside the +-E band sends the round through the full fold and the exact check. The
-// passed-over markers' own right-hand sides are not needed again once a round reaches the group's end, which is the only case certified.
-// Decisions, move lists and forward sums are the plain path's bit for bit (tests: HB_CERT=0 against 1).
+// NEXT group's panels (7 of 15 per move, eight moves per trip instead of four); a marker that is not proven to stay (nearly always: a real
+// crosser) joins the candidates and the round is repeated before anything is fetched — a candidate is decided exactly, so an unnecessary
+// one costs a lane of the serial pass and nothing else. The passed-over markers' own right-hand sides are not needed again once a round
+// reaches the group's end, which is the only case certified; a round that does not (more than 64 candidates: cold and dense sweeps) takes
+// the full fold and the exact check as before. Decisions and move lists are the plain path's; where a group needs one round (the stationary
+// regime) every sum is too, bit for bit; where the two paths cut a crowded group into rounds differently the forward sums are grouped
+// differently and effects agree to the last bits' rounding (tests: HB_CERT=0 against 1).
+#ifndef HBG_CERT_MARGIN
+#define HBG_CERT_MARGIN 0.9
+#endif
 template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false, bool CERT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
                                                                                                  persist_view pv)
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int *ev_ga = cs_ga + 64;                                    // [64] G16: ga[] of the round's movers
     int *cs_cm = ev_ga + 64;                                    // [64] CERT: the candidates' gcmax[]
     int *wcnt = cs_cm + 64;                                     // [HBG_DM][8] candidates per (panel of the group, wave)
-    int *misc = wcnt + 64;                                      // [0] moves of the round, [1] position the round ends at, [2] abort, [8..15] violations per wave, [16..23] moves published per panel, [24..31] CERT: per wave, bit 0 a proven crosser, bit 1 a marker the certificate cannot decide
+    int *misc = wcnt + 64;                                      // [0] moves of the round, [1] position the round ends at, [2] abort, [8..15] violations per wave, [16..23] moves published per panel, [24..31] CERT: per wave, a marker not proven to stay
     for (int l = 0; l < R; l++) corr[(size_t)l * P + t] = 0.0;
     if (t < 64) { wcnt[t] = 0; if (t < 32) misc[t] = 0; }
 
@@ -113,7 +119,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         double r0[HBG_DM];
         float fl[HBG_DM];
         int gBi[(G16 || CERT) ? HBG_DM : 1], gBf[G16 ? HBG_FW : 1]; // gB of this thread's markers in the group (G16, CERT) and in the panels ahead (G16)
-        (void)gBi; (void)gBf;
+        float sqf[CERT ? HBG_DM : 1];                                // CERT: lower bound of sqrt(threshold) of this thread's markers
+        (void)gBi; (void)gBf; (void)sqf;
         if constexpr (G16 || CERT) {
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) gBi[i] = v.gB[(size_t)(gp0 + min(i, Dg - 1)) * P + t];
@@ -140,6 +147,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) fl[i] = i < Dg ? fl[i] : __int_as_float(0x7fc00000);
+            if constexpr (CERT) { // a LOWER bound of the square root of the (float) threshold: the certificate compares magnitudes, not squares
+#pragma unroll
+                for (int i = 0; i < HBG_DM; i++) sqf[i] = sqrtf(fl[i]) * (1.0f - 4e-7f);
+            }
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++)
                 bad |= (i < Dg) && (__double_as_longlong(dj[i]) == -1ll || (far_in && __double_as_longlong(fc[i]) == -1ll));
@@ -336,18 +347,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (lane == 0) misc[0] = __popcll(moved);
                 if constexpr (CERT) { // what the certificate needs: prefix sums of ga * change in marker order, their largest magnitude, and E
                     double w = lv ? (double)cs_ga[lane] * dmine : 0.0;
-                    const double e = lv ? (double)cs_cm[lane] * fabs(dmine) : 0.0;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const double up = __shfl_up(w, o, 64);
-                        if (lane >= o) w += up;
+                    double e = lv ? (double)cs_cm[lane] * fabs(dmine) : 0.0;
+                    double am;
+                    if (ncr <= 16) { // (the usual case) inclusive scans inside the first row of 16 lanes, by DPP: sum of w, running max of |prefix|, sum of e
+#define HBG_SCAN_STEP(N)                                                                                                           \
+                        {                                                                                                          \
+                            const double uw = dpp_row_shr_f64<N>(w), ue = dpp_row_shr_f64<N>(e);                                   \
+                            w += uw;                                                                                               \
+                            e += ue;                                                                                               \
+                        }
+                        HBG_SCAN_STEP(1) HBG_SCAN_STEP(2) HBG_SCAN_STEP(4) HBG_SCAN_STEP(8)
+#undef HBG_SCAN_STEP
+                        am = fabs(w);
+#define HBG_MAX_STEP(N) am = fmax(am, dpp_row_shr_f64<N>(am));
+                        HBG_MAX_STEP(1) HBG_MAX_STEP(2) HBG_MAX_STEP(4) HBG_MAX_STEP(8)
+#undef HBG_MAX_STEP
+                        // (lane ncr - 1 of row 0 holds the totals; lanes of the other rows hold zeros)
+                        e = readlane_f64(e, ncr - 1);
+                        am = readlane_f64(am, ncr - 1);
+                    } else {
+#pragma unroll 1
+                        for (int o = 1; o < ncr; o <<= 1) {
+                            const double up = __shfl_up(w, o, 64);
+                            if (lane >= o) w += up;
+                        }
+                        am = lane < ncr ? fabs(w) : 0.0;
+#pragma unroll 1
+                        for (int o = 32; o > 0; o >>= 1) {
+                            am = fmax(am, __shfl_xor(am, o, 64));
+                            e += __shfl_xor(e, o, 64);
+                        }
                     }
-                    spre[lane + 1] = w;
-                    double am = fabs(w);
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) am = fmax(am, __shfl_xor(am, o, 64));
-                    const double et = wave_sum(e);
-                    if (lane == 0) { spre[0] = 0.0; spre[66] = et; spre[67] = am; }
+                    if (lane < ncr) spre[lane + 1] = w;
+                    if (lane == 0) { spre[0] = 0.0; spre[66] = e; spre[67] = am; }
                 }
             }
             __syncthreads(); // B4
@@ -358,16 +390,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if constexpr (CERT) {
                 if (nmoves > 0 && pos_hi >= Dg * P) {
                     const double E = spre[66] * (1.0 + 1e-9), Amax = spre[67] * (1.0 + 1e-9);
-                    // stage 1 (registers only): |rhs| + |gB| max|A| + E below the threshold — true for all but the few per cent of the markers that
-                    // the shift could reach at all
-                    unsigned st2 = 0, unc = 0, crs = 0;
+                    // stage 1 (registers only): |rhs| + |gB| max|A| + E below the square root of the threshold — true for all but the few per cent
+                    // of the markers that the shift could reach at all
+                    unsigned st2 = 0, open = 0;
 #pragma unroll
                     for (int i = 0; i < HBG_DM; i++) {
                         if (i < Dg) {
                             const int pos = i * P + t;
-                            const double b1 = (fabs(r0[i]) + fabs((double)gBi[i]) * Amax + E) * (1.0 + 1e-9);
-                            const bool open = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && fl[i] == fl[i] && b1 * b1 >= (double)fl[i];
-                            st2 |= open ? 1u << i : 0u;
+                            const double b1 = fma(fabs((double)gBi[i]), Amax, fabs(r0[i]) + E);
+                            const bool op = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && b1 >= (double)sqf[i]; // (NaN, the inactive and the hot markers: false)
+                            st2 |= op ? 1u << i : 0u;
                         }
                     }
                     // stage 2: the shift this marker really sees, from the prefix sum at the number of candidates before it
@@ -375,25 +407,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const bool mine = left != 0u;
                         const int i = mine ? __ffs((int)left) - 1 : 0;
                         double r0i = r0[0];
-                        float fli = fl[0];
+                        float sqi = sqf[0];
                         int Bi = gBi[0];
 #pragma unroll
                         for (int x = 1; x < HBG_DM; x++) {
                             r0i = (i == x) ? r0[x] : r0i;
-                            fli = (i == x) ? fl[x] : fli;
+                            sqi = (i == x) ? sqf[x] : sqi;
                             Bi = (i == x) ? gBi[x] : Bi;
                         }
                         const int before = min(64, __shfl(myscan, i * 8 + wave, 64) + (int)((rkp >> (8 * i)) & 0xffull)); // the round's candidates before this marker
-                        const double cc = fabs(fma(-(double)Bi, spre[before], r0i));
-                        const double hi = (cc + E) * (1.0 + 1e-9), lo = (cc - E) * (1.0 - 1e-9);
-                        if (mine && hi * hi >= (double)fli) {
-                            if (lo > 0.0 && lo * lo >= (double)fli) crs |= 1u << i;
-                            else unc |= 1u << i;
-                        }
+                        const double hi = (fabs(fma(-(double)Bi, spre[before], r0i)) + E) * (1.0 + 1e-9);
+                        // (not proven to stay — or within a tenth of its threshold: a marker that close is taken along now rather than in one more
+                        // repetition when the next candidate's move has pushed it over; an extra candidate is decided exactly and costs a lane)
+                        if (mine && hi >= HBG_CERT_MARGIN * (double)sqi) open |= 1u << i;
                     }
                     {
-                        const unsigned long long bu = __ballot(unc != 0u), bc = __ballot(crs != 0u);
-                        if (lane == 0) misc[24 + wave] = (bu != 0ull ? 2 : 0) | (bc != 0ull ? 1 : 0);
+                        const unsigned long long bo = __ballot(open != 0u);
+                        if (lane == 0) misc[24 + wave] = bo != 0ull;
                     }
                     __syncthreads(); // B4b
                     int any = 0;
@@ -404,12 +434,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         for (int w = 0; w < 8; w++) any |= w8[w];
                     }
                     HBG_ACC(9);
-                    if (any & 1) { // a proven crosser: it joins the candidates and the round is repeated — nothing was fetched for it
-                        forced |= crs;
+                    if (any) { // a marker that may have crossed (nearly always: has) joins the candidates and the round is repeated — nothing was fetched for it
+                        forced |= open;
                         HBG_CNT(15, 1);
                         continue;
                     }
-                    need_full = (any & 2) != 0;
+                    need_full = false;
                 }
             }
             // ---- (5) the round's moves onto the later markers of the group AND forward, all rows of up to HBG_CH moves in one

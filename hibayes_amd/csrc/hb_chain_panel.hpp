@@ -53,6 +53,15 @@ __device__ __forceinline__ double readlane_f64(double v, int k)
     return __hiloint2double(hi, lo);
 }
 
+// v of the lane N below within the lane's row of 16 (DPP row_shr: a modifier of the move, no LDS round trip); 0 where there is none
+template <int N>
+__device__ __forceinline__ double dpp_row_shr_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + N, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 // LDS plan (dynamic, one object): [row cache: nslot x P int32][ev_del: P f64][ev_ix: P i32][slot_of: P i32]
 // [red: 16 f64][cnts: 16 i32][wcnt: 16 i32].
 // The row cache holds the full Gram rows G[k][0..P) of the markers that are certain to move this sweep

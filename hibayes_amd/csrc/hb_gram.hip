@@ -192,7 +192,10 @@ __global__ __launch_bounds__(128) void k_gcmax(const int32_t *__restrict__ gram,
     for (int t4 = threadIdx.x * 4; t4 < P; t4 += blockDim.x * 4) {
         const int4 gq = *reinterpret_cast<const int4 *>(gram + rowi * P + t4);
         const int4 bq = *reinterpret_cast<const int4 *>(gB + (size_t)p * P + t4);
-        mx = max(mx, max(max(abs(gq.x - a * bq.x), abs(gq.y - a * bq.y)), max(abs(gq.z - a * bq.z), abs(gq.w - a * bq.w))));
+        // (the diagonal, x_k . x_k, is no pair: a marker's own entry never reaches another marker's right-hand side)
+        const int c0 = (l == 0 && t4 == k) ? 0 : abs(gq.x - a * bq.x), c1 = (l == 0 && t4 + 1 == k) ? 0 : abs(gq.y - a * bq.y);
+        const int c2 = (l == 0 && t4 + 2 == k) ? 0 : abs(gq.z - a * bq.z), c3 = (l == 0 && t4 + 3 == k) ? 0 : abs(gq.w - a * bq.w);
+        mx = max(mx, max(max(c0, c1), max(c2, c3)));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
