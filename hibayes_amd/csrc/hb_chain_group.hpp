@@ -59,7 +59,7 @@
 // regime) every sum is too, bit for bit; where the two paths cut a crowded group into rounds differently the forward sums are grouped
 // differently and effects agree to the last bits' rounding (tests: HB_CERT=0 against 1).
 #ifndef HBG_CERT_MARGIN
-#define HBG_CERT_MARGIN 0.9
+#define HBG_CERT_MARGIN 1.0
 #endif
 template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false, bool CERT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const double E = spre[66] * (1.0 + 1e-9), Amax = spre[67] * (1.0 + 1e-9);
                     // stage 1 (registers only): |rhs| + |gB| max|A| + E below the square root of the threshold — true for all but the few per cent
                     // of the markers that the shift could reach at all
-                    unsigned st2 = 0, open = 0;
+                    unsigned st2 = 0, open = 0, close_by = 0;
 #pragma unroll
                     for (int i = 0; i < HBG_DM; i++) {
                         if (i < Dg) {
@@ -417,9 +417,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         }
                         const int before = min(64, __shfl(myscan, i * 8 + wave, 64) + (int)((rkp >> (8 * i)) & 0xffull)); // the round's candidates before this marker
                         const double hi = (fabs(fma(-(double)Bi, spre[before], r0i)) + E) * (1.0 + 1e-9);
-                        // (not proven to stay — or within a tenth of its threshold: a marker that close is taken along now rather than in one more
-                        // repetition when the next candidate's move has pushed it over; an extra candidate is decided exactly and costs a lane)
-                        if (mine && hi >= HBG_CERT_MARGIN * (double)sqi) open |= 1u << i;
+                        if (mine && hi >= (double)sqi) open |= 1u << i; // not proven to stay
+                        // (within HBG_CERT_MARGIN of its threshold: taken along IF the round is repeated anyway — the new candidate's move may push
+                        // it over, which would cost one more repetition; an extra candidate is decided exactly and costs a lane)
+                        if (mine && hi >= HBG_CERT_MARGIN * (double)sqi) close_by |= 1u << i;
                     }
                     {
                         const unsigned long long bo = __ballot(open != 0u);
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     HBG_ACC(9);
                     if (any) { // a marker that may have crossed (nearly always: has) joins the candidates and the round is repeated — nothing was fetched for it
-                        forced |= open;
+                        forced |= open | close_by;
                         HBG_CNT(15, 1);
                         continue;
                     }
