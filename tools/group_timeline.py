@@ -50,8 +50,8 @@ info = RunInfo(); check(L.hb_run_state(run, ct.byref(info)))
 nmv, cand, rounds, redo, rep = st[:, 10], st[:, 12], st[:, 13], st[:, 14], st[:, 15]
 per = np.append(st[1:, 16] - st[:-1, 16], st[-1, 17] - st[-1, 16])
 cyc = float(st[-1, 17] - st[0, 16])
-names = ["dots (waiting)", "ranking", "exact data", "gram gather", "serial pass", "fold+verify", "commit+publish", "forward", "end of group", "(unused)"]
-print("%s geometry %s: %d groups, %d moves, %d candidates (first rounds), %d committed rounds, %d rolled back, %d repeated by the pre-check; chain span %d cycles" % (
+names = ["dots (waiting)", "ranking", "exact data", "gram gather", "serial pass", "fold+verify", "commit+publish", "forward", "end of group", "certificate"]
+print("%s geometry %s: %d groups, %d moves, %d candidates (first rounds), %d committed rounds, %d rolled back after a full fold, %d repeated by the certificate before the fold; chain span %d cycles" % (
     model, ctx.pipeline(), ng, nmv.sum(), cand.sum(), rounds.sum(), redo.sum(), rep.sum(), cyc))
 print("  whole sweep, cycles by phase (accumulated over all rounds): " + " | ".join("%s %d" % (names[k], st[:, k].sum()) for k in range(10)))
 for name, sel in (("quiet", cand == 0), ("candidates, no move", (cand > 0) & (nmv == 0)), ("1-4 moves", (nmv >= 1) & (nmv <= 4)),
