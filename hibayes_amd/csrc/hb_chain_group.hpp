@@ -94,6 +94,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int model = pin->model_index;
     const int count_pip = pin->count_pip, store = pin->store;
+
     double wacc = 0.0;
     int nact = 0, cacc[K1 + 1];
 #pragma unroll
@@ -262,19 +263,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int rank = basew + (int)((rkp >> (8 * i)) & 0xffull);
                 if (mine && rank == 64) misc[1] = i * P + t;
                 if (mine && rank < 64) {
+                    // ONE round trip: every load is issued before the first is looked at (round 5: the effect's product with x'x used to sit
+                    // behind "gold != 0", which put the load of x'x a second round trip behind the load of the effect; for an effect of zero
+                    // fma(xx, 0, rhs) is rhs exactly, so the product is taken unconditionally)
                     const size_t j = (size_t)(gp0 + i) * P + t;
                     const double gold = v.g[j], xx = v.xpx[j];
-                    cs_d[rank] = (gold != 0.0) ? fma(xx, gold, r0i) : r0i;
+                    double thc[K1], ivc[K1], szc[K1];
+#pragma unroll
+                    for (int c = 0; c < K1; c++) {
+                        thc[c] = v.thr[(size_t)c * v.m_pad + j];
+                        ivc[c] = v.invv[(size_t)c * v.m_pad + j];
+                        szc[c] = v.sdz[(size_t)c * v.m_pad + j];
+                    }
+                    int gac = 0, cmc = 0;
+                    if constexpr (G16 || CERT) gac = v.ga[j];
+                    if constexpr (CERT) cmc = v.gcmax[j];
+                    cs_d[rank] = fma(xx, gold, r0i);
                     cs_d[64 + rank] = gold;
 #pragma unroll
                     for (int c = 0; c < K1; c++) {
-                        cs_d[(2 + c) * 64 + rank] = v.thr[(size_t)c * v.m_pad + j];
-                        cs_d[(2 + K1 + c) * 64 + rank] = v.invv[(size_t)c * v.m_pad + j];
-                        cs_d[(2 + 2 * K1 + c) * 64 + rank] = v.sdz[(size_t)c * v.m_pad + j];
+                        cs_d[(2 + c) * 64 + rank] = thc[c];
+                        cs_d[(2 + K1 + c) * 64 + rank] = ivc[c];
+                        cs_d[(2 + 2 * K1 + c) * 64 + rank] = szc[c];
                     }
                     cs_pos[rank] = i * P + t;
-                    if constexpr (G16 || CERT) cs_ga[rank] = v.ga[j];
-                    if constexpr (CERT) cs_cm[rank] = v.gcmax[j];
+                    if constexpr (G16 || CERT) cs_ga[rank] = gac;
+                    if constexpr (CERT) cs_cm[rank] = cmc;
                     rk |= (unsigned long long)rank << (8 * i);
                     inrm |= 1u << i;
                 }
