@@ -28,14 +28,20 @@
 // 3 gather, 4 serial pass, 5 fold + verify, 6 commit + publish, 7 forward, 8 end of group; counters: 10 moves, 11 waited for
 // dots, 12 candidates of the first round, 13 committed rounds, 14 rolled-back rounds; 16 / 17 clock at
 // the group's start / end.
-#define HBG_BEGIN() do { if (v.dbg && t == 0) { for (int z_ = 0; z_ < 32; z_++) v.dbg[(size_t)gcount * 32 + z_] = 0; hbg_tl = clock64(); v.dbg[(size_t)gcount * 32 + 16] = hbg_tl; } } while (0)
-#define HBG_ACC(k) do { if (v.dbg && t == 0) { const long long now_ = clock64(); v.dbg[(size_t)gcount * 32 + (k)] += now_ - hbg_tl; hbg_tl = now_; } } while (0)
-#define HBG_CNT(k, x) do { if (v.dbg && t == 0) v.dbg[(size_t)gcount * 32 + (k)] += (x); } while (0)
-#define HBG_END() do { if (v.dbg && t == 0) v.dbg[(size_t)gcount * 32 + 17] = clock64(); } while (0)
+// The stamps accumulate in LDS (no-return ds_add: a few cycles each) and reach v.dbg once per group: a read-modify-write of global memory per stamp cost
+// ~500 cycles each, twenty times per group — a fifth of what was being measured.
+#define HBG_ADD(k, x) (void)__hip_atomic_fetch_add(&hbg_lds[k], (unsigned long long)(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define HBG_BEGIN() do { if (v.dbg && t == 0) { hbg_tl = clock64(); hbg_t0 = hbg_tl; } } while (0)
+#define HBG_ACC(k) do { if (v.dbg && t == 0) { const long long now_ = clock64(); HBG_ADD(k, now_ - hbg_tl); hbg_tl = now_; } } while (0)
+#define HBG_CNT(k, x) do { if (v.dbg && t == 0) HBG_ADD(k, x); } while (0)
+#define HBG_MARK(k) do { if (v.dbg && t == 0) HBG_ADD(k, clock64() - hbg_tl); } while (0) /* cycles into the current phase */
+#define HBG_END() do { if (v.dbg && t == 0) { hbg_lds[16] = (unsigned long long)hbg_t0; hbg_lds[17] = (unsigned long long)clock64(); \
+        for (int z_ = 0; z_ < 32; z_++) { v.dbg[(size_t)gcount * 32 + z_] = (long long)hbg_lds[z_]; hbg_lds[z_] = 0ull; } } } while (0)
 #else
 #define HBG_BEGIN() do { } while (0)
 #define HBG_ACC(k) do { } while (0)
 #define HBG_CNT(k, x) do { } while (0)
+#define HBG_MARK(k) do { } while (0)
 #define HBG_END() do { } while (0)
 #endif
 // Template shape: HBG_DM = panels per group the register arrays are sized for (>= D), HBG_FW = panels ahead a move is folded into
@@ -110,8 +116,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();
 
-    long long hbg_tl = 0;
-    (void)hbg_tl;
+    long long hbg_tl = 0, hbg_t0 = 0;
+    (void)hbg_tl; (void)hbg_t0;
+#if HB_STAMPS
+    unsigned long long *hbg_lds = reinterpret_cast<unsigned long long *>(misc + 32); // [32]
+    if (t < 32) hbg_lds[t] = 0ull;
+#endif
     int gslot = 0; // ring slot of the group's first panel
     for (int gp0 = pv.p0; ok && gp0 < np; gp0 += D) {
         const int Dg = min(D, np - gp0);
@@ -156,6 +166,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < HBG_DM; i++)
                 bad |= (i < Dg) && (__double_as_longlong(dj[i]) == -1ll || (far_in && __double_as_longlong(fc[i]) == -1ll));
             HBG_CNT(11, bad ? 1 : 0);
+            HBG_MARK(19); // (the opening's values are in registers)
             if (__any(bad)) { // the mat-vec (or k_fwd) has not delivered (all of) this group yet: look again
                 const unsigned long long t0 = wall_clock64();
                 for (unsigned looks = 0;; looks++) {
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     hb_long_wait(looks);
                 }
             }
+            HBG_MARK(20);
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) fc[i] = far_in ? fc[i] : 0.0;
 #pragma unroll
@@ -200,6 +212,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
+        // candidate thresholds of the group's rounds (candf * filter word, as a double)
+        double thc[HBG_DM];
+#pragma unroll
+        for (int i = 0; i < HBG_DM; i++) thc[i] = (fl[i] == -__int_as_float(0x7f800000)) ? -1.0 : pv.candf * (double)fl[i];
         HBG_ACC(0);
         const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP; // block l = 0 of the group's first panel
         const size_t pstep = (size_t)(pv.Lg + 2) * PP;                   // block l of panel p -> block l + 1 of panel p + 1
@@ -217,30 +233,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // ---- (2) the round's candidates, ranked in marker order ----
             unsigned iscm = 0;
             unsigned long long rkp = 0; // rank of marker i * P + t among its wave's candidates of panel i: 8 bits per i
+            int cntv = 0;               // lane i: candidates of panel i in this wave
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) {
-                bool isc = false;
-                if (i < Dg) {
-                    const bool active = fl[i] == fl[i], hot = fl[i] == -__int_as_float(0x7f800000);
-                    isc = (i * P + t) >= pos_lo && active && (hot || ((forced >> i) & 1u) || r0[i] * r0[i] >= pv.candf * (double)fl[i]);
-                }
+                // (thc[]: NaN for a filtered-out marker and for a panel past the group's end — never a candidate, and never forced —, -1 for a
+                // hot one — always)
+                const bool isc = (i * P + t) >= pos_lo && ((((forced >> i) & 1u) != 0u) || r0[i] * r0[i] >= thc[i]);
                 const unsigned long long cm = __ballot(isc);
-                rkp |= (unsigned long long)__popcll(cm & lt) << (8 * i);
+                rkp |= (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u)) << (8 * i);
                 iscm |= isc ? 1u << i : 0u;
-                if (lane == 0) wcnt[i * 8 + wave] = __popcll(cm);
+                cntv = (lane == i) ? __popcll(cm) : cntv;
             }
+            if (lane < HBG_DM) wcnt[lane * 8 + wave] = cntv; // (one write per wave)
             if (t == 0) misc[1] = Dg * P;
             __syncthreads(); // B1
             if (misc[2]) { ok = false; break; }
             int total, myscan;
             {   // exclusive scan of the (panel, wave) counts in every wave: lane = panel * 8 + wave
                 const int cnt = wcnt[lane];
-                int inc = cnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int up = __shfl_up(inc, o, 64);
-                    if (lane >= o) inc += up;
-                }
+                const int inc = wave_scan_incl(cnt);
                 total = __builtin_amdgcn_readlane(inc, 63);
                 myscan = inc - cnt;
             }
@@ -250,22 +261,57 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int ncr = min(total, 64);
             unsigned inrm = 0;
             unsigned long long rk = 0; // rank in the round of marker i * P + t, 8 bits per i (valid where inrm has the bit)
-            // a thread almost never holds more than one candidate: the loop body (the exact per-marker data, one round trip)
-            // exists once, the marker's registers are picked with selects
+            // (2a) the candidates' ranks and positions (a thread almost never holds more than one candidate)
             for (unsigned left = iscm; __any(left != 0u);) {
+                const bool mine = left != 0u;
+                const int i = mine ? __ffs((int)left) - 1 : 0;
+                left &= left - 1u;
+                const int basew = __shfl(myscan, i * 8 + wave, 64); // candidates before this (panel, wave)
+                const int rank = basew + (int)((rkp >> (8 * i)) & 0xffull);
+                if (mine && rank == 64) misc[1] = i * P + t;
+                if (mine && rank < 64) {
+                    cs_pos[rank] = i * P + t;
+                    rk |= (unsigned long long)rank << (8 * i);
+                    inrm |= 1u << i;
+                }
+            }
+            __syncthreads(); // B2
+            HBG_ACC(2);
+            const int pos_hi = misc[1];
+            // (2b) + (3) ONE round trip for both (round 5: they used to be two, the gather's loads issued only after the exact data had come back —
+            // and, above 8 candidates, in two dependent batches): the Gram entries among the round's candidates, cg[k][c] = x_k . x_c for k < c
+            // (zero elsewhere) — every load unconditional on a clamped address, eight per thread at P = 512 —, then the candidates' exact
+            // per-marker data; everything is stored when it has all arrived.
+            int gq[8];
+            const bool wide = P == 512;
+            auto gather_one = [&](int q) {
+                const int idx = t + q * 512, k = idx >> 6, c = idx & 63;
+                const bool valid = k < c && c < ncr; // (k < c < ncr <= 64 implies idx < ncr * 64)
+                const int a = cs_pos[valid ? k : 0], b = cs_pos[valid ? c : 0];
+                const int pa = a >> lgP, ia = a & (P - 1), pb = b >> lgP, ib = b & (P - 1);
+                const size_t off = valid ? ((size_t)pb * (pv.Lg + 1) + (pb - pa)) * PP + (size_t)ia * P + ib : (size_t)t;
+                return gblk0[off];
+            };
+#pragma unroll
+            for (int q = 0; q < 8; q++) gq[q] = 0;
+            if (wide) {
+                gq[0] = gather_one(0); // rows k < 8: all there is up to eight candidates (the usual round)
+                if (ncr > 8) {         // (uniform)
+#pragma unroll
+                    for (int q = 1; q < 8; q++) gq[q] = gather_one(q);
+                }
+            }
+            for (unsigned left = inrm; __any(left != 0u);) {
                 const bool mine = left != 0u;
                 const int i = mine ? __ffs((int)left) - 1 : 0;
                 left &= left - 1u;
                 double r0i = r0[0];
 #pragma unroll
                 for (int x = 1; x < HBG_DM; x++) r0i = (i == x) ? r0[x] : r0i;
-                const int basew = __shfl(myscan, i * 8 + wave, 64); // candidates before this (panel, wave)
-                const int rank = basew + (int)((rkp >> (8 * i)) & 0xffull);
-                if (mine && rank == 64) misc[1] = i * P + t;
-                if (mine && rank < 64) {
-                    // ONE round trip: every load is issued before the first is looked at (round 5: the effect's product with x'x used to sit
-                    // behind "gold != 0", which put the load of x'x a second round trip behind the load of the effect; for an effect of zero
-                    // fma(xx, 0, rhs) is rhs exactly, so the product is taken unconditionally)
+                const int rank = (int)((rk >> (8 * i)) & 0xffull);
+                if (mine) {
+                    // (for an effect of zero fma(xx, 0, rhs) is rhs exactly: the product is taken unconditionally — behind "gold != 0" the load
+                    // of x'x was a second round trip)
                     const size_t j = (size_t)(gp0 + i) * P + t;
                     const double gold = v.g[j], xx = v.xpx[j];
                     double thc[K1], ivc[K1], szc[K1];
@@ -286,29 +332,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         cs_d[(2 + K1 + c) * 64 + rank] = ivc[c];
                         cs_d[(2 + 2 * K1 + c) * 64 + rank] = szc[c];
                     }
-                    cs_pos[rank] = i * P + t;
                     if constexpr (G16 || CERT) cs_ga[rank] = gac;
                     if constexpr (CERT) cs_cm[rank] = cmc;
-                    rk |= (unsigned long long)rank << (8 * i);
-                    inrm |= 1u << i;
                 }
             }
-            __syncthreads(); // B2
-            HBG_ACC(2);
-            const int pos_hi = misc[1];
-            // ---- (3) Gram entries among the round's candidates: cg[k][c] = x_k . x_c for k < c, zero elsewhere ----
-            for (int idx = t; idx < ncr * 64; idx += P) {
-                const int k = idx >> 6, c = idx & 63;
-                int gval = 0;
-                if (k < c && c < ncr) {
-                    const int a = cs_pos[k], b = cs_pos[c];
-                    const int pa = a >> lgP, ia = a & (P - 1), pb = b >> lgP, ib = b & (P - 1);
-                    gval = v.gram[((size_t)(gp0 + pb) * (pv.Lg + 1) + (pb - pa)) * PP + (size_t)ia * P + ib];
+            if (wide) {
+                if (t < ncr * 64) cg[t] = ((t >> 6) < (t & 63) && (t & 63) < ncr) ? gq[0] : 0;
+                if (ncr > 8) {
+#pragma unroll
+                    for (int q = 1; q < 8; q++) {
+                        const int idx = t + q * 512, k = idx >> 6, c = idx & 63;
+                        if (idx < ncr * 64) cg[idx] = (k < c && c < ncr) ? gq[q] : 0;
+                    }
                 }
-                cg[idx] = gval;
+            } else {
+                for (int idx = t; idx < ncr * 64; idx += P) {
+                    const int k = idx >> 6, c = idx & 63;
+                    int gval = 0;
+                    if (k < c && c < ncr) {
+                        const int a = cs_pos[k], b = cs_pos[c];
+                        const int pa = a >> lgP, ia = a & (P - 1), pb = b >> lgP, ib = b & (P - 1);
+                        gval = v.gram[((size_t)(gp0 + pb) * (pv.Lg + 1) + (pb - pa)) * PP + (size_t)ia * P + ib];
+                    }
+                    cg[idx] = gval;
+                }
             }
             __syncthreads(); // B3
             HBG_ACC(3);
+
             // ---- (4) the exact serial chain over the round's candidates: wave 0, one candidate per lane, in marker order ----
             if (wave == 0) {
                 const bool lv = lane < ncr;

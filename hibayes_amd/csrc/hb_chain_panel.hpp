@@ -62,6 +62,19 @@ __device__ __forceinline__ double dpp_row_shr_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// inclusive prefix sum over the 64 lanes of a wave without an LDS round trip per step: four row_shr steps inside the rows of 16, then the row
+// totals handed on by row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3) — the gfx9 wave-wide DPP modes
+__device__ __forceinline__ int wave_scan_incl(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // LDS plan (dynamic, one object): [row cache: nslot x P int32][ev_del: P f64][ev_ix: P i32][slot_of: P i32]
 // [red: 16 f64][cnts: 16 i32][wcnt: 16 i32].
 // The row cache holds the full Gram rows G[k][0..P) of the markers that are certain to move this sweep
