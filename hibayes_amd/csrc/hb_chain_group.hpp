@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < HBG_DM; i++) fl[i] = i < Dg ? fl[i] : __int_as_float(0x7fc00000);
             if constexpr (CERT) { // a LOWER bound of the square root of the (float) threshold: the certificate compares magnitudes, not squares
 #pragma unroll
-                for (int i = 0; i < HBG_DM; i++) sqf[i] = sqrtf(fl[i]) * (1.0f - 4e-7f);
+                for (int i = 0; i < HBG_DM; i++) sqf[i] = __builtin_amdgcn_sqrtf(fl[i]) * (1.0f - 1e-6f); // (v_sqrt_f32: 1 ulp; the correctly rounded root is thirty instructions per marker)
             }
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++)
@@ -231,17 +231,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         double absd_grp = 0.0;
         for (;;) {
             // ---- (2) the round's candidates, ranked in marker order ----
-            unsigned iscm = 0;
+            // (the masks are integers, bit i = marker i * P + t: written with && and || over the eight markers the compiler kept sixteen lane masks
+            // in scalar register pairs across the round — more than there are — and moved them in and out of vector lanes all the way)
             unsigned long long rkp = 0; // rank of marker i * P + t among its wave's candidates of panel i: 8 bits per i
             int cntv = 0;               // lane i: candidates of panel i in this wave
+            const int pl = pos_lo >> lgP; // (< Dg: the loop ends when pos_lo reaches the group's end)
+            const unsigned lom = ((0x1feu << pl) & 0xffu) | ((t >= (pos_lo & (P - 1))) ? 1u << pl : 0u); // marker at or after pos_lo
+            unsigned gem = 0;
+#pragma unroll
+            for (int i = 0; i < HBG_DM; i++) // (thc[]: NaN for a filtered-out marker and for a panel past the group's end — never a candidate, and never forced —, -1 for a hot one — always)
+                gem |= (r0[i] * r0[i] >= thc[i]) ? 1u << i : 0u;
+            const unsigned iscm = (gem | forced) & lom;
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) {
-                // (thc[]: NaN for a filtered-out marker and for a panel past the group's end — never a candidate, and never forced —, -1 for a
-                // hot one — always)
-                const bool isc = (i * P + t) >= pos_lo && ((((forced >> i) & 1u) != 0u) || r0[i] * r0[i] >= thc[i]);
-                const unsigned long long cm = __ballot(isc);
+                const unsigned long long cm = __ballot(((iscm >> i) & 1u) != 0u);
                 rkp |= (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u)) << (8 * i);
-                iscm |= isc ? 1u << i : 0u;
                 cntv = (lane == i) ? __popcll(cm) : cntv;
             }
             if (lane < HBG_DM) wcnt[lane * 8 + wave] = cntv; // (one write per wave)
@@ -460,13 +464,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     unsigned st2 = 0, open = 0, close_by = 0;
 #pragma unroll
                     for (int i = 0; i < HBG_DM; i++) {
-                        if (i < Dg) {
-                            const int pos = i * P + t;
-                            const double b1 = fma(fabs((double)gBi[i]), Amax, fabs(r0[i]) + E);
-                            const bool op = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && b1 >= (double)sqf[i]; // (NaN, the inactive and the hot markers: false)
-                            st2 |= op ? 1u << i : 0u;
-                        }
+                        const double b1 = fma(fabs((double)gBi[i]), Amax, fabs(r0[i]) + E);
+                        st2 |= (b1 >= (double)sqf[i]) ? 1u << i : 0u; // (sqf NaN — the inactive and the hot markers, the panels past the group's end: false)
                     }
+                    st2 &= lom & ~iscm; // (every marker is before pos_hi: the round reaches the group's end)
                     // stage 2: the shift this marker really sees, from the prefix sum at the number of candidates before it
                     for (unsigned left = st2; __any(left != 0u); left &= left - 1u) {
                         const bool mine = left != 0u;
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll 1
             for (int e0 = 0; e0 < nmoves; e0 += HBG_CH) {
                 int gv[HBG_CH][HBG_DM], gf[HBG_CH][HBG_FW];
-                int pae[HBG_CH], iae[HBG_CH], gaf[HBG_CH];
+                int pae[HBG_CH], iae[HBG_CH], gaf[HBG_CH], latm[HBG_CH];
                 double dl[HBG_CH];
 #pragma unroll
                 for (int f = 0; f < HBG_CH; f++) {
@@ -561,6 +562,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     iae[f] = a & (P - 1);
                     dl[f] = (e0 + f < nmoves) ? ev_del[e] : 0.0;
                     gaf[f] = G16 ? __builtin_amdgcn_readfirstlane(ev_ga[e]) : 0;
+                    // bit i: marker (i, t) comes after the mover in the order (an integer mask, used through a one-bit signed field extract: as
+                    // a chain of && and || the compiler built it from scalar branches and sixteen lane masks per trip)
+                    latm[f] = (int)(((0x1feu << pae[f]) & 0xffu) | ((t > iae[f]) ? 1u << pae[f] : 0u));
                 }
 #pragma unroll
                 for (int f = 0; f < HBG_CH; f++) {
@@ -586,10 +590,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int f = 0; f < HBG_CH; f++) {
 #pragma unroll
                     for (int i = 0; i < HBG_DM; i++) {
-                        // marker (i, t) takes the move of (pae, iae) if it comes later in the order
-                        const bool later = i > pae[f] || (i == pae[f] && t > iae[f]);
+                        // marker (i, t) takes the move of (pae, iae) if it comes later in the order: the others add an exact zero (a panel past
+                        // the group's end takes whatever its stand-in row holds — its right-hand side is never looked at)
                         // (G16: G[k][j] = g16[k][j] + ga[k] gB[j], an exact integer — the fold's arithmetic is the int32 band's, bit for bit)
-                        if (i < Dg && later) rnew[i] = fma(-(double)(G16 ? gv[f][i] + gaf[f] * gBi[G16 ? i : 0] : gv[f][i]), dl[f], rnew[i]);
+                        const int gm = (G16 ? gv[f][i] + gaf[f] * gBi[G16 ? i : 0] : gv[f][i]) & __builtin_amdgcn_sbfe(latm[f], i, 1);
+                        rnew[i] = fma(-(double)gm, dl[f], rnew[i]);
                     }
 #pragma unroll
                     for (int x = 0; x < HBG_FW; x++) fw[x] = (x < nfw) ? fma((double)(G16 ? gf[f][x] + gaf[f] * gBf[G16 ? x : 0] : gf[f][x]), dl[f], fw[x]) : fw[x];
@@ -601,13 +606,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bool anyv = false;
             if (need_full) {
 #pragma unroll
-                for (int i = 0; i < HBG_DM; i++) {
-                    if (i < Dg) {
-                        const int pos = i * P + t;
-                        const bool viol = pos >= pos_lo && pos < pos_hi && !((iscm >> i) & 1u) && rnew[i] * rnew[i] >= (double)fl[i]; // (NaN filter: false)
-                        violm |= viol ? 1u << i : 0u;
-                    }
-                }
+                for (int i = 0; i < HBG_DM; i++) violm |= (rnew[i] * rnew[i] >= (double)fl[i]) ? 1u << i : 0u; // (NaN filter, also past the group's end: false)
+                const int ph = pos_hi >> lgP;
+                const unsigned him = ((1u << ph) - 1u) | ((t < (pos_hi & (P - 1))) ? 1u << ph : 0u); // marker before pos_hi
+                violm &= lom & him & ~iscm;
                 {
                     const unsigned long long vm = __ballot(violm != 0u);
                     if (lane == 0) misc[8 + wave] = vm != 0ull;
