@@ -162,9 +162,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int i = 0; i < HBG_DM; i++) sqf[i] = __builtin_amdgcn_sqrtf(fl[i]) * (1.0f - 1e-6f); // (v_sqrt_f32: 1 ulp; the correctly rounded root is thirty instructions per marker)
             }
+            // (the sentinel is a NaN and no delivered word is one: a NaN anywhere shows in the sum — fifteen adds and one compare instead of
+            // sixteen 64-bit compares under scalar masks. A panel past the group's end reads the last panel's words again; without k_fwd's
+            // share fc[] holds the dots a second time: neither needs a mask)
+            {
+                double sdf = dj[0] + fc[0];
 #pragma unroll
-            for (int i = 0; i < HBG_DM; i++)
-                bad |= (i < Dg) && (__double_as_longlong(dj[i]) == -1ll || (far_in && __double_as_longlong(fc[i]) == -1ll));
+                for (int i = 1; i < HBG_DM; i++) sdf += dj[i] + fc[i];
+                bad = sdf != sdf;
+            }
             HBG_CNT(11, bad ? 1 : 0);
             HBG_MARK(19); // (the opening's values are in registers)
             if (__any(bad)) { // the mat-vec (or k_fwd) has not delivered (all of) this group yet: look again
@@ -186,9 +192,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         fc[i] = ld_sc1(&fcp[j]);
                     }
                     }
+                    {
+                        double sdf = dj[0] + fc[0];
 #pragma unroll
-                    for (int i = 0; i < HBG_DM; i++)
-                        bad |= (i < Dg) && (__double_as_longlong(dj[i]) == -1ll || (far_in && __double_as_longlong(fc[i]) == -1ll));
+                        for (int i = 1; i < HBG_DM; i++) sdf += dj[i] + fc[i];
+                        bad = sdf != sdf;
+                    }
                     if (!__any(bad)) break;
                     if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
                         if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); misc[2] = 1; }
@@ -246,7 +255,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < HBG_DM; i++) {
                 const unsigned long long cm = __ballot(((iscm >> i) & 1u) != 0u);
                 rkp |= (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u)) << (8 * i);
-                cntv = (lane == i) ? __popcll(cm) : cntv;
+                {   // lane i takes the count: one v_writelane, no lane mask (this clang has no builtin for it)
+                    const int pc = __builtin_amdgcn_readfirstlane(__popcll(cm));
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(pc), "n"(i));
+                }
             }
             if (lane < HBG_DM) wcnt[lane * 8 + wave] = cntv; // (one write per wave)
             if (t == 0) misc[1] = Dg * P;
