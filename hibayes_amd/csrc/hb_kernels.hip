@@ -74,28 +74,31 @@ __global__ __launch_bounds__(256) void k_sweep_init(double *__restrict__ acc, un
         for (int k = mb_lo + i; k < mb_hi; k += stride) mbs[(size_t)k * HB_MBS] = ~0ull;
 }
 
-__global__ __launch_bounds__(1024) void k_quant0(const double *__restrict__ r, int64_t ld, int8_t *__restrict__ rq,
-                                                 double *__restrict__ mb, int *__restrict__ vexp, const double *__restrict__ force_max)
+// sweep start of the fixed-point path, in two steps that use the whole device (round 5: one workgroup of 1024 took 33 us over n = 50 000 —
+// 49 dependent loads per thread, twice — and k_pre + k_hotlist beside it are done after 30): max |yadj| (exact in any order: the doubles
+// are non-negative, so their bit patterns order like the numbers and one integer atomicMax per wave collects them; *out zeroed before),
+// then the digits of every row on that exponent.
+__global__ __launch_bounds__(256) void k_absmax(const double *__restrict__ r, int64_t ld, unsigned long long *__restrict__ out)
 {
-    __shared__ double red[16];
-    __shared__ double s_max;
-    double mx = force_max ? *force_max : 0.0; // (row-sharded mode: max |yadj| over ALL shards, so that every shard's digits share one exponent)
-    for (int64_t i = threadIdx.x; i < ld && !force_max; i += blockDim.x) mx = fmax(mx, fabs(r[i]));
+    double mx = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ld; i += (int64_t)gridDim.x * blockDim.x) mx = fmax(mx, fabs(r[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double m2 = 0.0;
-        for (int i = 0; i < (int)(blockDim.x >> 6); i++) m2 = fmax(m2, red[i]);
-        s_max = m2;
-        mb[0] = m2;
-        vexp[0] = hb_fix_exp(m2);
-    }
-    __syncthreads();
-    const int E = hb_fix_exp(s_max);
-    for (int64_t row0 = (int64_t)threadIdx.x * 4; row0 < ld; row0 += (int64_t)blockDim.x * 4)
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(mx));
+}
+
+__global__ __launch_bounds__(256) void k_quant0(const double *__restrict__ r, int64_t ld, int8_t *__restrict__ rq, double *__restrict__ mb,
+                                                int *__restrict__ vexp, const double *__restrict__ maxp)
+{
+    // (maxp: the word k_absmax left in mb[0], or — row-sharded mode — max |yadj| over ALL shards, so that every shard's digits share one exponent)
+    const double m2 = *maxp;
+    const int E = hb_fix_exp(m2);
+    for (int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; row0 < ld; row0 += (int64_t)gridDim.x * blockDim.x * 4)
         hb_store_digits(rq, ld, row0, E, r[row0], r[row0 + 1], r[row0 + 2], r[row0 + 3]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (maxp != mb) mb[0] = m2;
+        vexp[0] = E;
+    }
 }
 
 __global__ void k_sum_partials(const double *__restrict__ partial, int pstride, int nsplit, int ncols,
@@ -392,7 +395,10 @@ static void launch_dotq_fin(hb_ctx *c, int col0, int ncols, int gidx, double *ou
 static void launch_quant0(hb_ctx *c, hipStream_t st)
 {
     (void)hipMemsetAsync(c->accq, 0, sizeof(long long) * (size_t)HB_ND * c->m_pad, st);
-    hipLaunchKernelGGL(k_quant0, dim3(1), dim3(1024), 0, st, c->r, c->ld, c->rq, c->mb, c->vexp, (const double *)nullptr);
+    const int qb = (int)std::max<int64_t>(1, std::min<int64_t>(64, (c->ld / 4 + 255) / 256));
+    (void)hipMemsetAsync(c->mb, 0, sizeof(double), st);
+    hipLaunchKernelGGL(k_absmax, dim3(qb), dim3(256), 0, st, c->r, c->ld, reinterpret_cast<unsigned long long *>(c->mb));
+    hipLaunchKernelGGL(k_quant0, dim3(qb), dim3(256), 0, st, c->r, c->ld, c->rq, c->mb, c->vexp, (const double *)c->mb);
     if (c->row_reduce) { // the shards' maxima -> one exponent for all (host round trip: this is the cross-check mode)
         (void)hipStreamSynchronize(st);
         std::vector<double> slot((size_t)std::max(1, c->row_world), 0.0);
@@ -402,7 +408,7 @@ static void launch_quant0(hb_ctx *c, hipStream_t st)
         if (c->row_reduce(c->row_user, slot.data(), slot.size())) { c->row_failed = true; return; }
         for (double v : slot) mxl = std::max(mxl, v);
         (void)hipMemcpy(c->scratch, &mxl, sizeof(double), hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(k_quant0, dim3(1), dim3(1024), 0, st, c->r, c->ld, c->rq, c->mb, c->vexp, (const double *)c->scratch);
+        hipLaunchKernelGGL(k_quant0, dim3(qb), dim3(256), 0, st, c->r, c->ld, c->rq, c->mb, c->vexp, (const double *)c->scratch);
     }
 }
 

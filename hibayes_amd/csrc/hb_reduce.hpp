@@ -11,22 +11,46 @@ __global__ __launch_bounds__(1024) void k_reduce_ru(const double *__restrict__ r
                                                     int n, double *__restrict__ acc)
 {
     __shared__ double red[16];
+    // (eight loads of each array in flight per thread — the plain loop waited for every one of its 49 — and the same additions in the same
+    // order: the sums are bit for bit what they were; 26 -> 8 us at n = 50 000, at the end of every sweep)
     double sr = 0, sr2 = 0, su = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const double a = r[i];
-        sr += a;
-        sr2 = fma(a, a, sr2);
-        su += u[i];
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * (int)blockDim.x) {
+        double a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + k * (int)blockDim.x;
+            a[k] = i < n ? r[i] : 0.0;
+            b[k] = i < n ? u[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (i0 + k * (int)blockDim.x < n) {
+                sr += a[k];
+                sr2 = fma(a[k], a[k], sr2);
+                su += b[k];
+            }
+        }
     }
     sr = block_sum(sr, red);
     sr2 = block_sum(sr2, red);
     su = block_sum(su, red);
     const double mean = su / n;
     double a2 = 0, a3 = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const double d = mean - u[i];
-        a2 = fma(d, d, a2);
-        a3 += d;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * (int)blockDim.x) {
+        double b[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + k * (int)blockDim.x;
+            b[k] = i < n ? u[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (i0 + k * (int)blockDim.x < n) {
+                const double d = mean - b[k];
+                a2 = fma(d, d, a2);
+                a3 += d;
+            }
+        }
     }
     a2 = block_sum(a2, red);
     a3 = block_sum(a3, red);
