@@ -81,7 +81,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned long long lt = (1ull << lane) - 1ull;
 
     double *corr = reinterpret_cast<double *>(smem);            // [R][P]
-    double *cs_d = corr + (size_t)R * P;                        // one round's candidates: rhs, gold, thr[K1], invv[K1], sdz[K1]
+    // CERT: the STAGED opening. What a group's opening needs of its markers that no other workgroup of the sweep writes — candidate threshold, filter
+    // word, gB: 16 bytes per marker, pv.opn, written by k_hotlist — is brought here for the NEXT group by LDS-DMA (no registers: holding the words
+    // in flight in registers spilled 90 of them) by the seven waves that stand at the serial pass's barrier anyway; row D holds NaN records for
+    // the panels past the sweep's end. The opening then asks memory only for the dots and k_fwd's corrections.
+    int4 *nx = reinterpret_cast<int4 *>(corr + (size_t)R * P);  // [D + 1][P]
+    double *cs_d = reinterpret_cast<double *>(nx + (CERT ? (size_t)(D + 1) * P : 0)); // one round's candidates: rhs, gold, thr[K1], invv[K1], sdz[K1]
     double *res_g = cs_d + (2 + 3 * K1) * 64;                   // ... their new effects
     double *ev_del = res_g + 64;                                // the round's moves: change of effect
     double *red = ev_del + 64;                                  // [16]
@@ -122,6 +127,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned long long *hbg_lds = reinterpret_cast<unsigned long long *>(misc + 32); // [32]
     if (t < 32) hbg_lds[t] = 0ull;
 #endif
+    // the records of the group that starts at panel gn0 as 1-KiB pieces (64 markers), dealt over the waves w0 .. S - 1
+    auto stage_next = [&](int gn0, int w0) {
+        const int npc = min(D, np - gn0) * (P >> 6);
+        const char *src = reinterpret_cast<const char *>(pv.opn + (size_t)gn0 * P);
+        const unsigned long long sb = (unsigned long long)(uintptr_t)src;
+        const unsigned dst0 = (unsigned)(uintptr_t)nx;
+        for (int k = __builtin_amdgcn_readfirstlane(wave) - w0; k < npc; k += S - w0) {
+            const unsigned long long a = sb + ((unsigned long long)k << 10);
+            const char *sbase = reinterpret_cast<const char *>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                                                           (unsigned)__builtin_amdgcn_readfirstlane((int)a)));
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(dst0 + ((unsigned)k << 10)));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"((unsigned)lane * 16u), "s"(sbase), "s"(dst) : "memory");
+        }
+    };
+    (void)stage_next;
+    if constexpr (CERT) {
+        nx[(size_t)D * P + t] = make_int4(0, 0x7ff80000, 0x7fc00000, 0); // (threshold NaN, filter word NaN, gB 0)
+        if (pv.p0 < np) stage_next(pv.p0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     int gslot = 0; // ring slot of the group's first panel
     for (int gp0 = pv.p0; ok && gp0 < np; gp0 += D) {
         const int Dg = min(D, np - gp0);
@@ -132,10 +160,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int gBi[(G16 || CERT) ? HBG_DM : 1], gBf[G16 ? HBG_FW : 1]; // gB of this thread's markers in the group (G16, CERT) and in the panels ahead (G16)
         float sqf[CERT ? HBG_DM : 1];                                // CERT: lower bound of sqrt(threshold) of this thread's markers
         (void)gBi; (void)gBf; (void)sqf;
-        if constexpr (G16 || CERT) {
+        if constexpr (G16 && !CERT) {
 #pragma unroll
             for (int i = 0; i < HBG_DM; i++) gBi[i] = v.gB[(size_t)(gp0 + min(i, Dg - 1)) * P + t];
         }
+        double thc[HBG_DM];  // candidate thresholds of the group's rounds (candf * filter word, as a double; hot: -1, filtered out: NaN)
+        bool staged = false; // (uniform) the next group's records have been requested
+        (void)staged;
         if constexpr (G16) {
 #pragma unroll
             for (int x = 0; x < HBG_FW; x++) gBf[x] = v.gB[(size_t)min(gp0 + D + x, np - 1) * P + t];
@@ -153,14 +184,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < HBG_DM; i++) {
                 const size_t j = (size_t)(gp0 + min(i, Dg - 1)) * P + t;
                 dj[i] = ld_sc1(&v.dsum[j]);
-                fl[i] = pv.thr0f[j];
+                if constexpr (!CERT) fl[i] = pv.thr0f[j];
                 fc[i] = ld_sc1(&fcp[j]);
             }
+            if constexpr (CERT) { // (the staged records: read while the loads above fly)
 #pragma unroll
-            for (int i = 0; i < HBG_DM; i++) fl[i] = i < Dg ? fl[i] : __int_as_float(0x7fc00000);
-            if constexpr (CERT) { // a LOWER bound of the square root of the (float) threshold: the certificate compares magnitudes, not squares
+                for (int i = 0; i < HBG_DM; i++) {
+                    const int4 rec = nx[(size_t)(i < Dg ? i : D) * P + t]; // (scalar row select: a panel past the group's end reads the NaN row)
+                    thc[i] = __hiloint2double(rec.y, rec.x);
+                    fl[i] = __int_as_float(rec.z);
+                    gBi[i] = rec.w;
+                    // a LOWER bound of the square root of the (float) threshold: the certificate compares magnitudes, not squares (v_sqrt_f32: 1 ulp;
+                    // the correctly rounded root is thirty instructions per marker)
+                    sqf[i] = __builtin_amdgcn_sqrtf(fl[i]) * (1.0f - 1e-6f);
+                }
+            } else {
 #pragma unroll
-                for (int i = 0; i < HBG_DM; i++) sqf[i] = __builtin_amdgcn_sqrtf(fl[i]) * (1.0f - 1e-6f); // (v_sqrt_f32: 1 ulp; the correctly rounded root is thirty instructions per marker)
+                for (int i = 0; i < HBG_DM; i++) fl[i] = i < Dg ? fl[i] : __int_as_float(0x7fc00000);
+#pragma unroll
+                for (int i = 0; i < HBG_DM; i++) thc[i] = (fl[i] == -__int_as_float(0x7f800000)) ? -1.0 : pv.candf * (double)fl[i];
             }
             // (the sentinel is a NaN and no delivered word is one: a NaN anywhere shows in the sum — fifteen adds and one compare instead of
             // sixteen 64-bit compares under scalar masks. A panel past the group's end reads the last panel's words again; without k_fwd's
@@ -221,10 +263,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        // candidate thresholds of the group's rounds (candf * filter word, as a double)
-        double thc[HBG_DM];
-#pragma unroll
-        for (int i = 0; i < HBG_DM; i++) thc[i] = (fl[i] == -__int_as_float(0x7f800000)) ? -1.0 : pv.candf * (double)fl[i];
         HBG_ACC(0);
         const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP; // block l = 0 of the group's first panel
         const size_t pstep = (size_t)(pv.Lg + 2) * PP;                   // block l of panel p -> block l + 1 of panel p + 1
@@ -375,6 +413,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             __syncthreads(); // B3
             HBG_ACC(3);
+            bool stage_wait = false; // (per wave) this wave has pieces in flight
+            if constexpr (CERT) {    // (the next group's records: by the waves that would otherwise stand at B4 while wave 0 walks the serial chain)
+                if (!staged) {
+                    if (wave != 0 && gp0 + D < np) { stage_next(gp0 + D, 1); stage_wait = true; }
+                    staged = true;
+                }
+            }
 
             // ---- (4) the exact serial chain over the round's candidates: wave 0, one candidate per lane, in marker order ----
             if (wave == 0) {
@@ -462,6 +507,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (lane < ncr) spre[lane + 1] = w;
                     if (lane == 0) { spre[0] = 0.0; spre[66] = e; spre[67] = am; }
                 }
+            }
+            if constexpr (CERT) {
+                if (stage_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the pieces have landed: these waves had nothing else to do)
             }
             __syncthreads(); // B4
             HBG_ACC(4);
@@ -703,6 +751,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (pos_lo >= Dg * P) break;
         }
         if (!ok) break;
+        if constexpr (CERT) { // (a group without a single candidate never got to its serial pass)
+            if (!staged) {
+                if (gp0 + D < np) stage_next(gp0 + D, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
         // ---- end of the group: counts, bound on max |yadj|, chain_done (the update rows of this group wait for it) ----
         if (wave == S - 1) {
             if (lane < Dg) {

@@ -21,6 +21,7 @@ struct persist_view {
     const float *thr0f;                  // ... and the opening filter
     double candf;                        // a marker at zero is a chain candidate when q >= candf * thr0 (candf <= 1)
     double *fcorr;                       // k_fwd's corrections (null: the chain folds all Lv D panels ahead itself)
+    const int4 *opn;                     // k_chain_group, certified shape: the staged opening's records (hb_ctx.opn); null: the opening loads and computes its own
 };
 
 #define HB_LBMAX 20
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(512) void k_hotlist(const hb_sweep_in *__restrict__
                                                  const double *__restrict__ g, const double *__restrict__ thr0,
                                                  const double *__restrict__ xpx, double kappa, int P, int nslot,
                                                  int *__restrict__ slot_of, int *__restrict__ hotpack, float *__restrict__ thr0f,
-                                                 uint8_t *__restrict__ tracker)
+                                                 uint8_t *__restrict__ tracker, int4 *__restrict__ opn = nullptr,
+                                                 const int32_t *__restrict__ gB = nullptr, double candf = 1.0)
 {
     __shared__ int wcnt[16];
     const int p = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63, S = P >> 6;
@@ -108,6 +110,10 @@ __global__ __launch_bounds__(512) void k_hotlist(const hb_sweep_in *__restrict__
             if ((double)f > th) f = nextafterf(f, -__int_as_float(0x7f800000));
         }
         thr0f[j] = f;
+        if (opn) { // the group chain's staged opening: the candidate threshold as it compares it (hot: -1, always; filtered out: NaN, never), the filter word, gB
+            const double thc = (f == -__int_as_float(0x7f800000)) ? -1.0 : candf * (double)f;
+            opn[j] = make_int4(__double2loint(thc), __double2hiint(thc), __float_as_int(f), gB ? gB[j] : 0);
+        }
     }
     const unsigned long long hmask = __ballot(hot);
     if (lane == 0) wcnt[wave] = __popcll(hmask);

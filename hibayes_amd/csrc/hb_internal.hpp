@@ -58,6 +58,7 @@ struct hb_ctx {
     unsigned int *h_flags = nullptr;
     int *hot_slot = nullptr, *hot_list = nullptr, *hot_n = nullptr; // per-sweep row-cache lists (k_hotlist): hot_list is packed, 256 ints per panel
     float *thr0f = nullptr;                                          // per-sweep opening filter of the chain (k_hotlist)
+    int4 *opn = nullptr;                                             // per-sweep, 16 bytes per marker: {candidate threshold (double), opening filter (float), gB}: what k_chain_group's opening needs that no other workgroup of the sweep writes — staged in its LDS a group ahead (k_hotlist writes it)
     int64_t ld = 0; // bytes per genotype column on device (multiple of 256)
     int precise = 0;
     int64_t m_offset = 0;

@@ -662,7 +662,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     const int ns = std::max(0, persist_nslot(c->P, std::min(c->L, HB_LBMAX), kp));
     // (the hot lists are rebuilt for every range: they hold the effects as they are when the range starts)
     hipLaunchKernelGGL(k_hotlist, dim3(c->npanels), dim3(c->P), 0, sA, c->d_in, c->vx, c->g, c->thr, c->xpx, c->kappa, c->P, ns, c->hot_slot,
-                       c->hot_list, c->thr0f, c->tracker);
+                       c->hot_list, c->thr0f, c->tracker, (c->gcert_ok && c->gB) ? c->opn : nullptr, c->gB, c->candf);
     if (fx) HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[1 % c->npanels], 0));
     HB_HIP(hipEventRecord(c->ev_fork, sA));
     HB_HIP(hipStreamWaitEvent(sB, c->ev_fork, 0));
@@ -676,7 +676,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     if (cert) { cv.ga = c->ga; cv.gB = c->gB; cv.gcmax = c->gcmax; }
     const int last_panels = np - (g0 + ngroups - 1) * D;
     persist_view pv{np, D, Lv, c->L, c->Lg, pb, c->flags,
-                    c->hot_slot, c->hot_list, c->thr0f, c->candf, nullptr};
+                    c->hot_slot, c->hot_list, c->thr0f, c->candf, nullptr, nullptr};
+    if (cert) pv.opn = c->opn; // (k_hotlist wrote it: gcert_ok)
     // HB_CHAIN_ALONE=1 / hb_ctx_set_profiling(c, 4) — a TIMING AND COUNTER DIAGNOSTIC, results are meaningless (it needs no
     // co-resident kernels, so it is also how k_chain_persist runs under a counter-collecting profiler, tools/chain_counters.py): the mat-vec launches run first against a pre-set
     // chain_done (their update rows find empty event lists), the chain afterwards with the device to itself; the stamped span
