@@ -752,6 +752,13 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         warm_r = 4;
         if (const char *e = getenv("HB_WARM_R")) warm_r = std::max(0, std::min(16, atoi(e)));
     }
+    // the wide group chain with k_fwd beside it (BayesB / BayesC, the headline): warmers on the same fourth stream — the listed markers' Gram rows
+    // for the chain's share of the band (its own group and the next: 2 D - 1 blocks) and the panels' exact per-marker data (HB_WARM_G: workgroups
+    // per XCD, 0 = off)
+    if (fwd && c->s_warm && warm_r == 0) {
+        warm_r = c->warm_g;
+        if (const char *e = getenv("HB_WARM_G")) warm_r = std::max(0, std::min(16, atoi(e)));
+    }
     if (dense) { // (Lb + 1 target panels are open at any time: Lb ahead for their band, the chain's own for its far sub-blocks)
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         hipLaunchKernelGGL(k_fold_dense, dim3(8 * (c->L + 1)), dim3(256), 0, c->s_upd, cv, pv, c->ddense, c->fcorr2, c->L + 1);
@@ -792,10 +799,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     }
     if (warm_r) {
         HB_HIP(hipStreamWaitEvent(c->s_warm, c->ev_fork, 0));
-        int ahead = 2; // (measured, BayesR at n = 50k, m = 500k: off 48.3 sweeps/s, 2 panels ahead 51.2, 4 ahead 50.5, 8 ahead 50.0)
+        int ahead = fwd ? 2 * D : 2; // (measured, BayesR at n = 50k, m = 500k: off 48.3 sweeps/s, 2 panels ahead 51.2, 4 ahead 50.5, 8 ahead 50.0)
         if (const char *e = getenv("HB_WARM_AHEAD")) ahead = std::max(1, atoi(e));
         persist_view pw = pv;
-        pw.Lb = 1; // (the chain folds into the next panel only)
+        pw.Lb = fwd ? 2 * D - 1 : 1; // (BayesR: the chain folds into the next panel only; the group chain: into its own group's later panels and the next group's)
         hipLaunchKernelGGL(k_warm, dim3(8 * warm_r), dim3(256), 0, c->s_warm, pw, cv, kp, c->gram, c->P, ahead, warm_r, reinterpret_cast<int *>(c->flags + 48));
         HB_HIP(hipGetLastError());
     }

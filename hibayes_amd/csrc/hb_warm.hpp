@@ -82,6 +82,8 @@ __global__ __launch_bounds__(256) void k_warm(persist_view pv, chain_view v, int
                 }
             }
             for (int i = t * 4; i < P; i += 1024) acc += reinterpret_cast<const int4 *>(pv.slot_of + j0 + i)->x;
+            if (v.ga && v.gcmax) // (the certified group chain's candidates fetch these with the rest)
+                for (int i = t * 4; i < P; i += 1024) acc += reinterpret_cast<const int4 *>(v.ga + j0 + i)->x ^ reinterpret_cast<const int4 *>(v.gcmax + j0 + i)->x;
         }
         const int *hl = pv.hotpack + (size_t)q * HB_HS;
         const int cnt = max(hl[0], hl[1]); // (with and without a slot in the row cache)
