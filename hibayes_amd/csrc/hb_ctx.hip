@@ -247,6 +247,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     TRY(dev_alloc(&c->hot_list, (size_t)(c->npanels + 1) * 256));
     TRY(dev_alloc(&c->thr0f, mp + 1024));
     TRY(dev_alloc(&c->opn, mp + 1024));
+    TRY(dev_alloc(&c->ru_ws, (size_t)128));
     TRY(dev_alloc(&c->hot_n, (size_t)c->npanels));
     if (getenv("HB_DEBUG_ABORT")) {
         TRY(dev_alloc(&c->ldiag, ((size_t)c->npanels + 2) * 4));
@@ -313,7 +314,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->s_dbg) (void)hipStreamDestroy(c->s_dbg);
     void *ptrs[] = {c->X, c->X2, c->xpx, c->vx, c->s1, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->fcorr, c->ddense, c->fcorr2, c->dots, c->ev_count, c->ev_idx,
-                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->gram16, c->ga, c->gB, c->gcmax, c->g16_flag, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->opn, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa, c->snap, c->ldiag};
+                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->gram16, c->ga, c->gB, c->gcmax, c->g16_flag, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->opn, c->ru_ws, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa, c->snap, c->ldiag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     blocks_free(c);

@@ -147,6 +147,7 @@ struct hb_ctx {
     int blk_n = 0;
     std::vector<double> blk_cpc; // C_i . C_i
     double *scratch = nullptr; // small device scratch (>= 4096 doubles)
+    double *ru_ws = nullptr;   // k_reduce_ru's partial sums and tickets (128 doubles, zero at rest)
     long long *dbg = nullptr;  // optional chain-kernel cycle stamps, 32 per panel
     // optional (hb_ctx_set_profiling bit 3): start / end of every block of every mat-vec launch of the last sweep on the
     // constant 100 MHz clock, [launch][HB_LSTAMP_BLOCKS][2]; lstamp_nblk[launch] = blocks the launch had (0: not launched)

@@ -7,58 +7,103 @@
 // end-of-sweep reductions behind src/Bayes.cpp:819 (var(u), N-1, two-pass like arma::var) and
 // :823 (yadj.yadj); also sum(yadj) for the next intercept draw (:480). One workgroup.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_reduce_ru(const double *__restrict__ r, const double *__restrict__ u,
-                                                    int n, double *__restrict__ acc)
+// Sixteen workgroups of one wave instead of one workgroup of sixteen (round 5: one compute unit draws ~45 GB/s from HBM, and the sums run at the end of
+// every sweep with nothing beside them: 25 us at n = 50 000), with the SAME numbers bit for bit: thread (b, lane) adds the elements b * 64 + lane,
+// + 1024, + 2048 ... in that order, as thread b * 64 + lane of the one workgroup did; a wave's 64 partial sums are folded by the same shuffles;
+// the sixteen wave sums are added in wave order by the workgroup that arrives last (a ticket), which also publishes the mean for the second
+// pass — the others wait for it (sixteen waves are always resident together) — and, after the second pass, resets the tickets.
+// ws: [0..15] sum r, [16..31] sum r^2, [32..47] sum u (then: sum d^2), [48..63] sum d, [64] mean; counters at ws + 80 (three unsigned, zero at rest).
+__global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, const double *__restrict__ u, int n, double *__restrict__ acc,
+                                                  double *__restrict__ ws)
 {
-    __shared__ double red[16];
-    // (eight loads of each array in flight per thread — the plain loop waited for every one of its 49 — and the same additions in the same
-    // order: the sums are bit for bit what they were. It stayed at 25 us at n = 50 000 — one compute unit draws ~45 GB/s from HBM whatever it keeps in
-    // flight; the same per-thread sums spread over sixteen workgroups and one final tree would be the same numbers at a tenth of the time)
+    const int lane = threadIdx.x, b = blockIdx.x, nb = gridDim.x, stride = nb * 64;
+    unsigned *cnt = reinterpret_cast<unsigned *>(ws + 80);
     double sr = 0, sr2 = 0, su = 0;
-    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * (int)blockDim.x) {
-        double a[8], b[8];
+    for (int i0 = b * 64 + lane; i0 < n; i0 += 8 * stride) {
+        double av[8], bv[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int i = i0 + k * (int)blockDim.x;
-            a[k] = i < n ? r[i] : 0.0;
-            b[k] = i < n ? u[i] : 0.0;
+            const int i = i0 + k * stride;
+            av[k] = i < n ? r[i] : 0.0;
+            bv[k] = i < n ? u[i] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            if (i0 + k * (int)blockDim.x < n) {
-                sr += a[k];
-                sr2 = fma(a[k], a[k], sr2);
-                su += b[k];
+            if (i0 + k * stride < n) {
+                sr += av[k];
+                sr2 = fma(av[k], av[k], sr2);
+                su += bv[k];
             }
         }
     }
-    sr = block_sum(sr, red);
-    sr2 = block_sum(sr2, red);
-    su = block_sum(su, red);
-    const double mean = su / n;
+    sr = wave_sum(sr);
+    sr2 = wave_sum(sr2);
+    su = wave_sum(su);
+    __shared__ int s_last;
+    if (lane == 0) {
+        __hip_atomic_store(&ws[b], sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws[16 + b], sr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws[32 + b], su, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicAdd(&cnt[0], 1u) == (unsigned)nb - 1u;
+    }
+    __syncthreads();
+    if (s_last) {
+        if (lane == 0) {
+            __threadfence();
+            double t0 = 0, t1 = 0, t2 = 0;
+            for (int i = 0; i < nb; i++) {
+                t0 += __hip_atomic_load(&ws[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t1 += __hip_atomic_load(&ws[16 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t2 += __hip_atomic_load(&ws[32 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            acc[HB_ACC_SUMR] = t0;
+            acc[HB_ACC_SUMR2] = t1;
+            __hip_atomic_store(&ws[64], t2 / n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            __hip_atomic_store(&cnt[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (lane == 0) {
+        while (__hip_atomic_load(&cnt[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    const double mean = __hip_atomic_load(&ws[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double a2 = 0, a3 = 0;
-    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * (int)blockDim.x) {
-        double b[8];
+    for (int i0 = b * 64 + lane; i0 < n; i0 += 8 * stride) {
+        double bv[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int i = i0 + k * (int)blockDim.x;
-            b[k] = i < n ? u[i] : 0.0;
+            const int i = i0 + k * stride;
+            bv[k] = i < n ? u[i] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            if (i0 + k * (int)blockDim.x < n) {
-                const double d = mean - b[k];
+            if (i0 + k * stride < n) {
+                const double d = mean - bv[k];
                 a2 = fma(d, d, a2);
                 a3 += d;
             }
         }
     }
-    a2 = block_sum(a2, red);
-    a3 = block_sum(a3, red);
-    if (threadIdx.x == 0) {
-        acc[HB_ACC_SUMR] = sr;
-        acc[HB_ACC_SUMR2] = sr2;
-        acc[HB_ACC_VARU] = n > 1 ? (a2 - a3 * a3 / n) / (n - 1) : 0.0;
+    a2 = wave_sum(a2);
+    a3 = wave_sum(a3);
+    if (lane == 0) {
+        __hip_atomic_store(&ws[32 + b], a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws[48 + b], a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        if (atomicAdd(&cnt[2], 1u) == (unsigned)nb - 1u) { // (everybody has read the mean and left its sums: the last one closes)
+            __threadfence();
+            double t2 = 0, t3 = 0;
+            for (int i = 0; i < nb; i++) {
+                t2 += __hip_atomic_load(&ws[32 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t3 += __hip_atomic_load(&ws[48 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            acc[HB_ACC_VARU] = n > 1 ? (t2 - t3 * t3 / n) / (n - 1) : 0.0;
+            cnt[0] = 0u;
+            cnt[1] = 0u;
+            cnt[2] = 0u;
+        }
     }
 }
 
