@@ -8,7 +8,7 @@
 // :823 (yadj.yadj); also sum(yadj) for the next intercept draw (:480). One workgroup.
 // ---------------------------------------------------------------------------------------------
 // Sixteen workgroups of one wave instead of one workgroup of sixteen (round 5: one compute unit draws ~45 GB/s from HBM, and the sums run at the end of
-// every sweep with nothing beside them: 25 us at n = 50 000), with the SAME numbers bit for bit: thread (b, lane) adds the elements b * 64 + lane,
+// every sweep with nothing beside them: 25 us at n = 50 000, 14 now — the rest is the hand-overs below), with the SAME numbers bit for bit: thread (b, lane) adds the elements b * 64 + lane,
 // + 1024, + 2048 ... in that order, as thread b * 64 + lane of the one workgroup did; a wave's 64 partial sums are folded by the same shuffles;
 // the sixteen wave sums are added in wave order by the workgroup that arrives last (a ticket), which also publishes the mean for the second
 // pass — the others wait for it (sixteen waves are always resident together) — and, after the second pass, resets the tickets.
@@ -19,16 +19,18 @@ __global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, 
     const int lane = threadIdx.x, b = blockIdx.x, nb = gridDim.x, stride = nb * 64;
     unsigned *cnt = reinterpret_cast<unsigned *>(ws + 80);
     double sr = 0, sr2 = 0, su = 0;
-    for (int i0 = b * 64 + lane; i0 < n; i0 += 8 * stride) {
-        double av[8], bv[8];
+    // (a pass is a chain of dependent memory round trips, ~1 us each: 28 elements of both arrays in flight per thread make it two at n = 50 000)
+    constexpr int B1 = 28, B2 = 56;
+    for (int i0 = b * 64 + lane; i0 < n; i0 += B1 * stride) {
+        double av[B1], bv[B1];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < B1; k++) {
             const int i = i0 + k * stride;
             av[k] = i < n ? r[i] : 0.0;
             bv[k] = i < n ? u[i] : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < B1; k++) {
             if (i0 + k * stride < n) {
                 sr += av[k];
                 sr2 = fma(av[k], av[k], sr2);
@@ -48,15 +50,19 @@ __global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, 
         s_last = atomicAdd(&cnt[0], 1u) == (unsigned)nb - 1u;
     }
     __syncthreads();
-    if (s_last) {
+    if (s_last) { // (the whole wave: lane i fetches wave i's sums — one round trip, not forty-eight —, lane 0 adds them in wave order)
+        __threadfence();
+        const int li = min(lane, nb - 1);
+        const double v0 = __hip_atomic_load(&ws[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double v1 = __hip_atomic_load(&ws[16 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double v2 = __hip_atomic_load(&ws[32 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int i = 0; i < nb; i++) {
+            t0 += readlane_f64(v0, i);
+            t1 += readlane_f64(v1, i);
+            t2 += readlane_f64(v2, i);
+        }
         if (lane == 0) {
-            __threadfence();
-            double t0 = 0, t1 = 0, t2 = 0;
-            for (int i = 0; i < nb; i++) {
-                t0 += __hip_atomic_load(&ws[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                t1 += __hip_atomic_load(&ws[16 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                t2 += __hip_atomic_load(&ws[32 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             acc[HB_ACC_SUMR] = t0;
             acc[HB_ACC_SUMR2] = t1;
             __hip_atomic_store(&ws[64], t2 / n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -70,15 +76,15 @@ __global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, 
     __syncthreads();
     const double mean = __hip_atomic_load(&ws[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double a2 = 0, a3 = 0;
-    for (int i0 = b * 64 + lane; i0 < n; i0 += 8 * stride) {
-        double bv[8];
+    for (int i0 = b * 64 + lane; i0 < n; i0 += B2 * stride) {
+        double bv[B2];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < B2; k++) {
             const int i = i0 + k * stride;
             bv[k] = i < n ? u[i] : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < B2; k++) {
             if (i0 + k * stride < n) {
                 const double d = mean - bv[k];
                 a2 = fma(d, d, a2);
@@ -88,17 +94,25 @@ __global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, 
     }
     a2 = wave_sum(a2);
     a3 = wave_sum(a3);
+    __syncthreads(); // (s_last is rewritten: everybody has read it)
     if (lane == 0) {
         __hip_atomic_store(&ws[32 + b], a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ws[48 + b], a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
-        if (atomicAdd(&cnt[2], 1u) == (unsigned)nb - 1u) { // (everybody has read the mean and left its sums: the last one closes)
-            __threadfence();
-            double t2 = 0, t3 = 0;
-            for (int i = 0; i < nb; i++) {
-                t2 += __hip_atomic_load(&ws[32 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                t3 += __hip_atomic_load(&ws[48 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        s_last = atomicAdd(&cnt[2], 1u) == (unsigned)nb - 1u; // (everybody has read the mean and left its sums: the last one closes)
+    }
+    __syncthreads();
+    if (s_last) {
+        __threadfence();
+        const int li = min(lane, nb - 1);
+        const double v2 = __hip_atomic_load(&ws[32 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double v3 = __hip_atomic_load(&ws[48 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double t2 = 0, t3 = 0;
+        for (int i = 0; i < nb; i++) {
+            t2 += readlane_f64(v2, i);
+            t3 += readlane_f64(v3, i);
+        }
+        if (lane == 0) {
             acc[HB_ACC_VARU] = n > 1 ? (t2 - t3 * t3 / n) / (n - 1) : 0.0;
             cnt[0] = 0u;
             cnt[1] = 0u;
