@@ -40,9 +40,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--burnin", type=int, default=300,
+    ap.add_argument("--burnin", type=int, default=400,
                     help="MCMC burn-in sweeps run as part of the set-up, before the warm-up steps: the chain starts with ~5 %% of the "
-                         "markers in the model and needs a few hundred sweeps to reach the regime a 20 000-iteration run spends its time in")
+                         "markers in the model and needs a few hundred sweeps to reach the regime a 20 000-iteration run spends its time in (round 5: 400, "
+                         "not 300 — the markers changed per sweep still fall from 950 to 770 between sweep 300 and 450, and with --warmup 5 the timed "
+                         "sweeps sat on that slope)")
     ap.add_argument("--burnin-secondary", type=int, default=300)
     ap.add_argument("--burnin-converged", type=int, default=2500,
                     help="the secondary model (BayesR) is measured twice: after --burnin-secondary sweeps (the chain has not found the signal "

@@ -210,7 +210,7 @@ def test_config3_bayesr_n50k_m500k_draw_for_draw_against_live_oracle(c3):
 @pytest.mark.parametrize("model,Pi,fold,geo,bits,sweeps", [("BayesCpi", [0.95, 0.05], None, (1, 3, 7), 2, 300),
                                                            ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 8, 150)])
 def test_config3_stationary_state_against_live_oracle(c3, model, Pi, fold, geo, bits, sweeps):
-    """n = 50k, m = 500k IN the regime `value` is measured in: 300 sweeps of burn-in on the GPU (bench.py's own --burnin; BayesR 150),
+    """n = 50k, m = 500k IN the regime `value` is measured in: 300 sweeps of burn-in on the GPU (bench.py's --burnin until the last run of round 5, 400 since; BayesR 150),
     then 2 sweeps on both sides from the reported state."""
     _full_size_vs_oracle(50000, 500000, model, Pi, fold, geo, 0, niter=2, shared=c3, bits=bits, adaptive=(bits == 2), stationary=sweeps)
 
