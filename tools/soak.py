@@ -7,8 +7,9 @@ import hibayes_amd as H
 from hibayes_amd._lib import check, BayesArgs, RunInfo, BayesOut
 import bench
 
-def run(n, m, model, niter, nburn, seed=20240901):
+def run(n, m, model, niter, nburn, seed=20240901, bits=8):
     c = H.Context(n, m); c.set_pipeline(*bench.PIPELINE.get(model, (1, 1, 1))); c.generate(seed, 1000)
+    if bits == 2: c.build_gram(); c.set_layout(2, keep_int8=False)  # (the headline's layout: k_dotq2m beside the certified group chain)
     y = bench.synth_phenotype(c, n, m, 0, m, seed, None, model)
     Pi, fold = bench.prior(model)
     a = BayesArgs(); a.n, a.m = n, m; yv = np.ascontiguousarray(y); a.y = yv.ctypes.data; a.model = model.encode()
@@ -49,6 +50,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "dense":  # the models in which every ma
             print("  FAILED %s n=%d m=%d: %s" % (model, n, m, e), flush=True)
     print("dense soak: %d of %d runs failed; %d sweeps completed, %d of them replayed after a device time-out" % (nfail, len(cases), ntot, nrep), flush=True)
     sys.exit(1 if nfail else 0)
+elif len(sys.argv) > 1 and sys.argv[1] == "cpi":  # soak.py cpi [sweeps]: the headline — BayesCpi at config-3 size on the 2-bit layout (k_chain_group certified + k_fwd + k_dotq2m)
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 8000
+    rep = run(50000, 500000, "BayesCpi", k, min(500, k // 2), bits=2)
+    print("BayesCpi soak (2-bit): %d sweeps completed, %d of them replayed after a device time-out" % (k, rep), flush=True)
 elif len(sys.argv) > 1 and sys.argv[1] == "bayesr":  # soak.py bayesr [sweeps]: config 3's model on its own (k_chain_persist + k_fwd + k_warm)
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
     rep = run(50000, 500000, "BayesR", k, min(500, k // 2))
