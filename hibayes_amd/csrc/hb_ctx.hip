@@ -128,6 +128,10 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     HB_HIP(hipSetDevice(p->device));
     hb_ctx *c = new hb_ctx();
     c->device = p->device;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && ncu > 0) c->num_cus = ncu;
+    }
     c->n = p->n;
     c->m = p->m;
     c->P = P;

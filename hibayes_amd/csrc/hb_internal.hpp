@@ -49,6 +49,7 @@ struct hb_ctx {
     int NB = 1;    // residual versions kept = Lv + D
     int pipeline = 0;              // 0: serial kernels per panel; 1: persistent chain workgroup + flags
     int chain_kind = 1;            // group-granular chain (k_chain_group): bit 0 BayesB/C, bit 1 the dense models at one panel per group; 0 = k_chain_persist everywhere (HB_CHAIN=panel / all / <bits>)
+    int num_cus = 256;             // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     bool warm_group = false;       // k_warm beside the group chain (HB_WARM_GROUP=1)
     int warm_g = 0;                // k_warm workgroups per XCD beside the wide group chain with k_fwd (HB_WARM_G)
     bool dense_chain = true;       // BayesRR / A / L at panel 512: k_chain_dense + k_fold_dense (hb_chain_dense.hpp; HB_DENSE=0: k_chain_persist)

@@ -263,9 +263,24 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     int ns = std::max(1, std::min(std::max(1, nst / 4), (int)((double)(mfma && !getenv("HB_DOTQ2_TILES") ? ((q2m_g == 0 || q2m_g == 3) ? 900 : 800) : c->dotq2_tiles) / ncg + 0.5)));
     // (int32 accumulators of genotypes scaled by up to 32 — Q2_SCALED, k_dotq2m: rows x 96 x 128 < 2^31 bounds a tile at 174 000 individuals)
     ns = std::max(ns, (int)(((int64_t)nst * RS + 131071) / 131072));
-    const int NS = (nst + ns - 1) / ns, nsplit = (nst + NS - 1) / NS;
     upd_view uq{};
     if (upd) uq = *upd;
+    const int nupd_blk = (uq.p1 > uq.p0) ? (int)(c->ld / (uq.dense ? 64 : 256)) : 0, nfin_blk = fin_ncols > 0 ? (fin_ncols + 63) / 64 : 0;
+    if (mfma && (q2m_g == 0 || q2m_g == 3) && !getenv("HB_DOTQ2_TILES")) {
+        // ALL blocks of the launch resident at once (round 5, the last measurement of the round). A block of this kernel holds 37 KB of LDS: four per
+        // compute unit, 128 per XCD — less the chain workgroup's compute unit and k_fwd's share of another, which sit on ONE XCD — and the
+        // dispatcher deals the blocks round-robin over the eight XCDs whatever they have free. 784 tiles + 196 update + 56 finalize blocks = 1 036
+        // is 130 per XCD: the XCD with the chain started its last nine tiles when its first ones ended, 8.4 us into a 9-us launch, and the launch
+        // took 14.6 us in situ (tools/launch_roles.py). Fewer, longer tiles until the fullest XCD's share fits its slots: 12.6 us, 433 -> 454 sweeps/s.
+        const int lds = q2m_g == 3 ? q2m512_lds<true>() : q2m512_lds<false>();
+        const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, lds)));
+        const int cus_per_xcd = std::max(1, c->num_cus / 8);
+        const int budget = 8 * (cus_per_xcd * per_cu - (per_cu + 3)); // (the fullest XCD gets ceil(blocks / 8))
+        auto total = [&](int k) { const int NSk = (nst + k - 1) / k; return nupd_blk + nfin_blk + ncg * ((nst + NSk - 1) / NSk); };
+        const int ns_min = std::max(1, (int)(((int64_t)nst * RS + 131071) / 131072));
+        while (ns > ns_min && total(ns) > budget) ns--;
+    }
+    const int NS = (nst + ns - 1) / ns, nsplit = (nst + NS - 1) / NS;
     dq_view v{};
     v.X = nullptr;
     v.X2 = reinterpret_cast<const uint8_t *>(c->X2) + (int64_t)col0 * c->ld2;
@@ -279,8 +294,8 @@ static void launch_dotq2(hb_ctx *c, int col0, int ncols, int slot, hipStream_t s
     v.nstages = nst;
     v.NS = NS;
     v.ncg = ncg;
-    v.nupd = (uq.p1 > uq.p0) ? (int)(c->ld / (uq.dense ? 64 : 256)) : 0;
-    v.nfin = fin_ncols > 0 ? (fin_ncols + 63) / 64 : 0;
+    v.nupd = nupd_blk;
+    v.nfin = nfin_blk;
     v.fin_acc = c->accq + fin_col0;
     v.fin_out = c->dsum + fin_col0;
     v.fin_exp = c->gexp + fin_gidx;

@@ -56,6 +56,13 @@ with H.Context(n, m, seed=20240901) as c:
         ok = a[:, 0] > 0
         s0 = a[ok, 0].min()
         fi, up, ti = a[:nfin][ok[:nfin]], a[nfin:nfin + nupd][ok[nfin:nfin + nupd]], a[nupd + nfin:][ok[nupd + nfin:]]  # (block roles by index: finalize, update, tiles)
+        if len(rows) == 20:  # one launch in detail: when do its tiles start?
+            ts = np.sort(ti[:, 0] - s0) * 1e-2
+            print("  launch %d in detail: %d tiles; start times (us) p50 %.2f p90 %.2f p95 %.2f p98 %.2f max %.2f; tiles that start later than 2 us: %d; update blocks start p50 %.2f max %.2f, end p50 %.2f" % (
+                g, len(ts), np.percentile(ts, 50), np.percentile(ts, 90), np.percentile(ts, 95), np.percentile(ts, 98), ts.max(), int((ts > 2.0).sum()),
+                np.percentile(up[:, 0] - s0, 50) * 1e-2, (up[:, 0] - s0).max() * 1e-2, np.percentile(up[:, 1] - s0, 50) * 1e-2))
+            late = np.argsort(ti[:, 0])[-12:]
+            print("    the twelve latest tiles: index in the launch %s start %s" % ((late + nupd + nfin).tolist(), np.round((ti[late, 0] - s0) * 1e-2, 2).tolist()))
         rows.append((s0, up[:, 1].max() - s0 if len(up) else 0, (up[:, 1] - up[:, 0]).mean() if len(up) else 0, fi[:, 1].max() - s0 if len(fi) else 0,
                      ti[:, 1].max() - s0, np.percentile(ti[:, 1] - s0, 50), (ti[:, 1] - ti[:, 0]).mean(), a[ok, 1].max(), ti[:, 0].max() - s0))
     r = np.array(rows, dtype=np.float64)
