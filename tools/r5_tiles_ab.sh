@@ -3,7 +3,7 @@
 # Fewer, longer tiles:
 cd /root/repo
 O=gpurun_out
-for tl in 900 730 680 730 900 620; do
+for tl in ${TILES_LIST:-900 730 680 730 900 620}; do
   HB_DOTQ2_TILES=$tl python bench.py --steps 200 --warmup 100 --no-cpu --no-ab --secondary '' --tertiary '' > $O/r5_tiles.json 2> $O/r5_tiles.err
   python - <<PY
 import json
