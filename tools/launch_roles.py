@@ -10,7 +10,7 @@ import bench as B
 bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 Lv = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 MODEL = os.environ.get("HB_ROLES_MODEL", "BayesCpi")   # BayesR: one panel per launch, int8 columns (python tools/launch_roles.py 8 2)
-D = 1 if MODEL == "BayesR" else 7
+D = int(os.environ.get("HB_ROLES_D", "1" if MODEL == "BayesR" else "7"))  # (BayesRR / A / L: HB_ROLES_D=2, python tools/launch_roles.py 8 2)
 n, m = 50000, 500000
 L = H.lib()
 L.hb_ctx_debug_launch_stamps.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]
