@@ -32,7 +32,99 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # arithmetic of the dominant kernel (everything else — chain, residual, updates — is f64 in every mode)
-DTYPE = {0: "f32", 1: "f64", 2: "fx56 (exact: f64 residual as 7 int8 digit planes, i8 x i8 -> i32 dot4; error below an f64 ddot's)"}
+DTYPE = {0: "f32", 1: "f64", 2: "i8 x i8 -> i32 (exact fixed point: the f64 residual as 7 int8 digit planes; error below an f64 ddot's)"}
+
+LINE_LIMIT = 6000   # bytes; the driver keeps ~10 KB of stdout tail and parses the last line out of it (round 5's 23 KB line was lost)
+
+
+def _r(x, sig=6):
+    """numbers of the compact line: 6 significant digits"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float("%.*g" % (sig, float(x)))
+    except (TypeError, ValueError):
+        return None
+
+
+def _leg(b, name):
+    """one side leg on the compact line: exactly {leg, model, bits, kernel, value, ms_per_step, frac, regime}"""
+    if not isinstance(b, dict):
+        return None
+    if "error" in b:
+        return {"leg": name, "model": b.get("model"), "error": str(b["error"])[:80]}
+    rf = b.get("roofline", {})
+    return {"leg": name, "model": b.get("model"), "bits": b.get("resident_genotype_bits"), "kernel": rf.get("kernel"),
+            "value": _r(b.get("value")), "ms_per_step": _r(b.get("ms_per_step")), "frac": _r(rf.get("frac"), 4),
+            "frac_of_measured_copy": _r(rf.get("frac_of_measured_copy"), 4), "regime": b.get("regime")}
+
+
+def compact_line(res, full_path):
+    """The ONE JSON line the driver parses: the contract's top-level keys, a config of five keys, ONE roofline block and ONE
+    cpu_baseline block of scalars, and one small object per side leg. Everything else (in-situ statistics, regime curves, states,
+    notes) is in the full record written to `full_path`. Kept under LINE_LIMIT bytes (asserted here and in tests/test_host_logic.py)."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: _r(res.get(k)) for k in top}
+    cfg = res.get("config", {})
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:160], "model": cfg.get("model"), "n": cfg.get("n"), "m": cfg.get("m_per_gpu"),
+                      "m_global": cfg.get("m_global"), "bits": cfg.get("resident_genotype_bits")}
+    rf = res.get("roofline", {})
+    line["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms",
+                                                   "launches_per_sweep", "measured_copy_GBps", "frac_of_measured_copy")}
+    line["roofline"]["isolated_frac"] = _r(rf.get("isolated", {}).get("frac"), 4)
+    line["regime"] = res.get("regime")
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        if "error" in cb:
+            line["cpu_baseline"] = {"error": str(cb["error"])[:120]}
+        else:
+            line["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind", "value_1thread", "int8_value", "int8_cores", "host_cpu_quota")}
+            line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:100]
+            if cb.get("value"):
+                line["vs_cpu_baseline"] = _r(res["value"] / cb["value"], 4)
+    legs = []
+    for key, name in (("int8", "int8"), ("vdot4_ab", "vdot4"), ("mfma_ab", "mfma"), ("secondary", "secondary")):
+        lg = _leg(res.get(key), name)
+        if lg:
+            legs.append(lg)
+        conv = res.get(key, {}).get("converged") if isinstance(res.get(key), dict) else None
+        if isinstance(conv, dict):
+            legs.append(_leg(conv, name + "_converged"))
+    for b in res.get("all_move", []) or []:
+        legs.append(_leg(b, "all_move"))
+    line["legs"] = legs
+    if res.get("n_gpus", 1) > 1:
+        pr = res.get("per_rank_ms_per_step") or {}
+        line["per_rank_ms_per_step"] = {"min": _r(pr.get("min")), "max": _r(pr.get("max"))}
+        ar = res.get("allreduce") or {}
+        line["allreduce"] = {"ms_per_call": _r(ar.get("ms_per_call_back_to_back")), "bytes": ar.get("bytes"), "collective": str(cfg.get("collective", ""))[:90]}
+        line["ranks_counted_by_all_reduce"] = res.get("ranks_counted_by_all_reduce")
+        st = res.get("strong")
+        if isinstance(st, dict):
+            line["strong_value"] = _r(st.get("value"))
+            line["strong"] = {k: _r(st.get(k)) for k in ("m_global", "m_per_gpu", "ms_per_step", "model", "error") if k in st}
+    line["full"] = full_path
+    out = json.dumps(line, separators=(",", ":"))
+    if len(out) >= LINE_LIMIT:      # never lose the record to its own size again: drop the legs, keep the contract
+        line["legs"] = [{"leg": lg.get("leg"), "model": lg.get("model"), "value": lg.get("value"), "frac": lg.get("frac")} for lg in legs if lg]
+        out = json.dumps(line, separators=(",", ":"))
+    assert len(out) < LINE_LIMIT, "bench line is %d bytes" % len(out)
+    return out
+
+
+def write_full(res):
+    """the full record (everything round 5 printed on the line) beside the compact line: profiles/bench_last_full.json, and
+    gpurun_out/ when that exists (it is what travels back from a gpurun box)"""
+    path = os.path.join("profiles", "bench_last_full.json")
+    for d in ("profiles", "gpurun_out"):
+        try:
+            if d == "gpurun_out" and not os.path.isdir(os.path.join(ROOT, d)):
+                continue
+            with open(os.path.join(ROOT, d, "bench_last_full.json"), "w") as f:
+                json.dump(res, f, indent=1)
+        except OSError:
+            pass
+    return path
 
 
 def parse():
@@ -46,10 +138,11 @@ def parse():
                          "not 300 — the markers changed per sweep still fall from 950 to 770 between sweep 300 and 450, and with --warmup 5 the timed "
                          "sweeps sat on that slope)")
     ap.add_argument("--burnin-secondary", type=int, default=300)
-    ap.add_argument("--burnin-converged", type=int, default=2500,
+    ap.add_argument("--burnin-converged", type=int, default=0,
                     help="the secondary model (BayesR) is measured twice: after --burnin-secondary sweeps (the chain has not found the signal "
                          "yet: ~30 000 markers in the model, ~49 000 moves per sweep) and again after this many MORE sweeps, continued from "
-                         "the first leg's state (nnz ~2 000-5 000: the regime a 50 000-iteration run lives in); 0 = first figure only")
+                         "the first leg's state (nnz ~2 000-5 000: the regime a 50 000-iteration run lives in); 0 (default since round 6: the leg is "
+                         "43 of the bench's 57 seconds) = first figure only; 2500 = round 5's converged leg")
     ap.add_argument("--stamped", type=int, default=10,
                     help="sweeps run right after the timed region with every block of every mat-vec launch stamped on the device's "
                          "100 MHz clock (hb_ctx_matvec_stamps): the in-situ launch duration the roofline is computed from")
@@ -68,6 +161,7 @@ def parse():
     ap.add_argument("--secondary", default="BayesR", help="second model measured on the same genotypes ('' = none)")
     ap.add_argument("--tertiary", default="BayesRR,BayesA,BayesL",
                     help="the models in which every marker moves every sweep (comma-separated), each reported in the 'all_move' list ('' = none)")
+    ap.add_argument("--no-strong", action="store_true", help="--gpus > 1, weak scaling: skip the strong-scaling leg (config 4: --m-global markers over all ranks)")
     ap.add_argument("--no-ab", action="store_true", help="skip the two side legs of the headline model (matrix-core A/B kernel, int8 columns)")
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--precise", type=int, default=2,
@@ -122,9 +216,8 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
     stationary regime (markers in the model = daxpy count) the GPU figure is quoted in."""
     from oracle import oracle as O
     mc = min(args.cpu_m, args.m)
-    X8 = ctx.download(0, mc)
+    X8 = np.asfortranarray(ctx.download(0, mc))
     Xd = np.asfortranarray(X8, dtype=np.float64)  # the reference's layout: 8 bytes per genotype
-    del X8
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -143,9 +236,11 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
     # is bounded by a wall-clock guard in a child process.
     import multiprocessing as mp
 
-    def timed(thr):
+    def timed(thr, Xm=None):
+        Xm = Xd if Xm is None else Xm
+
         def _child(q):
-            rr = O.bayes(y, Xd, args.model, Pi, fold=fold, niter=it, nburn=it - 1, thin=1, threads=thr,
+            rr = O.bayes(y, Xm, args.model, Pi, fold=fold, niter=it, nburn=it - 1, thin=1, threads=thr,
                          rng=O.RNG_PHILOX, seed=args.seed, g_init=gi)
             q.put(rr["iters_done"] / rr["loop_seconds"])
 
@@ -182,6 +277,13 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
         else:
             slow[str(thr)] = v
     best_thr = max(out, key=lambda k: out[k])
+    # SURVEY 8d, last sentence: the same sampler on int8 columns (NOT the reference's layout: reported separately, never as "the baseline")
+    i8 = {}
+    for thr in sorted({1, best_thr}):
+        v = timed(thr, X8)
+        if isinstance(v, float):
+            i8[thr] = v
+    i8_best = max(i8, key=lambda k: i8[k]) if i8 else None
     cpu_model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -193,7 +295,9 @@ def cpu_baseline(ctx, y, args, Pi, fold, g_warm=None):
     return {"value": out[best_thr], "unit": "sweeps/s", "cores": best_thr, "kind": "port",
             "sample": "oracle/hb_oracle.c (double col-major X, serial marker loop, dot/axpy on a persistent team of row-chunk workers) on the first %d of %d "
                       "markers, n=%d, %d sweeps, scaled by m_sample/m" % (mc, args.m, args.n, 1 + args.cpu_sweeps),
-            "value_1thread": out[1], "by_threads": {str(k): v for k, v in sorted(out.items())}, "not_finished": slow,
+            "value_1thread": out[1], "int8_value": i8.get(i8_best), "int8_cores": i8_best, "int8_by_threads": {str(k): v for k, v in sorted(i8.items())},
+            "int8_what": "the same port reading int8 columns (1 byte per genotype instead of the reference's 8): not the reference's layout, reported separately",
+            "by_threads": {str(k): v for k, v in sorted(out.items())}, "not_finished": slow,
             "regime": "warm start from the GPU chain's effects after its timed region" if gi is not None else "cold start",
             "host_cores": cores, "host_cpu_quota": quota,
             "cpu_model": cpu_model}
@@ -228,7 +332,7 @@ def valu_block(n, cols, avg_ms, kernel):
                     "(profiles/r04_dot4_rate.txt, profiles/r04_pmc_sq_k_dotq2.txt)"}
 
 
-def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8, kind=0):
+def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8, kind=0, copy_gbps=None):
     """roofline of the dominant kernel (the panel mat-vec), PHYSICAL: achieved = the bytes of genotypes the resident layout holds for
     one launch (n x columns x bits / 8) / the average duration of the sweep's full-width mat-vec launches AS THE SWEEP RUNS THEM
     (device-clock stamps of every block, chain workgroup and update rows beside them); frac = achieved / the 8 TB/s HBM peak.
@@ -253,6 +357,11 @@ def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8, kin
          "genotypes_priced_at_one_byte": {"bytes_per_launch": one, "achieved": one / (avg_ms * 1e-3) / 1e9, "frac": one / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                           "what": "SURVEY 8d's n x m denominator: genotypes per second priced at one byte each, whatever "
                                                   "the resident layout; equals `frac` for int8 columns, not a bandwidth for 2-bit ones"}}
+    if copy_gbps:
+        # "also report fraction of a measured streaming-read kernel on the same buffer" — what the chip delivers when the
+        # resident genotypes are only read (hb_ctx_time_stream_read), so that "achievable" is visible beside the nominal 8 TB/s
+        r["measured_copy_GBps"] = copy_gbps
+        r["frac_of_measured_copy"] = ach / copy_gbps
     if bound == "valu":
         r["bound_note"] = ("the 2-bit v_dot4 kernel is bound by LDS return bandwidth and VALU issue (see `valu`), not by HBM: `frac` is the HBM "
                            "roofline of the bytes it moves and is far below 1 by construction")
@@ -261,6 +370,18 @@ def roofline_block(args, n, cols, launches, insitu, iso_ms, traffic, bits=8, kin
         r["in_situ"] = {k: insitu[k] for k in ("min_ms", "max_ms", "sum_ms", "span_ms", "blocks_per_launch", "full_width_launches",
                                                "ms_per_step_of_the_stamped_sweeps")}
     return r
+
+
+def copy_ceiling(ctx, note=None):
+    """GB/s of a plain streaming read of the resident genotype buffer (one untimed pass, then 3 timed)"""
+    try:
+        ms, nb = ctx.time_stream_read(reps=3)
+        gbps = nb / (ms * 1e-3) / 1e9
+        if note:
+            note("streaming read of the resident genotypes: %.1f MB in %.3f ms = %.0f GB/s" % (nb / 1e6, ms, gbps))
+        return gbps
+    except Exception:  # noqa: BLE001  (a reported side number)
+        return None
 
 
 def regime_tag(ms_per_step, insitu):
@@ -584,7 +705,8 @@ def main():
     ctx.time_matvec(reps=1)                                   # (untimed: clocks and TLBs as in the steady state of a run)
     iso_ms, launches, cols = ctx.time_matvec(reps=5)
     kernel_main = (("k_dotq2m" if kind_main == 2 else "k_dotq2r" if kind_main == 1 else "k_dotq2") if bits == 2 else "k_dotq") if args.precise == 2 else "k_dot"
-    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, pmc_traffic(n, cols, kernel_main), bits, kind_main)
+    copy_main = copy_ceiling(ctx, note)
+    roof = roofline_block(args, n, cols, launches, insitu_main, iso_ms, pmc_traffic(n, cols, kernel_main), bits, kind_main, copy_main)
     note("mat-vec timing pass done")
 
     # one unit = one pass over m_ref markers (the metric's m = 500k); all ranks together pass over m_global markers per step
@@ -625,8 +747,12 @@ def main():
     roof["traffic_source"] = ("separate rocprofv3 --pmc FETCH_SIZE pass of the same launch shape, read from the tracked profiles/r05_pmc_traffic.json "
                               "(counters cannot be collected inside this process)") if roof.get("traffic") is not None else "none (no counter pass on file for this launch shape)"
 
+    copy_by_bits = {bits: copy_main}
+
     def leg_block(model, el, Kx, Wx, ev, nnzx, missx, ins, iso, launches_x, cols_x, bits_x, kind, geo_x, burn_x, curve=None):
-        kern = roofline_block(args, n, cols_x, launches_x, ins, iso, None, bits_x, kind)
+        if bits_x not in copy_by_bits:
+            copy_by_bits[bits_x] = copy_ceiling(ctx, note)     # (the leg's layout is the resident one while leg_block runs)
+        kern = roofline_block(args, n, cols_x, launches_x, ins, iso, None, bits_x, kind, copy_by_bits[bits_x])
         kern["traffic"] = pmc_traffic(n, cols_x, kern["kernel"])
         b = {"model": model, "value": Kx / el, "unit": "sweeps/s", "steps": Kx, "warmup": Wx, "ms_per_step": el / Kx * 1e3,
              "resident_genotype_bits": bits_x, "roofline": kern,
@@ -731,27 +857,6 @@ def main():
                 res.setdefault(key, []).append({"model": side, "error": repr(e)})
             else:
                 res[key] = {"model": side, "error": repr(e)}
-    # scalars of the side legs inside `roofline` (the driver's parsed record keeps the scalar keys of this block only)
-    for key, pre in (("int8", "int8"), ("mfma_ab", "mfma"), ("vdot4_ab", "vdot4")):
-        b = res.get(key)
-        if isinstance(b, dict) and "roofline" in b:
-            roof[pre + "_value"] = b["value"]
-            roof[pre + "_ms_per_step"] = b["ms_per_step"]
-            roof[pre + "_frac"] = b["roofline"]["frac"]
-            roof[pre + "_avg_launch_ms"] = b["roofline"]["avg_launch_ms"]
-            roof[pre + "_kernel"] = b["roofline"]["kernel"]
-            roof[pre + "_regime"] = b.get("regime")
-    b = res.get("secondary")
-    if isinstance(b, dict) and "value" in b:
-        roof["secondary_model"] = b["model"]
-        roof["secondary_value"] = b["value"]
-        roof["secondary_regime"] = b.get("regime")
-        if isinstance(b.get("converged"), dict):
-            roof["secondary_converged_value"] = b["converged"]["value"]
-            roof["secondary_converged_regime"] = b["converged"].get("regime")
-    for b in res.get("all_move", []):
-        if "value" in b:
-            roof["all_move_%s_value" % b["model"]] = b["value"]
     if world > 1:
         # what the scaling curve is made of: every rank's own time per step, and the exchange a sweep ends with on its own
         res["per_rank_ms_per_step"] = {"min": min(per_rank_main), "max": max(per_rank_main), "all": per_rank_main} if per_rank_main else None
@@ -778,8 +883,46 @@ def main():
         except Exception as e:  # the baseline is a reported side number, never the measured path
             res["cpu_baseline"] = {"error": repr(e)}
     ctx.close()
+    if world > 1:
+        try:
+            ones = torch.ones(1, dtype=torch.float64, device=comm.device)
+            comm.dist.all_reduce(ones)
+            res["ranks_counted_by_all_reduce"] = int(ones.item())
+        except Exception as e:  # noqa: BLE001
+            res["ranks_counted_by_all_reduce"] = repr(e)
+    if world > 1 and args.scaling == "weak" and not args.no_strong:
+        # BASELINE.json configs[3] in the SAME invocation (the driver passes no extra flags): --m-global markers (2 000 000) sharded
+        # over the ranks, the headline model, 2-bit resident — `strong_value` in passes over 500 000 markers per second
+        try:
+            from hibayes_amd.dist import shard_range
+            mg = args.m_global
+            lo, hi = shard_range(mg, rank, world)
+            ms_ = hi - lo
+            cs = H.Context(n, ms_, device=local_rank, panel=args.panel, precise=args.precise, m_offset=lo, seed=args.seed)
+            cs.generate(args.seed, mono_every=1000)
+            m_keep, args.m = args.m, ms_
+            try:
+                ys = synth_phenotype(cs, n, ms_, lo, mg, args.seed, comm, args.model)
+                cs.set_pipeline(*geo)
+                if adaptive:
+                    cs.set_adaptive(True)
+                cs.build_gram()
+                if args.bits == 2 and args.precise == 2:
+                    cs.set_layout(2, keep_int8=False)
+                    cs.set_matvec_kernel(kind_main)
+                els, evs, nnzs, _ = measure(H, L, cs, ys, args.model, K, W, args, rank, local_rank, world, lo, mg, comm, torch, note, burn=args.burnin)
+            finally:
+                args.m = m_keep
+                cs.close()
+            res["strong"] = {"value": (K / els) * (mg / 500000.0), "unit": "passes over 500 000 markers per second, all ranks together",
+                             "model": args.model, "m_global": mg, "m_per_gpu": ms_, "ms_per_step": els / K * 1e3, "steps": K, "warmup": W,
+                             "global_sweeps_per_s": K / els, "mean_changed_markers_per_sweep_per_rank": evs, "NumNZSnp_last": nnzs,
+                             "per_rank_ms_per_step": getattr(measure, "per_rank_ms", None),
+                             "what": "BASELINE.json configs[3]: BayesCpi, n=50k, m=2M sharded over the ranks, one residual all-reduce per sweep"}
+        except Exception as e:  # noqa: BLE001  (a side leg: its failure must not take the line with it)
+            res["strong"] = {"error": repr(e)[:200]}
     if rank == 0:
-        print(json.dumps(res))
+        print(compact_line(res, write_full(res)), flush=True)
     if comm is not None:
         comm.dist.destroy_process_group()
 

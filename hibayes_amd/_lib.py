@@ -198,7 +198,7 @@ SYMBOLS = [
     "hb_ctx_get_windows", "hb_ctx_last_timing", "hb_ctx_set_profiling", "hb_ctx_matvec", "hb_ctx_set_pipeline", "hb_ctx_time_matvec", "hb_ctx_matvec_stamps", "hb_ctx_set_layout", "hb_ctx_get_layout",
     "hb_ctx_download_gram_band", "hb_ctx_set_adaptive", "hb_ctx_get_pipeline", "hb_ctx_get_events", "hb_ctx_pipeline_note", "hb_ctx_matmul",
     "hb_comm_unique_id", "hb_comm_init", "hb_comm_world", "hb_comm_rank", "hb_comm_selftest", "hb_comm_destroy",
-    "hb_ctx_debug_inject_abort", "hb_ctx_set_matvec_kernel",
+    "hb_ctx_debug_inject_abort", "hb_ctx_set_matvec_kernel", "hb_ctx_time_stream_read",
     "hb_run_create", "hb_run_step", "hb_run_state", "hb_run_ctx", "hb_run_finish", "hb_run_destroy",
 ]
 
@@ -288,6 +288,7 @@ def lib():
     L.hb_ctx_set_pipeline.argtypes = [vp, i32, i32, i32]
     L.hb_ctx_set_adaptive.argtypes = [vp, i32]
     L.hb_ctx_time_matvec.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(i32), C.POINTER(i32)]
+    L.hb_ctx_time_stream_read.argtypes = [vp, i32, C.POINTER(dbl), C.POINTER(i64)]
     L.hb_ctx_set_layout.argtypes = [vp, i32, i32]
     L.hb_ctx_get_layout.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.hb_ctx_matvec_stamps.argtypes = [vp, C.POINTER(LaunchStats)]

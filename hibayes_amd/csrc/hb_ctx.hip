@@ -1272,6 +1272,12 @@ int hb_ctx_time_matvec(hb_ctx *c, int32_t reps, double *avg_ms, int32_t *launche
     return HB_OK;
 }
 
+int hb_ctx_time_stream_read(hb_ctx *c, int32_t reps, double *avg_ms, int64_t *bytes)
+{
+    if (!c || !avg_ms || !bytes) return hb_fail(HB_ERR_INVALID, "hb_ctx_time_stream_read: null argument");
+    return hbk_time_stream_read(c, reps > 0 ? reps : 1, avg_ms, bytes);
+}
+
 int hb_ctx_last_timing(hb_ctx *c, hb_sweep_timing *t)
 {
     if (!c || !t) return hb_fail(HB_ERR_INVALID, "hb_ctx_last_timing: null argument");

@@ -148,3 +148,56 @@ __global__ __launch_bounds__(256) void k_generate(int8_t *__restrict__ X, int64_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// measurement helper (SURVEY §8 d: "fraction of a measured streaming-read kernel on the same buffer"): what the chip delivers when
+// the resident genotypes are only READ — 16 bytes per lane and load, eight loads in flight per lane, non-temporal, a grid that fills
+// every compute unit eight times over. The OR of everything read is stored only if it has a value no genotype word combination can
+// give under the mask below, so the loads cannot be dropped and nothing is written.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned hb_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_stream_read(const hb_u32x4 *__restrict__ src, int64_t n16, unsigned *__restrict__ sink)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    hb_u32x4 a = {0, 0, 0, 0};
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        hb_u32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < 8; k++) a |= v[k];
+    }
+    for (; i < n16; i += stride) {
+        a |= __builtin_nontemporal_load(src + i);
+    }
+    const unsigned o = a.x | a.y | a.z | a.w;
+    if ((o & 0x80808080u) == 0x80808080u && (o & 0x7f7f7f7fu) == 0x12345678u) *sink = o; // (never true for genotype data; keeps the loads)
+}
+
+int hbk_time_stream_read(hb_ctx *c, int reps, double *avg_ms, int64_t *bytes)
+{
+    HB_HIP(hipSetDevice(c->device));
+    const bool two = c->layout == 2 && c->X2;
+    const void *p = two ? (const void *)c->X2 : (const void *)c->X;
+    const int64_t nb = (two ? c->ld2 : c->ld) * (int64_t)c->m_pad;
+    if (!p || nb < 16) return hb_fail(HB_ERR_INVALID, "hb_ctx_time_stream_read: no resident genotypes");
+    hipEvent_t e0, e1;
+    HB_HIP(hipEventCreate(&e0));
+    HB_HIP(hipEventCreate(&e1));
+    unsigned *sink = reinterpret_cast<unsigned *>(c->scratch);
+    const dim3 grid((unsigned)(c->num_cus * 8)), blk(256);
+    hipLaunchKernelGGL(k_stream_read, grid, blk, 0, c->stream, reinterpret_cast<const hb_u32x4 *>(p), nb / 16, sink);
+    HB_HIP(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_stream_read, grid, blk, 0, c->stream, reinterpret_cast<const hb_u32x4 *>(p), nb / 16, sink);
+    HB_HIP(hipEventRecord(e1, c->stream));
+    HB_HIP(hipStreamSynchronize(c->stream));
+    HB_HIP(hipGetLastError());
+    float ms = 0;
+    HB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / reps;
+    *bytes = nb / 16 * 16;
+    return HB_OK;
+}

@@ -210,6 +210,7 @@ extern "C" int hb_ctx_snapshot(hb_ctx *c, int model_index, bool store, bool coun
 extern "C" int hb_ctx_restore(hb_ctx *c);
 unsigned hbk_long_wait_flushes();
 int hbk_set_timeout(hb_ctx *c);
+int hbk_time_stream_read(hb_ctx *c, int reps, double *avg_ms, int64_t *bytes);
 int hbk_copy_segs(hb_ctx *c, const std::vector<hb_ctx::snap_seg> &segs, bool restore);
 
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed);

@@ -260,6 +260,13 @@ class Context:
         check(self.L.hb_ctx_time_matvec(self.h, reps, C.byref(ms), C.byref(nl), C.byref(nc)))
         return ms.value, nl.value, nc.value
 
+    def time_stream_read(self, reps=3):
+        """(ms per pass, bytes per pass) of a plain streaming read of the resident genotype buffer: the measured ceiling the
+        mat-vec's achieved bandwidth is quoted against beside the nominal HBM peak."""
+        ms, nb = C.c_double(), C.c_int64()
+        check(self.L.hb_ctx_time_stream_read(self.h, reps, C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
+
     def matvec_stamps(self):
         """In-situ statistics of the mat-vec launches of the last sweep (set_profiling(8) first); see hb_launch_stats."""
         st = LaunchStats()

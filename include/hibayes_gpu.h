@@ -491,6 +491,10 @@ int hb_ctx_last_timing(hb_ctx *c, hb_sweep_timing *t);
 /* measurement helper: the panel mat-vec launches of one sweep, issued back to back exactly as the sweep issues them
  * (same columns per launch), timed with HIP events on the context's stream; average milliseconds per launch */
 int hb_ctx_time_matvec(hb_ctx *c, int32_t reps, double *avg_ms, int32_t *launches_per_sweep, int32_t *cols_per_launch);
+/* measurement helper ("fraction of a measured streaming-read kernel on the same buffer"): the resident genotype buffer
+ * (int8 columns, or the 2-bit words when that layout is set) read once front to back by a plain 16-bytes-per-lane kernel, nothing
+ * computed, nothing written; average milliseconds per pass over `reps` passes (one untimed pass first) and the bytes of one pass */
+int hb_ctx_time_stream_read(hb_ctx *c, int32_t reps, double *avg_ms, int64_t *bytes);
 /* on: bit 0 HIP-event timing of the per-panel kernels (hb_ctx_last_timing), bit 1 cycle stamps inside the chain kernel,
  * bit 2 chain-alone diagnostic, bit 3 in-situ stamps of the mat-vec launches (hb_ctx_matvec_stamps) */
 int hb_ctx_set_profiling(hb_ctx *c, int32_t on);

@@ -58,9 +58,9 @@ typedef struct {
  * spin on that, each leader re-posts to its own line, its seven members spin on that: nobody's store has to invalidate 63 readers) */
 typedef struct {
     _Alignas(128) atomic_ulong go;   /* generation posted */
-    int op;                          /* 0 dot, 1 axpy, 2 quit */
+    int op;                          /* 0 dot, 1 axpy, 2 quit; 3 / 4: dot / axpy on an int8 column (x points at int8_t) */
     double a;
-    const double *x;
+    const void *x;
     const double *yc;
     double *y;
     char pad[128 - sizeof(atomic_ulong) - sizeof(int) - sizeof(double) - 3 * sizeof(void *) - 4];
@@ -95,31 +95,45 @@ static inline void team_range(const team_t *t, int id, int *lo, int *hi)
 }
 
 /* worker `id` runs its share of job `jb` (generation gen); a leader first re-posts the job to its group */
-static void team_do(team_t *t, int id, unsigned long gen, const team_job_t *jb)
+static int team_do(team_t *t, int id, unsigned long gen, const team_job_t *jb)
 {
+    /* the job line is read HERE, before this worker publishes anything: once it has signalled completion the master (or its leader)
+     * may already be rewriting the line for the next generation (advisor finding, round 5: the worker used to re-read op afterwards) */
+    const int op = jb->op;
+    const double a = jb->a;
+    const void *xv = jb->x;
+    const double *yc = jb->yc;
+    double *y = jb->y;
     const int leader = id % HBO_TEAM_GROUP == 0;
     if (leader && id + 1 < t->nthreads) {
         team_job_t *gl = &t->job[1 + id / HBO_TEAM_GROUP];
-        gl->op = jb->op; gl->a = jb->a; gl->x = jb->x; gl->yc = jb->yc; gl->y = jb->y;
+        gl->op = op; gl->a = a; gl->x = xv; gl->yc = yc; gl->y = y;
         atomic_store_explicit(&gl->go, gen, memory_order_release);
     }
-    if (jb->op == 2) return;
+    if (op == 2) return op;
     int lo, hi;
     team_range(t, id, &lo, &hi);
     double s = 0.0;
-    if (jb->op == 0) {
-        const double *x = jb->x, *y = jb->yc;
+    if (op == 0) {
+        const double *x = (const double *)xv;
 #pragma omp simd reduction(+ : s)
-        for (int i = lo; i < hi; i++) s += x[i] * y[i];
-    } else {
-        const double a = jb->a, *x = jb->x;
-        double *y = jb->y;
+        for (int i = lo; i < hi; i++) s += x[i] * yc[i];
+    } else if (op == 1) {
+        const double *x = (const double *)xv;
 #pragma omp simd
         for (int i = lo; i < hi; i++) y[i] += a * x[i];
+    } else if (op == 3) {
+        const int8_t *x = (const int8_t *)xv;
+#pragma omp simd reduction(+ : s)
+        for (int i = lo; i < hi; i++) s += (double)x[i] * yc[i];
+    } else {
+        const int8_t *x = (const int8_t *)xv;
+#pragma omp simd
+        for (int i = lo; i < hi; i++) y[i] += a * (double)x[i];
     }
     team_slot_t *me = &t->slot[id];
     me->part = s;
-    if (!leader) { atomic_store_explicit(&me->gen, gen, memory_order_release); return; }
+    if (!leader) { atomic_store_explicit(&me->gen, gen, memory_order_release); return op; }
     double g = s;       /* group leader: its members' partial sums, in member order */
     for (int k = id + 1; k < id + HBO_TEAM_GROUP && k < t->nthreads; k++) {
         team_wait(&t->slot[k].gen, gen);
@@ -127,6 +141,7 @@ static void team_do(team_t *t, int id, unsigned long gen, const team_job_t *jb)
     }
     me->gsum = g;
     atomic_store_explicit(&me->ggen, gen, memory_order_release);
+    return op;
 }
 
 static void *team_worker(void *p)
@@ -144,8 +159,7 @@ static void *team_worker(void *p)
     team_job_t *src = (id % HBO_TEAM_GROUP == 0) ? &t->job[0] : &t->job[1 + id / HBO_TEAM_GROUP];
     for (unsigned long gen = 1;; gen++) {
         team_wait(&src->go, gen);
-        team_do(t, id, gen, src);
-        if (src->op == 2) break;
+        if (team_do(t, id, gen, src) == 2) break;
     }
     return NULL;
 }
@@ -189,7 +203,7 @@ static void team_start(int nthreads, int n)
     g_team = t;
 }
 
-static double team_run(team_t *t, int op, double a, const double *x, const double *yc, double *y)
+static double team_run(team_t *t, int op, double a, const void *x, const double *yc, double *y)
 {
     team_job_t *root = &t->job[0];
     root->op = op; root->a = a; root->x = x; root->yc = yc; root->y = y;
@@ -234,6 +248,7 @@ static void hbo_daxpy(int n, double a, const double *x, double *y)
 
 static double ddot_i8(int n, const int8_t *x, const double *y)
 {
+    if (g_team && n == g_team->n) return team_run(g_team, 3, 0.0, x, y, NULL);
     double s = 0.0;
 #pragma omp simd reduction(+ : s)
     for (int i = 0; i < n; i++) s += (double)x[i] * y[i];
@@ -242,6 +257,7 @@ static double ddot_i8(int n, const int8_t *x, const double *y)
 
 static void daxpy_i8(int n, double a, const int8_t *x, double *y)
 {
+    if (g_team && n == g_team->n) { team_run(g_team, 4, a, x, NULL, y); return; }
 #pragma omp simd
     for (int i = 0; i < n; i++) y[i] += a * (double)x[i];
 }

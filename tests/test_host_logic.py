@@ -202,3 +202,36 @@ def test_sbrm_host_checks_before_any_device_work():
         sbrm(ss, ld, "BayesCpi", map=mp, windsize=1e6)
     with pytest.raises(ValueError, match="bad setting for collecting frequency"):
         sbrm(ss, ld, "BayesCpi", niter=10, nburn=8, thin=5)
+
+
+def test_bench_line_stays_small_enough_for_the_driver_to_parse():
+    """Round 5's bench line was 23 KB and the driver's record came back unparsed (`parsed: null`): the line is now built by
+    bench.compact_line() from the full record, which goes to a file. Built here from round 5's full record (canned numbers):
+    under 6000 bytes, one line, the contract's keys, ONE roofline and ONE cpu_baseline block of scalars, small side legs."""
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = json.load(open(os.path.join(root, "profiles", "r05_bench_driver_args.json")))
+    res["roofline"].update(measured_copy_GBps=6290.0, frac_of_measured_copy=0.52)
+    res["cpu_baseline"].update(int8_value=0.5, int8_cores=16)
+    line = bench.compact_line(res, "profiles/bench_last_full.json")
+    assert len(line) < bench.LINE_LIMIT <= 6000 and "\n" not in line
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["value"] == pytest.approx(res["value"], rel=1e-5) and out["config"]["workload"] and "model" in out["config"]
+    assert all(not isinstance(v, (dict, list)) for v in out["roofline"].values())
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "bytes_per_launch", "avg_launch_ms", "measured_copy_GBps", "frac_of_measured_copy"):
+        assert k in out["roofline"], k
+    assert all(not isinstance(v, (dict, list)) for v in out["cpu_baseline"].values())
+    for k in ("value", "unit", "cores", "kind", "sample", "value_1thread", "int8_value"):
+        assert k in out["cpu_baseline"], k
+    assert len(out["cpu_baseline"]["sample"]) <= 100
+    assert {lg["leg"] for lg in out["legs"]} >= {"int8", "vdot4", "secondary", "all_move"}
+    assert all(set(lg) <= {"leg", "model", "bits", "kernel", "value", "ms_per_step", "frac", "frac_of_measured_copy", "regime", "error"} for lg in out["legs"])
+    # a sharded run adds its per-rank figures and the strong-scaling leg, still under the limit
+    res.update(n_gpus=8, per_rank_ms_per_step={"min": 2.1, "max": 2.3, "all": [2.2] * 8}, ranks_counted_by_all_reduce=8,
+               allreduce={"ms_per_call_back_to_back": 0.05, "bytes": 400128}, strong={"value": 900.0, "m_global": 2000000, "m_per_gpu": 250000, "ms_per_step": 4.4, "model": "BayesCpi"})
+    out8 = json.loads(bench.compact_line(res, "x"))
+    assert out8["strong_value"] == 900.0 and out8["ranks_counted_by_all_reduce"] == 8 and out8["per_rank_ms_per_step"]["max"] == 2.3 and out8["allreduce"]["ms_per_call"] == 0.05
