@@ -105,7 +105,7 @@ class BayesOut(C.Structure):
         ("setup_seconds", C.c_double), ("loop_seconds", C.c_double),
         ("iters_done", C.c_int32),
         ("mean_events", C.c_double),
-        ("sweeps_replayed", C.c_int32), ("reserved_", C.c_int32),
+        ("sweeps_replayed", C.c_int32), ("resident_bits", C.c_int32),
         ("last", WarmState), ("g_last", C.c_void_p), ("vargL_last", C.c_void_p),
     ]
 
@@ -141,7 +141,7 @@ class RunInfo(C.Structure):
         ("vara", C.c_double), ("vare", C.c_double), ("varg", C.c_double), ("mu", C.c_double),
         ("pi", C.c_double * HB_MAX_FOLD), ("mean_events", C.c_double), ("mean_misses", C.c_double), ("mean_redo", C.c_double),
         ("loop_seconds", C.c_double), ("setup_seconds", C.c_double), ("gram_seconds", C.c_double),
-        ("sweeps_replayed", C.c_int32), ("reserved_", C.c_int32),
+        ("sweeps_replayed", C.c_int32), ("resident_bits", C.c_int32),
         ("lambda2", C.c_double),
     ]
 

@@ -28,7 +28,7 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
           thin=5, epsl_y_J=None, epsl_Gi=None, epsl_index=None, dfvr=None, s2vr=None, vg=None,
           dfvg=None, s2vg=None, ve=None, dfve=None, s2ve=None, windindx=None, outfreq=100, threads=0,
           verbose=True, *, seed=666666, device=0, panel=0, precise=2, store_alpha=True,
-          comm=None, m_global=None, m_offset=0, log=None, C=None, g_init=None, ctx=None, sync_every_blocks=1, genotype_bits=8,
+          comm=None, m_global=None, m_offset=0, log=None, C=None, g_init=None, ctx=None, sync_every_blocks=1, genotype_bits=0,
           shard_rows=False, n_global=None, row_offset=0, warm=None):
     """Individual-level Gibbs sampler on one MI355X (or one marker shard of it when `comm` is given).
 
@@ -39,6 +39,9 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
     an fp64 ddot's own rounding and independent of the launch geometry; 1 fp64 FMA; 0 the fp32 image of the residual.
     `ctx` (an engine.Context with genotypes already resident) replaces X: one upload serves several fits;
     the context's own pipeline geometry, seed addressing (m_offset) and panel are then used as they are.
+    `genotype_bits`: resident layout of the sweep — 0 (default) auto: 2 bits per genotype where that is exact and the faster sweep
+    (every code in 0..3, precise = 2, BayesB / BayesBpi / BayesC / BayesCpi at panel 512), int8 columns otherwise; 8 / 2 force one.
+    The chain is the same bit for bit; the result's "resident_bits" reports what ran.
     `warm` (a dict mu / vare / varg / pi / lambda2 / vargL, or a _lib.WarmState) with `g_init` continues a chain from a reported
     state instead of the prior defaults (hb_warm_state, include/hibayes_gpu.h).
     """
@@ -146,7 +149,7 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
         keep.append(ws)
     if shard_rows:  # exact cross-check mode: this process holds rows [row_offset, row_offset + n) of every marker (include/hibayes_gpu.h)
         a.shard_rows, a.n_global, a.row_offset = 1, int(n if n_global is None else n_global), int(row_offset)
-    a.genotype_bits = int(genotype_bits)  # 8: int8 columns resident; 2: 2 bits per genotype resident (codes 0..3), same chain
+    a.genotype_bits = int(genotype_bits)  # 0 (default): auto — 2 bits where exact and faster (codes 0..3, BayesB / C at panel 512), int8 otherwise; 8 / 2 force a layout; same chain
     a.sync_blocks = int(sync_every_blocks)  # exchanges per sweep of a sharded run; the chain itself does not depend on it
     if log is not None:
         logcb = _lib.LOG_FN(lambda line, _u: log(line.decode("utf-8", "replace")))
@@ -222,7 +225,7 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
     res["alpha_sd"] = bufs["alpha_sd"]
     res["timing"] = {"setup_seconds": o.setup_seconds, "loop_seconds": o.loop_seconds,
                      "iters_done": o.iters_done, "mean_events": o.mean_events,
-                     "sweeps_replayed": o.sweeps_replayed}
+                     "sweeps_replayed": o.sweeps_replayed, "resident_bits": o.resident_bits}
     res["nzct"], res["n_records"] = o.nzct, o.n_records
     del keep
     return res

@@ -917,6 +917,7 @@ int hb_ctx_restore(hb_ctx *c)
     int rc = hbk_copy_segs(c, c->snap_segs, true);
     if (rc) return rc;
     HB_HIP(hipMemsetAsync(c->flags, 0, sizeof(unsigned) * 4096, c->stream));
+    HB_HIP(hipMemsetAsync(c->ru_ws, 0, sizeof(double) * 128, c->stream)); // k_reduce_ru's tickets: zero at rest, also after a sweep that did not end
     c->aborted = false;
     return HB_OK;
 }

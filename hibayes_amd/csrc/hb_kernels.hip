@@ -576,7 +576,7 @@ static int enqueue_sweep_kernels(hb_ctx *c, int model, int n_fold, bool timed)
                                c->m_offset, c->seed, c->vx, c->g, c->vargL, 0);
             hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(1024), 0, sA, c->vargL, c->m, c->acc + HB_ACC_SUMVARGL);
         }
-        hipLaunchKernelGGL(k_reduce_ru, dim3(16), dim3(64), 0, sA, c->r, c->u, c->n, c->acc, c->ru_ws);
+        hipLaunchKernelGGL(k_reduce_ru, dim3(16), dim3(64), 0, sA, c->r, c->u, c->n, c->acc, c->ru_ws, c->flags);
         tm.end(3, b);
     }
     tm.end(4, t_all);
@@ -886,7 +886,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
                            c->vx, c->g, c->vargL, 0);
         hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(1024), 0, sA, c->vargL, c->m, c->acc + HB_ACC_SUMVARGL);
     }
-    if (last) hipLaunchKernelGGL(k_reduce_ru, dim3(16), dim3(64), 0, sA, c->r, c->u, c->n, c->acc, c->ru_ws);
+    if (last) hipLaunchKernelGGL(k_reduce_ru, dim3(16), dim3(64), 0, sA, c->r, c->u, c->n, c->acc, c->ru_ws, c->flags);
     HB_HIP(hipGetLastError());
     return HB_OK;
 }
@@ -1018,7 +1018,7 @@ int hbk_dot_panels(hb_ctx *c, int reps)
 
 int hbk_reduce_ru(hb_ctx *c)
 {
-    hipLaunchKernelGGL(k_reduce_ru, dim3(16), dim3(64), 0, c->stream, c->r, c->u, c->n, c->acc, c->ru_ws);
+    hipLaunchKernelGGL(k_reduce_ru, dim3(16), dim3(64), 0, c->stream, c->r, c->u, c->n, c->acc, c->ru_ws, c->flags);
     HB_HIP(hipGetLastError());
     return HB_OK;
 }

@@ -12,9 +12,13 @@
 // + 1024, + 2048 ... in that order, as thread b * 64 + lane of the one workgroup did; a wave's 64 partial sums are folded by the same shuffles;
 // the sixteen wave sums are added in wave order by the workgroup that arrives last (a ticket), which also publishes the mean for the second
 // pass — the others wait for it (sixteen waves are always resident together) — and, after the second pass, resets the tickets.
+// Round 6 (advisor finding): that wait is BOUNDED like every other hand-off of the library (HB_TIMEOUT_TICKS; on expiry the abort flag is
+// raised, fetch_acc reports HB_ERR_ABORTED and hb_run_step restores and replays), the mean and its ticket are published by memory-side
+// exchanges and polled by memory-side fetch-ors (the point all XCDs share: neither a writer's nor a reader's L2 can hold them back,
+// DESIGN 9.1), and the tickets are reset by the last workgroup whether or not the sweep was aborted (hb_ctx_restore clears them too).
 // ws: [0..15] sum r, [16..31] sum r^2, [32..47] sum u (then: sum d^2), [48..63] sum d, [64] mean; counters at ws + 80 (three unsigned, zero at rest).
 __global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, const double *__restrict__ u, int n, double *__restrict__ acc,
-                                                  double *__restrict__ ws)
+                                                  double *__restrict__ ws, unsigned *__restrict__ flags)
 {
     const int lane = threadIdx.x, b = blockIdx.x, nb = gridDim.x, stride = nb * 64;
     unsigned *cnt = reinterpret_cast<unsigned *>(ws + 80);
@@ -43,9 +47,9 @@ __global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, 
     su = wave_sum(su);
     __shared__ int s_last;
     if (lane == 0) {
-        __hip_atomic_store(&ws[b], sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws[16 + b], sr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws[32 + b], su, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(&ws[b]), (unsigned long long)__double_as_longlong(sr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(&ws[16 + b]), (unsigned long long)__double_as_longlong(sr2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(&ws[32 + b]), (unsigned long long)__double_as_longlong(su), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         s_last = atomicAdd(&cnt[0], 1u) == (unsigned)nb - 1u;
     }
@@ -53,9 +57,9 @@ __global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, 
     if (s_last) { // (the whole wave: lane i fetches wave i's sums — one round trip, not forty-eight —, lane 0 adds them in wave order)
         __threadfence();
         const int li = min(lane, nb - 1);
-        const double v0 = __hip_atomic_load(&ws[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double v1 = __hip_atomic_load(&ws[16 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double v2 = __hip_atomic_load(&ws[32 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double v0 = ld_fresh(&ws[li]);
+        const double v1 = ld_fresh(&ws[16 + li]);
+        const double v2 = ld_fresh(&ws[32 + li]);
         double t0 = 0, t1 = 0, t2 = 0;
         for (int i = 0; i < nb; i++) {
             t0 += readlane_f64(v0, i);
@@ -65,16 +69,25 @@ __global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, 
         if (lane == 0) {
             acc[HB_ACC_SUMR] = t0;
             acc[HB_ACC_SUMR2] = t1;
-            __hip_atomic_store(&ws[64], t2 / n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(&ws[64]), (unsigned long long)__double_as_longlong(t2 / n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence();
-            __hip_atomic_store(&cnt[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_exchange(&cnt[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (lane == 0) {
-        while (__hip_atomic_load(&cnt[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+    if (lane == 0 && !s_last) {
+        const unsigned long long t0 = wall_clock64();
+        unsigned looks = 0;
+        while (__hip_atomic_fetch_or(&cnt[1], 0u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++looks & 63u) == 0u && (ld_flag(flags + HB_FLAG_ABORT) != 0u || wall_clock64() - t0 > HB_TIMEOUT_TICKS)) {
+                if (ld_flag(flags + HB_FLAG_ABORT) == 0u) hb_abort_log(flags, HB_LOG_WAIT_GE, true, 0xA11u, (unsigned)b, 0ull);
+                st_flag(flags + HB_FLAG_ABORT, 1u); // (the sums of an aborted sweep are never used: fetch_acc fails first)
+                break;
+            }
+        }
     }
     __syncthreads();
-    const double mean = __hip_atomic_load(&ws[64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double mean = ld_fresh(&ws[64]);
     double a2 = 0, a3 = 0;
     for (int i0 = b * 64 + lane; i0 < n; i0 += B2 * stride) {
         double bv[B2];
@@ -96,8 +109,8 @@ __global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, 
     a3 = wave_sum(a3);
     __syncthreads(); // (s_last is rewritten: everybody has read it)
     if (lane == 0) {
-        __hip_atomic_store(&ws[32 + b], a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws[48 + b], a3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(&ws[32 + b]), (unsigned long long)__double_as_longlong(a2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(&ws[48 + b]), (unsigned long long)__double_as_longlong(a3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         s_last = atomicAdd(&cnt[2], 1u) == (unsigned)nb - 1u; // (everybody has read the mean and left its sums: the last one closes)
     }
@@ -105,8 +118,8 @@ __global__ __launch_bounds__(64) void k_reduce_ru(const double *__restrict__ r, 
     if (s_last) {
         __threadfence();
         const int li = min(lane, nb - 1);
-        const double v2 = __hip_atomic_load(&ws[32 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double v3 = __hip_atomic_load(&ws[48 + li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double v2 = ld_fresh(&ws[32 + li]);
+        const double v3 = ld_fresh(&ws[48 + li]);
         double t2 = 0, t3 = 0;
         for (int i = 0; i < nb; i++) {
             t2 += readlane_f64(v2, i);

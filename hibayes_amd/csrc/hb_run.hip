@@ -569,15 +569,32 @@ int hb_run::setup(const hb_bayes_args *args)
             recover_on = false;
         }
     }
+    // ---- resident layout (round 6): genotype_bits = 0 is "auto" — 2 bits per genotype where that is exact AND the faster sweep: codes
+    // 0..3 (PLINK's own alphabet, src/read_bed.cpp:116-120), the fixed-point mat-vec, and the point-mass models' wide launches
+    // (BayesB / BayesC at panel 512: 450 against 213 sweeps/s at n = 50k, m = 500k; the same chain bit for bit). The models whose
+    // launches cover one or two panels are bound by their chain workgroup and run the lighter int8 kernel beside it. 8 forces int8. ----
+    int bits_run = a.genotype_bits == 2 ? 2 : 8;
+    if (a.genotype_bits == 0 && own_ctx && !rowmode && a.precise == 2 && (model_index == 3 || model_index == 4) && c->P == 512 &&
+        c->pipeline && c->xmin >= 0 && c->xmax <= 3 && !getenv("HB_NO_AUTO_BITS")) {
+        // the band of the (3, 7) geometry and the packed genotypes must fit beside the int8 columns the band is built from
+        size_t fr = 0, tot = 0;
+        const size_t band = (size_t)28 * c->m_pad * c->P * sizeof(int32_t), x2 = (size_t)((c->ld + 511) / 512 * 128) * c->m_pad;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > band + x2 + ((size_t)2 << 30)) bits_run = 2;
+        else (void)hipGetLastError();
+    }
+    if (bits_run == 2 && own_ctx && a.genotype_bits == 0) {
+        rc = hb_ctx_set_pipeline(c, 1, 3, 7); // (set up as (2, 7) above; the third group of look-ahead pays on the 2-bit layout)
+        if (rc) return rc;
+    }
     if (!c->gram_ready) {
         rc = hb_ctx_build_gram(c, &gram_seconds);
         if (rc) return rc;
     }
-    if (a.genotype_bits == 2 && own_ctx) { // the Gram blocks (built from the int8 columns) are in place: pack, drop the int8 copy
+    if (a.genotype_bits != 0 && a.genotype_bits != 8 && a.genotype_bits != 2)
+        return hb_fail(HB_ERR_INVALID, "hb_bayes_run: genotype_bits must be 0 (auto), 8 or 2");
+    if (bits_run == 2 && own_ctx) { // the Gram blocks (built from the int8 columns) are in place: pack, drop the int8 copy
         rc = hb_ctx_set_layout(c, 2, 0);
         if (rc) return rc;
-    } else if (a.genotype_bits != 0 && a.genotype_bits != 8 && a.genotype_bits != 2) {
-        return hb_fail(HB_ERR_INVALID, "hb_bayes_run: genotype_bits must be 0, 8 or 2");
     }
     {   // geometry by regime: only from the wide-band geometry of the point-mass models, whose stored band serves the narrow one
         int32_t gp = 0, gl = 0, gd = 0, gb = 0;
@@ -1119,7 +1136,7 @@ int hb_run::finish(hb_bayes_out *o)
     o->iters_done = iter;
     o->mean_events = iter > 0 ? events_sum / iter : 0;
     o->sweeps_replayed = aborts;
-    o->reserved_ = 0;
+    o->resident_bits = c ? c->layout : 0;
     line("Posterior parameters:");
     line("    Mu %f", Mu);
     line("    Genetic var %f", o->Vg);
@@ -1173,7 +1190,7 @@ int hb_run_state(hb_run *r, hb_run_info *info)
     info->mean_misses = r->iter > 0 ? r->miss_sum / r->iter : 0.0;
     info->mean_redo = r->iter > 0 ? r->redo_sum / r->iter : 0.0;
     info->sweeps_replayed = r->aborts;
-    info->reserved_ = 0;
+    info->resident_bits = r->c ? r->c->layout : 0;
     info->lambda2 = r->lambda2;
     info->loop_seconds = r->loop_seconds;
     info->setup_seconds = r->setup_seconds;

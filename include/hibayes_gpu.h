@@ -168,11 +168,15 @@ typedef struct hb_bayes_args {
      * not see the other shards' moves; more exchanges = less of that staleness (and of the bias it causes where the shards'
      * markers are correlated), at one all-reduce and one pipeline drain each. Unsharded, the chain does not depend on it. */
     int32_t sync_blocks;
-    /* resident genotype layout of the sweep (ABI 4): 0 or 8 = int8 columns; 2 = 2 bits per genotype, PLINK's
+    /* resident genotype layout of the sweep (ABI 4; 0 = auto since round 6): 8 = int8 columns; 2 = 2 bits per genotype, PLINK's
      * own density (reference src/read_bed.cpp:116-167), expanded to bytes in registers inside the mat-vec — a
      * quarter of the bytes per sweep. Needs genotype codes 0..3 and the fixed-point mat-vec (precise = 2); same chain bit for bit
      * (the dot products are exact integers either way). A context the run creates drops its int8 copy once the Gram blocks
-     * are built; with a pre-loaded ctx the layout is the context's (hb_ctx_set_layout). */
+     * are built; with a pre-loaded ctx the layout is the context's (hb_ctx_set_layout).
+     * 0 = AUTO (what the Rcpp shim and ibrm() pass): 2 bits where that is exact and the faster sweep — every code in 0..3, precise = 2,
+     * BayesB / BayesBpi / BayesC / BayesCpi at panel 512 (the wide mat-vec launches; 450 against 213 sweeps/s at n = 50k, m = 500k), the
+     * band and the packed copy fitting the device — int8 columns otherwise. hb_bayes_out.resident_bits / hb_run_info.resident_bits
+     * report the choice. HB_NO_AUTO_BITS=1 in the environment keeps int8. */
     int32_t genotype_bits;
     /* Exact multi-GPU cross-check mode (ABI 4; SURVEY §8e "alternative rejected ... keep only as a correctness cross-check mode"):
      * shard the INDIVIDUALS instead of the markers. This process holds rows [row_offset, row_offset + n) of all m markers and of y
@@ -227,7 +231,7 @@ typedef struct hb_bayes_out {
     int32_t iters_done;
     double mean_events;      /* mean number of markers whose effect changed per sweep     */
     int32_t sweeps_replayed; /* (ABI 5) sweeps that timed out on the device and were replayed from the saved state */
-    int32_t reserved_;
+    int32_t resident_bits;   /* (was reserved_) the genotype layout the sweep read: 8 or 2 — what genotype_bits = 0 ("auto") chose */
     /* (ABI 6) the chain's state after its LAST iteration — what hb_bayes_args.g_init / .warm of a following run take to continue it:
      * the scalars in `last` (last.vargL is set to vargL_last), the effects in g_last (m, caller-allocated or NULL) and, for BayesL,
      * the per-marker variances in vargL_last (m, caller-allocated or NULL). */
@@ -255,7 +259,7 @@ typedef struct hb_run_info {
     double mean_redo;        /* mean rolled-back chain rounds per sweep so far */
     double loop_seconds, setup_seconds, gram_seconds;
     int32_t sweeps_replayed; /* (ABI 5) sweeps whose device pipeline timed out and that were replayed from the saved state (HB_ERR_ABORTED) */
-    int32_t reserved_;
+    int32_t resident_bits;   /* (was reserved_) the genotype layout the sweep read: 8 or 2 — what genotype_bits = 0 ("auto") chose */
     double lambda2;          /* (ABI 6) BayesL's lambda^2 after the last iteration (hb_warm_state.lambda2) */
 } hb_run_info;
 int hb_run_create(const hb_bayes_args *args, hb_run **out);

@@ -75,7 +75,7 @@ Rcpp::List Bayes(arma::vec &y, arma::mat &X, std::string model, arma::vec Pi,
     a.seed = (uint64_t)(unif_rand() * 4294967296.0);     // one draw from R's stream: set.seed() in ibrm() (R/bayes.r:151) still governs the run
     a.store_alpha = 1;
     a.precise = 2;                                       // exact fixed-point panel mat-vec (fp64-grade)
-    a.genotype_bits = 0;                                 // 2: keep the genotypes resident at 2 bits (codes 0..3 only; same chain)
+    a.genotype_bits = 0;                                 // auto: 2 bits per genotype resident where exact and faster (codes 0..3, BayesB / C), int8 otherwise; same chain
     a.interrupt = [](void*) -> int { try { Rcpp::checkUserInterrupt(); return 0; } catch (...) { return 1; } };
     a.log = [](const char *line, void*) { Rcpp::Rcout << line << std::endl; };
 
