@@ -249,6 +249,9 @@ static constexpr int q2_lds(int cpl, int rs) { return 2 * ((64 * cpl / (4096 / r
 #ifndef Q2M_NBUF
 #define Q2M_NBUF 3 /* stage buffers: NBUF - 1 (super-)stages in flight ahead of the one being multiplied (a stage computes in ~0.3 us, a loaded round trip takes ~2) */
 #endif
+#ifndef Q2M_NODIG
+#define Q2M_NODIG 0 /* TIMING DIAGNOSTIC ONLY (wrong results): dotq2m512_tile requests no digit pieces at all — the round-5 verdict's test of "the launch is bound by LDS-DMA ingest, a third of which is digits every single-wave tile re-reads" (profiles/r06_q2m_digits.txt) */
+#endif
 #ifndef Q2M_NT
 #define Q2M_NT 1 /* the genotype tile's DMA pieces carry the non-temporal hint (k_dotq: so that the digit planes and the chain's rows stay in L2) */
 #endif
@@ -399,7 +402,7 @@ __device__ __forceinline__ void dotq2m512_tile(const dq_view &v, char *smem, int
     // chunk 8 j + l / 8 (slot = chunk * 8 + plane: the seven planes of a read group are neighbours). The eight lanes that share a 128-byte line are then
     // eight apart; without SWZ they are neighbours and the reads conflict four- and seven-fold.
     constexpr int XSL = SWZ ? 1152 : HBQ_SLOT;
-    constexpr int NXP = 8, NDP = 4, XB = NXP * XSL, BUF = XB + NDP * 1024, PER = NXP + NDP, NSC = SC ? 4 : 1;
+    constexpr int NXP = 8, NDP = 4, XB = NXP * XSL, BUF = XB + NDP * 1024, PER = NXP + (Q2M_NODIG ? 0 : NDP), NSC = SC ? 4 : 1;
     static_assert((Q2M_NBUF - 1) * PER <= 63, "the in-flight DMA pieces must fit the 6-bit vmcnt");
     const int lane = threadIdx.x;
     const int cg = b % v.ncg, sp = b / v.ncg;
@@ -426,8 +429,10 @@ __device__ __forceinline__ void dotq2m512_tile(const dq_view &v, char *smem, int
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)buf * BUF));
 #pragma unroll
         for (int i = 0; i < NXP; i++) hbq_dma16<Q2M_NT != 0>(voff, xs + (int64_t)(8 * i) * ld2, dst + i * XSL);
+        if constexpr (!Q2M_NODIG) {
 #pragma unroll
-        for (int j = 0; j < NDP; j++) hbq_dma16<false>(doff[j], ds, dst + XB + j * 1024);
+            for (int j = 0; j < NDP; j++) hbq_dma16<false>(doff[j], ds, dst + XB + j * 1024);
+        }
     };
     hb_v4i C[4][NSC];
 #pragma unroll

@@ -170,6 +170,8 @@ int hbk_init_attrs()
 #define HB_GROUP_ATTR16(K1, DM, FW, CH) HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<K1, DM, FW, CH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     HB_GROUP_ATTR(1, 8, 14, 3); HB_GROUP_ATTR(1, 8, 7, 4); HB_GROUP_ATTR(1, 2, 4, 10); HB_GROUP_ATTR(1, 1, 2, 20);
     HB_GROUP_ATTR(3, 1, 2, 20); HB_GROUP_ATTR(7, 1, 2, 20);
+    HB_GROUP_ATTR(3, 8, 14, 3); HB_GROUP_ATTR(3, 8, 7, 4); HB_GROUP_ATTR(3, 2, 4, 10); // round 6: BayesR (K <= 4 classes) on the group chain at every shape
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 8, 7, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_GROUP_ATTR16(1, 8, 7, 4);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 8, 7, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -685,7 +687,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     chain_view cv{c->m_pad, c->P, c->nsplit, Lv, c->Lg, c->xpx, c->vx, c->g, c->tracker, c->nzrate, c->alpha_sum, c->alpha_sq,
                   c->thr, c->invv, c->sdz, c->gram, c->partial, c->dsum, c->ev_count, c->ev_idx, c->ev_delta, c->acc,
                   c->wind, c->wflag, c->dbg, fx ? c->mb : nullptr, xabs};
-    const bool g16 = c->gram16_ok && c->gram16 != nullptr; // (the compact band: only the wide group chain and its k_fwd read it)
+    const bool g16 = c->gram16_ok && c->gram16 != nullptr && kp == 1; // (the compact band: only the wide group chain and its k_fwd read it)
     if (g16) { cv.gram16 = c->gram16; cv.ga = c->ga; cv.gB = c->gB; }
     const bool cert = !g16 && c->gcert_ok && c->gcmax != nullptr; // (the wide group chain's certified violation check)
     if (cert) { cv.ga = c->ga; cv.gB = c->gB; cv.gcmax = c->gcmax; }
@@ -702,10 +704,14 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // (chain_kind bit 0: BayesB / BayesC; bit 1: the dense models too — BayesR and RR / A / L at one panel per group)
     const int shape = (D <= 1 && Lv * D <= 2) ? 2 : (D <= 2 && Lv * D <= 4) ? 1 : (D <= 8 && Lv * D <= 14) ? 0 : (c->fwd_group && Lv == 3 && D == 7 && c->P == 512) ? 0 : -1;
     const bool sparse_model = kp == 1 && (model == 3 || model == 4);
-    const bool group_chain = !dense && shape >= 0 && !c->chain_alone && (sparse_model ? (c->chain_kind & 1) != 0 : ((c->chain_kind & 2) != 0 && shape == 2));
+    // round 6: BayesR with up to four classes (kp == 3) runs the group chain too wherever a launch covers more than one panel (chain_kind bit 2
+    // clear; HB_CHAIN=panel keeps k_chain_persist). K1 nested thresholds per candidate instead of one; everything else — candidates, certificate
+    // (it bounds the right-hand side, not the class), fold, k_fwd — is the point-mass models' path.
+    const bool mix_model = kp == 3 && model == 6 && D >= 2;
+    const bool group_chain = !dense && shape >= 0 && !c->chain_alone && (sparse_model ? (c->chain_kind & 1) != 0 : mix_model ? c->chain_kind != 0 : ((c->chain_kind & 2) != 0 && shape == 2));
     // k_fwd beside the wide group chain: the chain folds a move into its own group and the next (15 rows, four moves per trip),
     // a second workgroup into the group after that (HB_FWD=0: the chain does all 22 rows itself, three moves per trip)
-    const bool fwd = group_chain && kp == 1 && (Lv == 2 || Lv == 3) && D == 7 && c->P == 512 && c->fwd_group && !alone;
+    const bool fwd = group_chain && (kp == 1 || mix_model) && (Lv == 2 || Lv == 3) && D == 7 && c->P == 512 && c->fwd_group && !alone;
     if (fwd) pv.fcorr = c->fcorr;
     if (c->L > HB_LBMAX && !fwd)
         return hb_fail(HB_ERR_UNSUPPORTED, "three groups of seven panels of look-ahead need the group chain with k_fwd (BayesB / BayesC, panel 512)");
@@ -725,7 +731,13 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         }
         if (group_chain) {
             const size_t sm = persist_smem(c->P);
-            if (fwd && g16) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            if (mix_model) {
+                if (fwd && cert) hipLaunchKernelGGL((k_chain_group<3, 8, 7, 4, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+                else if (fwd) hipLaunchKernelGGL((k_chain_group<3, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+                else if (shape == 0) hipLaunchKernelGGL((k_chain_group<3, 8, 14, 3>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+                else hipLaunchKernelGGL((k_chain_group<3, 2, 4, 10>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv); // (shape 1: D = 2; shape 2 needs D <= 1)
+            }
+            else if (fwd && g16) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (fwd && cert) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (fwd) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (kp == 1 && shape == 0) hipLaunchKernelGGL((k_chain_group<1, 8, 14, 3>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);

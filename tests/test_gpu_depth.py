@@ -112,8 +112,9 @@ def test_two_bit_resident_layout_is_the_same_chain(big, model, Pi, fold, geo, pa
     m = X.shape[1]
     kw = dict(fold=fold, niter=6, nburn=0, thin=1, seed=1357)
     ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, **kw)
-    r8 = H.Bayes(y, X, model, Pi, verbose=False, panel=panel, **kw)
+    r8 = H.Bayes(y, X, model, Pi, verbose=False, panel=panel, genotype_bits=8, **kw)
     r2 = H.Bayes(y, X, model, Pi, verbose=False, panel=panel, genotype_bits=2, **kw)
+    assert (r8["timing"]["resident_bits"], r2["timing"]["resident_bits"]) == (8, 2)
     _compare(r2, ref)
     for k in ("alpha", "pip", "g", "pi"):
         assert np.array_equal(r2[k], r8[k]), k
@@ -130,6 +131,30 @@ def test_two_bit_resident_layout_is_the_same_chain(big, model, Pi, fold, geo, pa
         rd = H.Bayes(y, None, model, Pi, verbose=False, g_init=g0, ctx=c, **kw)
         assert c.layout() == (2, False)
     _compare(rd, refd)
+
+
+def test_auto_layout_picks_two_bits_where_exact_and_faster_and_is_the_same_chain(big):
+    """hb_bayes_args.genotype_bits = 0 — what ibrm(), the Rcpp shim and Bayes() pass — is "auto" since round 6 (round-5 verdict: "make the
+    fast layout the default where it is exact"): 2 bits per genotype resident for BayesB / BayesC at panel 512 when every code is in
+    0..3, int8 columns for the other models and for other codes (the reference also accepts -1/0/1). Whatever it picks
+    is the forced-int8 chain bit for bit, and the result says which layout ran."""
+    X, y = big["X"][:, :16384], big["y"]
+    kw = dict(niter=5, nburn=0, thin=1, seed=4242, verbose=False)
+    ra = H.Bayes(y, X, "BayesCpi", [0.95, 0.05], **kw)
+    r8 = H.Bayes(y, X, "BayesCpi", [0.95, 0.05], genotype_bits=8, **kw)
+    assert (ra["timing"]["resident_bits"], r8["timing"]["resident_bits"]) == (2, 8)
+    for k in ("alpha", "pip", "g", "pi"):
+        assert np.array_equal(ra[k], r8[k]), k
+    assert np.array_equal(ra["MCMCsamples"]["alpha"], r8["MCMCsamples"]["alpha"])
+    # codes -1/0/1: not representable at 2 bits -> int8, silently (forcing 2 is refused with a text, as before)
+    Xs = (X[:, :8192] - 1).astype(np.int8)
+    rs = H.Bayes(y, Xs, "BayesCpi", [0.95, 0.05], **kw)
+    assert rs["timing"]["resident_bits"] == 8
+    with pytest.raises(H.HibayesError, match="codes 0..3"):
+        H.Bayes(y, Xs, "BayesCpi", [0.95, 0.05], genotype_bits=2, **kw)
+    # a model whose launches cover one panel (chain-bound): int8; a small problem (panel < 512): int8
+    assert H.Bayes(y, X[:, :8192], "BayesR", [0.95, 0.02, 0.02, 0.01], fold=[0, 1e-4, 1e-3, 1e-2], **kw)["timing"]["resident_bits"] == 8
+    assert H.Bayes(y, X[:, :2048], "BayesCpi", [0.95, 0.05], **kw)["timing"]["resident_bits"] == 8
 
 
 @pytest.mark.parametrize("model,Pi,fold,geo", [CASES[0], CASES[2]])
