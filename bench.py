@@ -143,6 +143,11 @@ def parse():
                          "yet: ~30 000 markers in the model, ~49 000 moves per sweep) and again after this many MORE sweeps, continued from "
                          "the first leg's state (nnz ~2 000-5 000: the regime a 50 000-iteration run lives in); 0 (default since round 6: the leg is "
                          "43 of the bench's 57 seconds) = first figure only; 2500 = round 5's converged leg")
+    ap.add_argument("--secondary-state", default=os.path.join("profiles", "state", "bayesr_config3.npz"),
+                    help="a stored chain state of the secondary model on THIS synthetic data (sparse effects + hyper-parameters after 2 800 sweeps; written "
+                         "by --save-state, checked against n / m / seed / model): the `converged` leg continues from it (hb_warm_state, 40 untimed sweeps first) "
+                         "instead of spending 40 s on its own burn-in; used when --burnin-converged is 0 and the file matches")
+    ap.add_argument("--save-state", default="", help="write the secondary model's state after its converged leg (needs --burnin-converged > 0) to this .npz")
     ap.add_argument("--stamped", type=int, default=10,
                     help="sweeps run right after the timed region with every block of every mat-vec launch stamped on the device's "
                          "100 MHz clock (hb_ctx_matvec_stamps): the in-situ launch duration the roofline is computed from")
@@ -840,6 +845,23 @@ def main():
                 res.setdefault(key, []).append(blk)
             else:
                 res[key] = blk
+                st_path = os.path.join(ROOT, args.secondary_state) if args.secondary_state else ""
+                st = None
+                if args.burnin_converged == 0 and st_path and os.path.exists(st_path):
+                    z = np.load(st_path)
+                    if (int(z["n"]), int(z["m"]), int(z["seed"]), str(z["model"])) == (n, m, args.seed, side) and len(z["pi"]) == len(prior(side)[0]):
+                        st = z
+                if st is not None:
+                    from hibayes_amd._lib import WarmState
+                    g3 = np.zeros(m)
+                    g3[st["idx"]] = st["val"]
+                    warm3 = WarmState.make(float(st["mu"]), float(st["vare"]), float(st["varg"]), [float(x) for x in st["pi"]])
+                    el3, ev3, nnz3, miss3 = measure(H, L, ctx, y2, side, K2, SIDE_WARMUP, args, rank, local_rank, world, m_offset, m_global, comm, torch, note,
+                                                    burn=0, g_init=g3, warm=warm3)
+                    blk["converged"] = leg_block(side, el3, K2, SIDE_WARMUP, ev3, nnz3, miss3, measure.insitu, iso2, launches2, cols2, bits2, 0, geo2, int(st["sweeps"]))
+                    blk["converged"]["note"] = ("continued (effects + hyper-parameters, hb_warm_state) from the state stored in %s: this model on this synthetic data after %d sweeps "
+                                                "— the chain has found the signal, few markers are left in the model; %d untimed sweeps first"
+                                                % (args.secondary_state, int(st["sweeps"]), SIDE_WARMUP))
                 if args.burnin_converged > 0:
                     g2, warm2 = measure.final
                     el3, ev3, nnz3, miss3 = measure(H, L, ctx, y2, side, K2, W2, args, rank, local_rank, world, m_offset, m_global, comm, torch, note,
@@ -850,6 +872,14 @@ def main():
                                                  burn_s + W2 + K2 + args.stamped + 1 + args.burnin_converged, curve3)
                     blk["converged"]["note"] = ("the same run continued (effects + hyper-parameters, hb_warm_state) for %d more sweeps: the chain has "
                                                 "found the signal, few markers are left in the model" % args.burnin_converged)
+                    if args.save_state and rank == 0:
+                        g4, w4 = measure.final
+                        nz = np.flatnonzero(g4)
+                        os.makedirs(os.path.dirname(os.path.abspath(args.save_state)), exist_ok=True)
+                        np.savez_compressed(args.save_state, n=n, m=m, seed=args.seed, model=side, idx=nz.astype(np.int32), val=g4[nz], mu=w4.mu, vare=w4.vare,
+                                            varg=w4.varg, pi=np.array([w4.pi[j] for j in range(len(prior(side)[0]))]),
+                                            sweeps=burn_s + 2 * (W2 + K2 + args.stamped + 1) + args.burnin_converged)
+                        note("state of %s written to %s (%d markers in the model)" % (side, args.save_state, nz.size))
                     blk["note"] = ("measured %d sweeps after a cold start, where the chain has not found the signal yet (tens of thousands of markers "
                                    "in the model, see state_after); `converged` is the later regime" % burn_s)
         except Exception as e:

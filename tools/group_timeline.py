@@ -34,6 +34,14 @@ if fold is not None:
     fv = np.array(fold); a.fold, a.n_fold = fv.ctypes.data, fv.size
 a.niter, a.nburn, a.thin = burn + 20, 0, 5
 a.seed, a.precise, a.ctx = 20240901, 2, ctx.h
+_keep = []
+if os.environ.get("GT_STATE"):   # start from a stored chain state (bench.py --save-state): the converged regime without its 2 500-sweep burn-in
+    from hibayes_amd._lib import WarmState
+    z = np.load(os.environ["GT_STATE"])
+    g0 = np.zeros(m); g0[z["idx"]] = z["val"]
+    w0 = WarmState.make(float(z["mu"]), float(z["vare"]), float(z["varg"]), [float(x) for x in z["pi"]])
+    a.g_init, a.warm = g0.ctypes.data, ct.addressof(w0)
+    _keep += [g0, w0]
 run = ct.c_void_p(); check(L.hb_run_create(ct.byref(a), ct.byref(run)))
 fin = ct.c_int32()
 check(L.hb_run_step(run, burn, ct.byref(fin)))
