@@ -64,6 +64,9 @@
 // the full fold and the exact check as before. Decisions and move lists are the plain path's; where a group needs one round (the stationary
 // regime) every sum is too, bit for bit; where the two paths cut a crowded group into rounds differently the forward sums are grouped
 // differently and effects agree to the last bits' rounding (tests: HB_CERT=0 against 1).
+#ifndef HBG_CH2MAX
+#define HBG_CH2MAX 15
+#endif
 #ifndef HBG_CERT_MARGIN
 #define HBG_CERT_MARGIN 1.0
 #endif
@@ -348,12 +351,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             };
 #pragma unroll
             for (int q = 0; q < 8; q++) gq[q] = 0;
+            const int nq = (ncr + 7) >> 3; // (uniform) blocks of eight rows of cg that hold anything: rows k >= ncr are never read
             if (wide) {
                 gq[0] = gather_one(0); // rows k < 8: all there is up to eight candidates (the usual round)
-                if (ncr > 8) {         // (uniform)
 #pragma unroll
-                    for (int q = 1; q < 8; q++) gq[q] = gather_one(q);
-                }
+                for (int q = 1; q < 8; q++)
+                    if (q < nq) gq[q] = gather_one(q); // (round 6: seven unconditional batches above eight candidates cost BayesR's 17-candidate rounds five batches of index arithmetic for nothing)
             }
             for (unsigned left = inrm; __any(left != 0u);) {
                 const bool mine = left != 0u;
@@ -392,9 +395,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             if (wide) {
                 if (t < ncr * 64) cg[t] = ((t >> 6) < (t & 63) && (t & 63) < ncr) ? gq[0] : 0;
-                if (ncr > 8) {
 #pragma unroll
-                    for (int q = 1; q < 8; q++) {
+                for (int q = 1; q < 8; q++) {
+                    if (q < nq) {
                         const int idx = t + q * 512, k = idx >> 6, c = idx & 63;
                         if (idx < ncr * 64) cg[idx] = (k < c && c < ncr) ? gq[q] : 0;
                     }
@@ -447,7 +450,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     gn = (q >= cthr[0]) ? gsel : 0.0;
                     if (K1 == 1 && model == 5 && fabs(gn) < 1e-6) gn = 1e-6; // src/Bayes.cpp:728
                 };
+                // (Round 6, measured and dropped — profiles/r06_spec_serial.txt: the loop on SPECULATED classes, a step being fma - subtract - readlane - fma
+                // and the decision checked afterwards. The genotypes are not centred: one move shifts every later right-hand side by n mean_k mean_c
+                // times its change — a large part of the distance to a threshold — so a candidate's class at the start of a block of four steps is wrong
+                // for one block in 2.4 (from the opening value: worse), and the re-runs cost more than the 270-cycle steps they replace.)
                 int rnext = cg[lane]; // row k of cg, one step ahead
+                HBG_MARK(21); // (cycles into the serial phase: the candidates' data are in registers)
                 for (int k = 0; k < ncr; k++) {
                     const int rcur = rnext;
                     rnext = cg[min(k + 1, ncr - 1) * 64 + lane];
@@ -457,6 +465,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const double dk = readlane_f64(gn - cgold, k);
                     crhs = fma(-(double)rcur, dk, crhs); // (row k is zero at and before lane k; a marker that stays adds an exact zero)
                 }
+                HBG_MARK(22); // (... the serial loop is done)
                 int cls;
                 double gn;
                 decide(crhs, cls, gn); // lane k's rhs was not touched after its own step: its outcome, for all lanes at once
@@ -491,22 +500,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         // (lane ncr - 1 of row 0 holds the totals; lanes of the other rows hold zeros)
                         e = readlane_f64(e, ncr - 1);
                         am = readlane_f64(am, ncr - 1);
-                    } else {
-#pragma unroll 1
-                        for (int o = 1; o < ncr; o <<= 1) {
-                            const double up = __shfl_up(w, o, 64);
-                            if (lane >= o) w += up;
-                        }
-                        am = lane < ncr ? fabs(w) : 0.0;
-#pragma unroll 1
-                        for (int o = 32; o > 0; o >>= 1) {
-                            am = fmax(am, __shfl_xor(am, o, 64));
-                            e += __shfl_xor(e, o, 64);
-                        }
+                    } else { // (lanes at and past ncr hold zeros: the scans run over the whole wave)
+                        w = wave_scan_incl_f64(w);
+                        am = readlane_f64(wave_scan_max_f64(fabs(w)), 63);
+                        e = readlane_f64(wave_scan_incl_f64(e), 63);
                     }
                     if (lane < ncr) spre[lane + 1] = w;
                     if (lane == 0) { spre[0] = 0.0; spre[66] = e; spre[67] = am; }
                 }
+                HBG_MARK(23); // (... wave 0 is at the barrier)
             }
             if constexpr (CERT) {
                 if (stage_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the pieces have landed: these waves had nothing else to do)
@@ -583,7 +585,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const gram_t *gbase = G16 ? reinterpret_cast<const gram_t *>(v.gram16) + (size_t)gp0 * (pv.Lg + 1) * PP : reinterpret_cast<const gram_t *>(gblk0);
             if (CERT && !need_full) {
                 // every passed-over marker is proven to stay and the round reaches the group's end: only the next group's panels need the moves
-                constexpr int CH2 = (63 / HBG_FW) < 8 ? (63 / HBG_FW) : 8;
+                // (rows requested together: at most 63 loads per lane; round 6: up to 15 moves per trip where a move has few rows — BayesR's 16 moves per
+                // two-panel group were two dependent trips of ~4 500 cycles each beside the streaming mat-vec)
+                constexpr int CH2 = (63 / HBG_FW) < HBG_CH2MAX ? (63 / HBG_FW) : HBG_CH2MAX;
                 if (have_fw) {
 #pragma unroll 1
                     for (int e0 = 0; e0 < nmoves; e0 += CH2) {

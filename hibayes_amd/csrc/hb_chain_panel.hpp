@@ -62,6 +62,38 @@ __device__ __forceinline__ double dpp_row_shr_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// the two wave-wide DPP moves of a 64-lane scan, on a double: row_bcast:15 (lane 15 of a row to the next row; rows 1 and 3 take it) and
+// row_bcast:31 (lane 31 to rows 2 and 3); every other lane gets +0.0
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_bcast_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum / running maximum (of non-negative values) over the 64 lanes of a wave, no LDS round trip (round 6: the certificate's
+// scans above sixteen candidates were five __shfl_up and twelve __shfl_xor round trips, ~2 000 cycles of a BayesR pass)
+__device__ __forceinline__ double wave_scan_incl_f64(double v)
+{
+    v += dpp_row_shr_f64<1>(v);
+    v += dpp_row_shr_f64<2>(v);
+    v += dpp_row_shr_f64<4>(v);
+    v += dpp_row_shr_f64<8>(v);
+    v += dpp_bcast_f64<0x142, 0xa>(v);
+    v += dpp_bcast_f64<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ double wave_scan_max_f64(double v)
+{
+    v = fmax(v, dpp_row_shr_f64<1>(v));
+    v = fmax(v, dpp_row_shr_f64<2>(v));
+    v = fmax(v, dpp_row_shr_f64<4>(v));
+    v = fmax(v, dpp_row_shr_f64<8>(v));
+    v = fmax(v, dpp_bcast_f64<0x142, 0xa>(v));
+    v = fmax(v, dpp_bcast_f64<0x143, 0xc>(v));
+    return v;
+}
+
 // inclusive prefix sum over the 64 lanes of a wave without an LDS round trip per step: four row_shr steps inside the rows of 16, then the row
 // totals handed on by row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3) — the gfx9 wave-wide DPP modes
 __device__ __forceinline__ int wave_scan_incl(int v)

@@ -571,6 +571,14 @@ int hb_ctx_get_layout(const hb_ctx *c, int32_t *bits, int32_t *int8_resident)
 
 int hb_ctx_set_pipeline(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t dotgroup)
 {
+    int rc = hb_ctx_switch_geometry(c, pipeline, lookahead, dotgroup);
+    if (!rc) { c->home_lv = c->Lv; c->home_d = c->D; } // (what an adaptive run returns to: hb_run.hip)
+    return rc;
+}
+
+} // extern "C"
+int hb_ctx_switch_geometry(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t dotgroup)
+{
     int rc = check_cols(c, 0, 0, "hb_ctx_set_pipeline");
     if (rc) return rc;
     if (c->env_pinned && c->concurrent && !c->force_geometry) return HB_OK; // HB_PIPELINE / HB_LOOKAHEAD / HB_DOTGROUP in the environment win (tuning runs)
@@ -584,6 +592,7 @@ int hb_ctx_set_pipeline(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t 
     if (c->L > c->Lg) c->gram_ready = false;
     return HB_OK;
 }
+extern "C" {
 
 int hb_ctx_set_adaptive(hb_ctx *c, int32_t on)
 {

@@ -117,6 +117,7 @@ struct hb_ctx {
     bool gram_ready = false, stats_ready = false;
     int Lg = 0;       // band blocks per panel (minus one) the stored gram[] was built with: every geometry with L <= Lg runs on it
     bool adaptive = false; // hb_run picks the geometry per sweep from the number of moves (hb_ctx_set_adaptive)
+    int home_lv = 0, home_d = 0; // the geometry its owner gave an adaptive context (hb_ctx_set_pipeline): a run that left it in its narrow geometry is followed by one that starts from this again
     int *xinfo = nullptr; // device: [0]=min value, [1]=max value over X
     int xmin = 0, xmax = 0;
 
@@ -214,6 +215,7 @@ int hbk_time_stream_read(hb_ctx *c, int reps, double *avg_ms, int64_t *bytes);
 int hbk_copy_segs(hb_ctx *c, const std::vector<hb_ctx::snap_seg> &segs, bool restore);
 
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed);
+int hb_ctx_switch_geometry(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t dotgroup); // hb_ctx_set_pipeline without touching home_lv / home_d (hb_run's per-sweep choice)
 extern "C" int hb_ctx_sweep_range(hb_ctx *c, const hb_sweep_in *in, int block, int nblocks);
 extern "C" int hb_ctx_sweep_begin(hb_ctx *c, const hb_sweep_in *in);
 extern "C" int hb_ctx_sweep_end(hb_ctx *c, hb_sweep_out *out);

@@ -172,6 +172,8 @@ int hbk_init_attrs()
     HB_GROUP_ATTR(3, 1, 2, 20); HB_GROUP_ATTR(7, 1, 2, 20);
     HB_GROUP_ATTR(3, 8, 14, 3); HB_GROUP_ATTR(3, 8, 7, 4); HB_GROUP_ATTR(3, 2, 4, 10); // round 6: BayesR (K <= 4 classes) on the group chain at every shape
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 8, 7, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 2, 4, 10, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 4, 8, 5, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_GROUP_ATTR16(1, 8, 7, 4);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 8, 7, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -734,7 +736,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
             if (mix_model) {
                 if (fwd && cert) hipLaunchKernelGGL((k_chain_group<3, 8, 7, 4, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
                 else if (fwd) hipLaunchKernelGGL((k_chain_group<3, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+                else if (cert && c->P == 512 && D <= 4 && Lv * D <= 8 && !(D <= 2 && Lv * D <= 4) && !getenv("HB_CERT_NARROW_OFF"))
+                    hipLaunchKernelGGL((k_chain_group<3, 4, 8, 5, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv); // (three or four panels per launch, certified)
                 else if (shape == 0) hipLaunchKernelGGL((k_chain_group<3, 8, 14, 3>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+                else if (cert && c->P == 512 && !getenv("HB_CERT_NARROW_OFF")) hipLaunchKernelGGL((k_chain_group<3, 2, 4, 10, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv); // (shape 1: D = 2, certified)
                 else hipLaunchKernelGGL((k_chain_group<3, 2, 4, 10>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv); // (shape 1: D = 2; shape 2 needs D <= 1)
             }
             else if (fwd && g16) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);

@@ -95,9 +95,11 @@ struct hb_run {
     bool recover_on = true;    // replay a sweep whose pipeline timed out (HB_RECOVER=0: fail the run, as before round 4)
     int aborts = 0;            // sweeps replayed so far
     int abort_win_start = 0, abort_win_count = 0, slow_timeout = 0; // three aborts within 64 iterations: a slow device, the run's time-out is raised
-    bool adaptive_geo = false; // choose (Lv, D) per sweep from the previous sweep's moves (BayesB/C)
+    bool adaptive_geo = false; // choose (Lv, D) per sweep from the previous sweep's moves (BayesB/C; round 6: BayesR)
     int geo_wide_lv = 2;       // look-ahead groups of the wide geometry (3 with k_fwd beside the chain, else 2)
-    int geo_cur = 0;           // 0: (2, 7), 1: (2, 2)
+    int geo_cur = 0;           // 0: the wide geometry — (2 | 3, 7) for BayesB / C, (2, 2) for BayesR; 1: the narrow one — (2, 2), (2, 1)
+    int geo_wide_d = 7, geo_narrow_lv = 2, geo_narrow_d = 2;
+    double geo_to_wide = 2.0, geo_to_narrow = 2.6; // moves per panel of the previous sweep below / above which the geometry changes
     double last_events_pp = 0;
     bool done = false;
     double setup_seconds = 0, gram_seconds = 0, loop_seconds = 0;
@@ -485,7 +487,9 @@ int hb_run::setup(const hb_bayes_args *args)
             rc = hb_ctx_set_pipeline(c, 1, a.genotype_bits == 2 ? 3 : 2, 7); // ((2, 7) where k_fwd is not available: panels other than 512)
         else if (always_in && c->P == 512) // k_chain_dense: two panels per launch (45.6 against 39.4 sweeps/s at n=50k, m=500k; (1, 1) 24.8, (1, 2) 27.7)
             rc = hb_ctx_set_pipeline(c, 1, 2, 2);
-        else rc = hb_ctx_set_pipeline(c, 1, 2, 1); // (BayesR; RR / A / L on small panels: the second group of look-ahead hides the update + launch boundary)
+        else if (model_index == 6 && n_fold <= 4 && c->P == 512 && !getenv("HB_NO_ADAPTIVE_R")) // BayesR: (2, 2) stored, (2, 1) while many markers move (geometry by regime, below)
+            rc = hb_ctx_set_pipeline(c, 1, 2, 2);
+        else rc = hb_ctx_set_pipeline(c, 1, 2, 1); // (BayesR with more classes; RR / A / L on small panels: the second group of look-ahead hides the update + launch boundary)
         if (rc) return rc;
         if (a.X_i8) rc = hb_ctx_upload_genotype_i8(c, a.X_i8, a.ld_i8, 0, m);
         else rc = hb_ctx_upload_genotype_f64(c, a.X_f64, a.ld_f64, 0, m);
@@ -596,12 +600,30 @@ int hb_run::setup(const hb_bayes_args *args)
         rc = hb_ctx_set_layout(c, 2, 0);
         if (rc) return rc;
     }
+    if (!own_ctx && c->adaptive && c->pipeline && c->home_d > 0 && (c->home_lv != c->Lv || c->home_d != c->D) && !rowmode) {
+        // an adaptive context that an earlier run left in its narrow geometry: start from the geometry its owner set (round 6: a second fit
+        // on the same context used to stay narrow for good, because only the wide geometry switches adaptivity on)
+        rc = hb_ctx_switch_geometry(c, 1, c->home_lv, c->home_d);
+        if (rc) return rc;
+    }
     {   // geometry by regime: only from the wide-band geometry of the point-mass models, whose stored band serves the narrow one
         int32_t gp = 0, gl = 0, gd = 0, gb = 0;
         (void)hb_ctx_get_pipeline(c, &gp, &gl, &gd, &gb);
         adaptive_geo = (model_index == 3 || model_index == 4) && (own_ctx || c->adaptive) && gp == 1 && (gl == 2 || gl == 3) && gd == 7 && c->Lg >= 20;
         geo_wide_lv = gl;
         geo_cur = 0;
+        // round 6, BayesR with up to four classes at panel 512: two panels per launch and the certified group chain (k_chain_group<3, 2, 4, 10>)
+        // once fewer than ~17 markers a panel move, one panel per launch and the per-panel chain with its row cache (k_chain_persist) above ~21
+        // (measured at n = 50k, m = 500k from a cold start, profiles/r06_bayesr_regime.txt: they cross at 19 moves per panel — 47.5 sweeps/s both;
+        // at 51: 37 against 54; at 11: 68 against 60; at 8: 85 against 69)
+        if (model_index == 6 && n_fold <= 4 && c->P == 512 && (own_ctx || c->adaptive) && gp == 1 && gl == 2 && gd == 2 && c->Lg >= 5 && !getenv("HB_NO_ADAPTIVE_R")) {
+            adaptive_geo = true;
+            geo_wide_d = 2;
+            geo_narrow_lv = 2;
+            geo_narrow_d = 1;
+            geo_to_wide = 17.0;
+            geo_to_narrow = 21.0;
+        }
         if (adaptive_geo) { // the first sweep: as many moves as markers are expected in the model (a cold start) or are in it
             double nz = 0;
             for (double gv : g_init) nz += gv != 0.0;
@@ -804,10 +826,10 @@ int hb_run::step()
     if (adaptive_geo) {
         const double pp = last_events_pp; // moves per panel of the previous sweep on this shard
         int want = geo_cur;
-        if (geo_cur == 1 && pp < 2.0) want = 0;       // -> (2, 7)
-        else if (geo_cur == 0 && pp > 2.6) want = 1;  // -> (2, 2)
+        if (geo_cur == 1 && pp < geo_to_wide) want = 0;         // -> (2 | 3, 7); BayesR: (2, 2)
+        else if (geo_cur == 0 && pp > geo_to_narrow) want = 1;  // -> (2, 2); BayesR: (2, 1)
         if (want != geo_cur) {
-            rc = hb_ctx_set_pipeline(c, 1, want == 0 ? geo_wide_lv : 2, want == 0 ? 7 : 2);
+            rc = hb_ctx_switch_geometry(c, 1, want == 0 ? geo_wide_lv : geo_narrow_lv, want == 0 ? geo_wide_d : geo_narrow_d);
             if (rc) return rc;
             geo_cur = want;
         }
@@ -832,7 +854,7 @@ int hb_run::step()
             c->timeout_ms = timeout_ms;
             if (fell_back) {
                 c->force_geometry = true;
-                (void)hb_ctx_set_pipeline(c, geo[0], geo[1], geo[2]);
+                (void)hb_ctx_switch_geometry(c, geo[0], geo[1], geo[2]);
                 c->force_geometry = false;
             }
         }
@@ -882,7 +904,7 @@ int hb_run::step()
         if (attempt >= 1 && !guard.fell_back) {
             (void)hb_ctx_get_pipeline(c, &guard.geo[0], &guard.geo[1], &guard.geo[2], &guard.geo[3]);
             c->force_geometry = true;
-            const int rc2 = hb_ctx_set_pipeline(c, 0, 0, 1);
+            const int rc2 = hb_ctx_switch_geometry(c, 0, 0, 1);
             c->force_geometry = false;
             if (rc2) return rc2;
             guard.fell_back = true;

@@ -129,7 +129,7 @@ def c3():
     c.close()
 
 
-def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=2, dense=0.0, shared=None, bits=8, adaptive=False, stationary=0):
+def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=2, dense=0.0, shared=None, bits=8, adaptive=False, stationary=0, installed_pi=None):
     """dense > 0: the chain starts from an installed state with that fraction of the markers in the model (g_init on both
     sides): crowded rounds, row-cache misses and band folds of hundreds of moves per mat-vec group from the first panel on.
     bits = 2: the sweep runs on the 2-bit resident layout with the int8 copy dropped after the Gram build, as bench.py's headline does.
@@ -162,6 +162,8 @@ def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=
             on = rs.choice(m, int(dense * m), replace=False)
             g0[on] = rs.normal(0, 0.01, on.size)
             kw["g_init"] = g0
+            if installed_pi is not None:   # ... and the hyper-parameters of a chain that has found the signal (hb_warm_state on both sides)
+                kw["warm"] = dict(mu=float(np.mean(y)), vare=float(0.6 * np.var(y)), varg=5e-5, pi=list(installed_pi))
         if stationary > 0:
             pre = H.Bayes(y, None, model, Pi, verbose=False, precise=precise, ctx=c, store_alpha=False,
                           **dict(kw, niter=stationary, nburn=stationary - 1, seed=777))
@@ -201,18 +203,30 @@ def test_config3_bayescpi_n50k_m500k_draw_for_draw_against_live_oracle(c3, geo, 
     _full_size_vs_oracle(50000, 500000, "BayesCpi", [0.95, 0.05], None, geo, 0, shared=c3, bits=bits)
 
 
-def test_config3_bayesr_n50k_m500k_draw_for_draw_against_live_oracle(c3):
-    """BASELINE.json configs[2] is BayesR at n=50k, m=500k: its own model, at its own size and default geometry, against the
-    live oracle (reference src/Bayes.cpp:743-815) — 2 sweeps from cold, ~47 moves per panel."""
-    _full_size_vs_oracle(50000, 500000, "BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 0, shared=c3)
+@pytest.mark.parametrize("geo", [(1, 2, 1), (1, 2, 2)])
+def test_config3_bayesr_n50k_m500k_draw_for_draw_against_live_oracle(c3, geo):
+    """BASELINE.json configs[2] is BayesR at n=50k, m=500k: its own model, at its own size, against the live oracle (reference
+    src/Bayes.cpp:743-815) — 2 sweeps from cold, ~47 moves per panel: in the geometry a run holds in that regime ((2, 1), k_chain_persist)
+    and, round 6, on the group chain it switches to once few markers move ((2, 2): here its crowded path — rounds of 64 candidates,
+    the full fold and the exact check)."""
+    _full_size_vs_oracle(50000, 500000, "BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], geo, 0, shared=c3)
 
 
 @pytest.mark.parametrize("model,Pi,fold,geo,bits,sweeps", [("BayesCpi", [0.95, 0.05], None, (1, 3, 7), 2, 300),
-                                                           ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 8, 150)])
+                                                           ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 8, 150),
+                                                           ])
 def test_config3_stationary_state_against_live_oracle(c3, model, Pi, fold, geo, bits, sweeps):
     """n = 50k, m = 500k IN the regime `value` is measured in: 300 sweeps of burn-in on the GPU (bench.py's --burnin until the last run of round 5, 400 since; BayesR 150),
     then 2 sweeps on both sides from the reported state."""
     _full_size_vs_oracle(50000, 500000, model, Pi, fold, geo, 0, niter=2, shared=c3, bits=bits, adaptive=(bits == 2), stationary=sweeps)
+
+
+def test_config3_bayesr_sparse_state_on_the_group_chain_against_live_oracle(c3):
+    """Round 6: BayesR at n = 50k, m = 500k in the regime its converged leg of bench.py runs in — 0.8 % of the markers in the model and
+    pi0 = 0.992 installed on both sides (these phenotypes keep 30 000 markers in the model for a thousand sweeps; bench.py's find the signal after
+    700) — geometry (2, 2): the certified group chain k_chain_group<3, 2, 4, 10>, ~16 moves per two-panel group, 2 sweeps against the live oracle."""
+    _full_size_vs_oracle(50000, 500000, "BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 2), 0, niter=2, shared=c3, dense=0.008,
+                         installed_pi=[0.992, 0.004, 0.003, 0.001])
 
 
 @pytest.mark.parametrize("model,Pi,fold,geo", [("BayesCpi", [0.95, 0.05], None, (1, 3, 7)),

@@ -35,7 +35,9 @@ def pheno(rng, X, ncausal=40):
 CASES = [  # model, Pi, fold, expected default geometry (pipeline, look-ahead groups, panels per mat-vec)
     ("BayesCpi", [0.95, 0.05], None, (1, 3, 7)),   # (three groups of look-ahead with k_fwd beside the chain: panel 512; else (1, 2, 7))
     ("BayesB", [0.8, 0.2], None, (1, 3, 7)),
-    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1)),
+    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1)),   # k_chain_persist: the geometry a BayesR run holds while many markers move
+    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 2)),   # round 6: the certified group chain (k_chain_group<3, 2, 4, 10>), its geometry once few do
+    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 3, 7)),   # ... and BayesR on the wide group chain with k_fwd (k_chain_group<3, 8, 7, 4>)
     ("BayesRR", [0.95, 0.05], None, (1, 2, 1)),
 ]
 
@@ -335,6 +337,9 @@ def test_dense_update_rows_are_the_old_update_rows_bit_for_bit(big, monkeypatch)
 LONG = [  # model, Pi, fold, geometry, resident bits, adaptive geometry, markers, sweeps, tolerance
     ("BayesCpi", [0.95, 0.05], None, (1, 3, 7), 2, True, 32768, 200, 1e-9),     # (measured on MI355X: 1.4e-15, 1.1e-14, 7e-15 of max |alpha|)
     ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 8, False, 32768, 200, 1e-9),
+    # round 6: BayesR on the certified group chain (k_chain_group<3, 2, 4, 10>) for 200 sweeps (this small problem keeps ~40 moves a panel: its crowded
+    # rounds and its certified ones; the sparse regime and the switch are test_bayesr_geometry_by_regime's)
+    ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 2), 8, False, 32768, 200, 1e-9),
     ("BayesRR", [0.95, 0.05], None, (1, 2, 2), 8, False, 8192 + 100, 100, 1e-9),
 ]
 
@@ -374,6 +379,35 @@ def test_long_chain_draw_for_draw_at_pipeline_depth(big, model, Pi, fold, geo, b
           % (model, niter, niter // 2 // 5, err, r["timing"]["mean_events"], geo_end))
     if adaptive:
         assert geo_end == geo          # the run ended in the wide geometry: the stationary regime was reached and run in
+
+
+def test_bayesr_geometry_by_regime(big):
+    """Round 6: a BayesR run (up to four classes, panel 512) picks its geometry per sweep from the moves of the sweep before — (2, 1) and
+    k_chain_persist while more than ~21 markers a panel move, (2, 2) and the certified group chain below ~17 (hb_run.hip; measured crossing at
+    19, profiles/r06_bayesr_regime.txt). From a cold start (5 % of the markers expected in the model: 26 a panel) the run leaves the stored (2, 2)
+    before its first sweep; from a sparse state with pi0 = 0.995 it stays there; either way it is the oracle's chain draw for draw."""
+    X, y = big["X"][:, :32768], big["y"]
+    m = X.shape[1]
+    Pi, fold = [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2]
+    kw = dict(fold=fold, niter=10, nburn=0, thin=1, seed=6809)
+    rng = np.random.default_rng(77)
+    g0 = np.where(rng.random(m) < 0.004, rng.normal(0, 0.02, m), 0.0)
+    warm = dict(mu=float(y.mean()), vare=float(0.6 * y.var()), varg=2e-4, pi=[0.995, 0.003, 0.0015, 0.0005])
+    for start, expect in (("cold", (1, 2, 1)), ("sparse", (1, 2, 2))):
+        k2 = dict(kw, g_init=g0, warm=warm) if start == "sparse" else kw
+        ref = O.bayes(y, X, "BayesR", Pi, rng=O.RNG_PHILOX, store_alpha=True, **k2)
+        with H.Context(X.shape[0], m, panel=512, seed=6809) as c:
+            c.upload(X)
+            c.set_pipeline(1, 2, 2)
+            c.set_adaptive(True)
+            r = H.Bayes(y, None, "BayesR", Pi, verbose=False, ctx=c, **k2)
+            geo_end = c.pipeline()[:3]
+        print("BayesR from a %s start: %.1f moves per sweep (%.1f per panel), geometry at the end %s" % (start, r["timing"]["mean_events"], r["timing"]["mean_events"] / 64, geo_end))
+        assert geo_end == expect, (start, geo_end)
+        _compare(r, ref)
+        # the one-call boundary (a context of the run's own) takes the same decisions: the same chain
+        r1 = H.Bayes(y, X, "BayesR", Pi, verbose=False, **k2)
+        _compare(r1, ref)
 
 
 @pytest.mark.parametrize("model,Pi,fold", [("BayesCpi", [0.95, 0.05], None), ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2]),

@@ -71,6 +71,8 @@ for name, sel in (("quiet", cand == 0), ("candidates, no move", (cand > 0) & (nm
     print("  %-20s groups %4d period %7.0f cyc (%.1f %% of the sweep) waited for dots %3.0f %% committed rounds %.2f rolled back %.2f repeated %.2f cand %.1f" % (
         name, k, per[sel].mean(), 100 * per[sel].sum() / cyc, 100 * (s[:, 11] > 0).mean(), rounds[sel].mean(), redo[sel].mean(), rep[sel].mean(), cand[sel].mean()))
     print("      " + " | ".join("%s %.0f" % (names[q], s[:, q].mean()) for q in range(10)))
+    if s[:, 21:24].any():
+        print("      inside the serial phase, cycles from its start (accumulated over the passes): data in registers %.0f | loop done %.0f | wave 0 at the barrier %.0f | barrier passed %.0f; speculated blocks run again %.2f" % (s[:, 21].mean(), s[:, 22].mean(), s[:, 23].mean(), s[:, 4].mean(), s[:, 24].mean()))
     if s[:, 18:21].any():
         print("      inside the opening, cycles from its start: prefetch barrier passed %.0f | values in registers %.0f | polled (if at all) %.0f" % tuple(s[:, q].mean() for q in (18, 19, 20)))
 print("moves/sweep %.0f" % info.mean_events)
