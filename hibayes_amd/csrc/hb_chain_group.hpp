@@ -244,6 +244,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         bad = sdf != sdf;
                     }
                     if (!__any(bad)) break;
+                    {   // (advisor finding, round 5) "not delivered" is the sentinel's BIT PATTERN; a delivered word that is a NaN or an infinity (an upstream
+                        // overflow) makes the sum a NaN too and would be polled until the time-out, replayed three times and reported as a time-out. If
+                        // every word of a lane with a NaN sum is there, the fault is numerical: stop now and say so (fetch_acc: h_flags[15])
+                        bool missing = false;
+#pragma unroll
+                        for (int i = 0; i < HBG_DM; i++) missing |= __double_as_longlong(dj[i]) == -1ll || (far_in && __double_as_longlong(fc[i]) == -1ll);
+                        if (__any(bad && !missing)) {
+                            if (lane == 0) { st_flag(pv.flags + 15, 1u); st_flag(pv.flags + HB_FLAG_ABORT, 1u); misc[2] = 1; }
+                            break;
+                        }
+                    }
                     if (ld_flag(pv.flags + HB_FLAG_ABORT) || wall_clock64() - t0 > HB_TIMEOUT_TICKS) {
                         if (lane == 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); misc[2] = 1; }
                         break;

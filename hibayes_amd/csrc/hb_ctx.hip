@@ -872,6 +872,8 @@ static int fetch_acc(hb_ctx *c)
                  c->h_flags[0], c->h_flags[8], c->h_flags[9], c->h_flags[10], c->h_flags[11], c->h_flags[12], c->h_flags[13], c->h_flags[14],
                  c->h_flags[1] ? "" : "; raised on another rank");
         if (getenv("HB_DEBUG_ABORT") && c->h_flags[1]) print_abort_diagnostics(c);
+        if (c->h_flags[15]) // (k_chain_group: every word of a group was delivered and one of them is not finite — a numerical fault upstream, not a lost hand-off)
+            return hb_fail(HB_ERR_ABORTED, std::string("a non-finite right-hand side reached the chain (dot product or correction overflowed): ") + msg);
         return hb_fail(HB_ERR_ABORTED, msg);
     }
     return HB_OK;

@@ -168,9 +168,12 @@ __global__ __launch_bounds__(256) void k_gram16(const int32_t *__restrict__ gram
     int a = 0;
     if (p - l >= 0) a = ga[(size_t)(p - l) * P + k];
     const int4 bq = *reinterpret_cast<const int4 *>(gB + (size_t)p * P + t);
-    const int c0 = gq.x - a * bq.x, c1 = gq.y - a * bq.y, c2 = gq.z - a * bq.z, c3 = gq.w - a * bq.w;
-    const int lo = min(min(c0, c1), min(c2, c3)), hi = max(max(c0, c1), max(c2, c3));
+    // (64-bit: the difference of two int32-range numbers; whatever does not fit a short raises the flag and the band stays int32 only)
+    const long long d0 = (long long)gq.x - (long long)a * bq.x, d1 = (long long)gq.y - (long long)a * bq.y, d2 = (long long)gq.z - (long long)a * bq.z,
+                    d3 = (long long)gq.w - (long long)a * bq.w;
+    const long long lo = min(min(d0, d1), min(d2, d3)), hi = max(max(d0, d1), max(d2, d3));
     if (p - l >= 0 && (lo < -32767 || hi > 32767)) *flag = 1; // (any writer: the band then stays int32 only)
+    const int c0 = (int)d0, c1 = (int)d1, c2 = (int)d2, c3 = (int)d3;
     short4 o;
     o.x = (short)c0; o.y = (short)c1; o.z = (short)c2; o.w = (short)c3;
     *reinterpret_cast<short4 *>(g16 + idx) = o;
@@ -193,8 +196,11 @@ __global__ __launch_bounds__(128) void k_gcmax(const int32_t *__restrict__ gram,
         const int4 gq = *reinterpret_cast<const int4 *>(gram + rowi * P + t4);
         const int4 bq = *reinterpret_cast<const int4 *>(gB + (size_t)p * P + t4);
         // (the diagonal, x_k . x_k, is no pair: a marker's own entry never reaches another marker's right-hand side)
-        const int c0 = (l == 0 && t4 == k) ? 0 : abs(gq.x - a * bq.x), c1 = (l == 0 && t4 + 1 == k) ? 0 : abs(gq.y - a * bq.y);
-        const int c2 = (l == 0 && t4 + 2 == k) ? 0 : abs(gq.z - a * bq.z), c3 = (l == 0 && t4 + 3 == k) ? 0 : abs(gq.w - a * bq.w);
+        // (advisor finding, round 5: in int32 the difference can overflow for int8-coded genotypes near the Gram's own range check — 64-bit, clamped:
+        // a bound of INT32_MAX makes the certificate prove nothing for that marker, which is safe)
+        auto cabs = [](int g, int aa, int b) { const long long d = (long long)g - (long long)aa * (long long)b; const long long m = d < 0 ? -d : d; return (int)(m > 2147483647ll ? 2147483647ll : m); };
+        const int c0 = (l == 0 && t4 == k) ? 0 : cabs(gq.x, a, bq.x), c1 = (l == 0 && t4 + 1 == k) ? 0 : cabs(gq.y, a, bq.y);
+        const int c2 = (l == 0 && t4 + 2 == k) ? 0 : cabs(gq.z, a, bq.z), c3 = (l == 0 && t4 + 3 == k) ? 0 : cabs(gq.w, a, bq.w);
         mx = max(mx, max(max(c0, c1), max(c2, c3)));
     }
 #pragma unroll

@@ -432,6 +432,11 @@ int hb_run::setup(const hb_bayes_args *args)
     if (a.warm) {
         has_warm = true;
         warm_ = *a.warm;
+        // (advisor finding, round 5) hb_warm_state carries mu, vare, varg, pi, lambda2 and the per-marker variances — NOT the fixed-effect or
+        // random-effect state (beta, the level effects, Vr): with C or R the run would restart those at their defaults beside warm marker
+        // effects, which is not a continuation of the same chain. Refused rather than silently half-continued.
+        if (a.nc > 0 || a.nr > 0)
+            return hb_fail(HB_ERR_UNSUPPORTED, "hb_bayes_run: a warm start (hb_warm_state) does not carry the fixed / random effect state: not available with C or R");
         if (!(std::isfinite(warm_.mu) && warm_.vare > 0 && std::isfinite(warm_.vare)))
             return hb_fail(HB_ERR_INVALID, "hb_bayes_run: warm state needs a finite mu and vare > 0");
         if ((model_index == 1 || model_index == 4 || model_index == 6) && !(warm_.varg > 0 && std::isfinite(warm_.varg)))
