@@ -147,6 +147,8 @@ def parse():
                     help="a stored chain state of the secondary model on THIS synthetic data (sparse effects + hyper-parameters after 2 800 sweeps; written "
                          "by --save-state, checked against n / m / seed / model): the `converged` leg continues from it (hb_warm_state, 40 untimed sweeps first) "
                          "instead of spending 40 s on its own burn-in; used when --burnin-converged is 0 and the file matches")
+    ap.add_argument("--init-state", default="", help="start the HEADLINE model's chain from a stored state (.npz written by --save-state for that model on this data) instead of "
+                                                     "the prior defaults: profiling runs of a converged chain (tools/r6_profiles.sh)")
     ap.add_argument("--save-state", default="", help="write the secondary model's state after its converged leg (needs --burnin-converged > 0) to this .npz")
     ap.add_argument("--stamped", type=int, default=10,
                     help="sweeps run right after the timed region with every block of every mat-vec launch stamped on the device's "
@@ -678,7 +680,7 @@ def main():
     if geo == (1, 3, 7) and args.bits != 2:
         geo = (1, 2, 7)  # int8 columns: the sweep is as long as the HBM-bound mat-vec stream, the third group of look-ahead buys nothing (205 vs 200 sweeps/s)
     ctx.set_pipeline(*geo)
-    adaptive = geo in ((1, 2, 7), (1, 3, 7)) and not os.environ.get("HB_NO_ADAPTIVE")
+    adaptive = (geo in ((1, 2, 7), (1, 3, 7)) or (args.model == "BayesR" and geo == (1, 2, 2))) and not os.environ.get("HB_NO_ADAPTIVE")
     if adaptive:
         ctx.set_adaptive(True)  # narrow band while many markers move (burn-in), this geometry once few do (the timed region)
     gram_s = ctx.build_gram()
@@ -695,8 +697,16 @@ def main():
         ctx.set_matvec_kernel(kind_main)
 
     K, W = args.steps, args.warmup
+    g_start = warm_start = None
+    if args.init_state:
+        from hibayes_amd._lib import WarmState
+        z = np.load(args.init_state)
+        assert (int(z["n"]), int(z["m"]), int(z["seed"]), str(z["model"])) == (n, m, args.seed, args.model), "--init-state: not this model / data"
+        g_start = np.zeros(m)
+        g_start[z["idx"]] = z["val"]
+        warm_start = WarmState.make(float(z["mu"]), float(z["vare"]), float(z["varg"]), [float(x) for x in z["pi"]])
     elapsed, mean_events, nnz, misses = measure(H, L, ctx, y, args.model, K, W, args, rank, local_rank, world, m_offset,
-                                        m_global, comm, torch, note, burn=args.burnin)
+                                        m_global, comm, torch, note, burn=args.burnin, g_init=g_start, warm=warm_start)
     replayed_main = getattr(measure, "replayed", 0)
     redo_main = getattr(measure, "redo", None)
     per_rank_main = getattr(measure, "per_rank_ms", None)
