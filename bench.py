@@ -48,14 +48,15 @@ def _r(x, sig=6):
 
 
 def _leg(b, name):
-    """one side leg on the compact line: exactly {leg, model, bits, kernel, value, ms_per_step, frac, regime}"""
+    """one side leg on the compact line: {leg, model, bits, kernel, value, ms_per_step, frac (mat-vec launches in situ), frac_sweep (resident bytes x sweeps/s
+    over the HBM peak; the all-move models: both passes), frac_of_measured_copy, regime}"""
     if not isinstance(b, dict):
         return None
     if "error" in b:
         return {"leg": name, "model": b.get("model"), "error": str(b["error"])[:80]}
     rf = b.get("roofline", {})
     return {"leg": name, "model": b.get("model"), "bits": b.get("resident_genotype_bits"), "kernel": rf.get("kernel"),
-            "value": _r(b.get("value")), "ms_per_step": _r(b.get("ms_per_step")), "frac": _r(rf.get("frac"), 4),
+            "value": _r(b.get("value")), "ms_per_step": _r(b.get("ms_per_step")), "frac": _r(rf.get("frac"), 4), "frac_sweep": _r(b.get("achieved_frac_of_hbm_peak"), 4),
             "frac_of_measured_copy": _r(rf.get("frac_of_measured_copy"), 4), "regime": b.get("regime")}
 
 
@@ -73,6 +74,8 @@ def compact_line(res, full_path):
                                                    "launches_per_sweep", "measured_copy_GBps", "frac_of_measured_copy")}
     line["roofline"]["isolated_frac"] = _r(rf.get("isolated", {}).get("frac"), 4)
     line["regime"] = res.get("regime")
+    line["achieved_GBps"] = _r(res.get("achieved_GBps"))                        # the metric's second half: resident genotype bytes x sweeps/s, all ranks
+    line["achieved_frac_of_hbm_peak"] = _r(res.get("achieved_frac_of_hbm_peak"), 4)
     cb = res.get("cpu_baseline")
     if isinstance(cb, dict):
         if "error" in cb:
@@ -846,7 +849,7 @@ def main():
             iso2, launches2, cols2 = ctx.time_matvec(reps=2)
             curve2 = list(getattr(measure, "curve", []))
             curve2.append({"sweeps": "timed region", "moves_per_sweep": round(ev2, 1), "sweeps_per_s": round(K2 / el2, 2)})
-            blk = leg_block(side, el2, K2, W2, ev2, nnz2, miss2, ins2, iso2, launches2, cols2, bits2, 0, geo2, burn_s, curve2)
+            blk = leg_block(side, el2, K2, W2, ev2, nnz2, miss2, ins2, iso2, launches2, cols2, bits2, 0, tuple(ctx.pipeline()[:3]), burn_s, curve2)
             if key == "all_move":
                 blk["note"] = ("every marker moves every sweep: a sweep reads the genotypes twice (mat-vec and residual update), 2 n m bytes — "
                                "`achieved_GBps` prices both passes, `roofline` the mat-vec launches (whose update rows ride in them)")
@@ -868,7 +871,10 @@ def main():
                     warm3 = WarmState.make(float(st["mu"]), float(st["vare"]), float(st["varg"]), [float(x) for x in st["pi"]])
                     el3, ev3, nnz3, miss3 = measure(H, L, ctx, y2, side, K2, SIDE_WARMUP, args, rank, local_rank, world, m_offset, m_global, comm, torch, note,
                                                     burn=0, g_init=g3, warm=warm3)
-                    blk["converged"] = leg_block(side, el3, K2, SIDE_WARMUP, ev3, nnz3, miss3, measure.insitu, iso2, launches2, cols2, bits2, 0, geo2, int(st["sweeps"]))
+                    ins3 = measure.insitu
+                    ctx.time_matvec(reps=1)       # (the geometry by regime may have changed the launch width since the first leg: (2, 1) cold, (2, 2) converged)
+                    iso3, launches3, cols3 = ctx.time_matvec(reps=2)
+                    blk["converged"] = leg_block(side, el3, K2, SIDE_WARMUP, ev3, nnz3, miss3, ins3, iso3, launches3, cols3, bits2, 0, tuple(ctx.pipeline()[:3]), int(st["sweeps"]))
                     blk["converged"]["note"] = ("continued (effects + hyper-parameters, hb_warm_state) from the state stored in %s: this model on this synthetic data after %d sweeps "
                                                 "— the chain has found the signal, few markers are left in the model; %d untimed sweeps first"
                                                 % (args.secondary_state, int(st["sweeps"]), SIDE_WARMUP))

@@ -229,7 +229,7 @@ def test_bench_line_stays_small_enough_for_the_driver_to_parse():
         assert k in out["cpu_baseline"], k
     assert len(out["cpu_baseline"]["sample"]) <= 100
     assert {lg["leg"] for lg in out["legs"]} >= {"int8", "vdot4", "secondary", "all_move"}
-    assert all(set(lg) <= {"leg", "model", "bits", "kernel", "value", "ms_per_step", "frac", "frac_of_measured_copy", "regime", "error"} for lg in out["legs"])
+    assert all(set(lg) <= {"leg", "model", "bits", "kernel", "value", "ms_per_step", "frac", "frac_sweep", "frac_of_measured_copy", "regime", "error"} for lg in out["legs"])
     # a sharded run adds its per-rank figures and the strong-scaling leg, still under the limit
     res.update(n_gpus=8, per_rank_ms_per_step={"min": 2.1, "max": 2.3, "all": [2.2] * 8}, ranks_counted_by_all_reduce=8,
                allreduce={"ms_per_call_back_to_back": 0.05, "bytes": 400128}, strong={"value": 900.0, "m_global": 2000000, "m_per_gpu": 250000, "ms_per_step": 4.4, "model": "BayesCpi"})
