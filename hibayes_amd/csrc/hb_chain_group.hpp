@@ -65,7 +65,7 @@
 // regime) every sum is too, bit for bit; where the two paths cut a crowded group into rounds differently the forward sums are grouped
 // differently and effects agree to the last bits' rounding (tests: HB_CERT=0 against 1).
 #ifndef HBG_CH2MAX
-#define HBG_CH2MAX 15
+#define HBG_CH2MAX 31
 #endif
 #ifndef HBG_CERT_MARGIN
 #define HBG_CERT_MARGIN 1.0

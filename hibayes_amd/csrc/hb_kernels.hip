@@ -174,6 +174,7 @@ int hbk_init_attrs()
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 8, 7, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 2, 4, 10, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 4, 8, 5, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 2, 2, 15, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_GROUP_ATTR16(1, 8, 7, 4);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 8, 7, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -713,7 +714,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     const bool group_chain = !dense && shape >= 0 && !c->chain_alone && (sparse_model ? (c->chain_kind & 1) != 0 : mix_model ? c->chain_kind != 0 : ((c->chain_kind & 2) != 0 && shape == 2));
     // k_fwd beside the wide group chain: the chain folds a move into its own group and the next (15 rows, four moves per trip),
     // a second workgroup into the group after that (HB_FWD=0: the chain does all 22 rows itself, three moves per trip)
-    const bool fwd = group_chain && (kp == 1 || mix_model) && (Lv == 2 || Lv == 3) && D == 7 && c->P == 512 && c->fwd_group && !alone;
+    // round 6: also beside BayesR's two-panel groups ((2, 2): the chain folds a move into the next group's two panels, k_fwd into the two after — half of the
+    // chain's fold rows leave its compute unit, and a group's ~16 moves fit ONE trip of 62 loads per lane instead of two of 60)
+    const bool fwd2 = group_chain && mix_model && Lv == 2 && D == 2 && c->P == 512 && c->fwd_group && !alone && cert && !getenv("HB_FWD2_OFF");
+    const bool fwd = (group_chain && (kp == 1 || mix_model) && (Lv == 2 || Lv == 3) && D == 7 && c->P == 512 && c->fwd_group && !alone) || fwd2;
     if (fwd) pv.fcorr = c->fcorr;
     if (c->L > HB_LBMAX && !fwd)
         return hb_fail(HB_ERR_UNSUPPORTED, "three groups of seven panels of look-ahead need the group chain with k_fwd (BayesB / BayesC, panel 512)");
@@ -734,7 +738,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         if (group_chain) {
             const size_t sm = persist_smem(c->P);
             if (mix_model) {
-                if (fwd && cert) hipLaunchKernelGGL((k_chain_group<3, 8, 7, 4, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+                if (fwd2) hipLaunchKernelGGL((k_chain_group<3, 2, 2, 15, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+                else if (fwd && cert) hipLaunchKernelGGL((k_chain_group<3, 8, 7, 4, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
                 else if (fwd) hipLaunchKernelGGL((k_chain_group<3, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
                 else if (cert && c->P == 512 && D <= 4 && Lv * D <= 8 && !(D <= 2 && Lv * D <= 4) && !getenv("HB_CERT_NARROW_OFF"))
                     hipLaunchKernelGGL((k_chain_group<3, 4, 8, 5, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv); // (three or four panels per launch, certified)
@@ -810,7 +815,8 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     }
     if (fwd) {
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
-        if (Lv == 2 && g16) hipLaunchKernelGGL((k_fwd<7, 1, 8, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+        if (fwd2) hipLaunchKernelGGL((k_fwd<2, 1, 16>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+        else if (Lv == 2 && g16) hipLaunchKernelGGL((k_fwd<7, 1, 8, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else if (Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else if (g16) hipLaunchKernelGGL((k_fwd<7, 2, 4, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else hipLaunchKernelGGL((k_fwd<7, 2, 4>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
