@@ -793,7 +793,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // for the chain's share of the band (its own group and the next: 2 D - 1 blocks) and the panels' exact per-marker data (HB_WARM_G: workgroups
     // per XCD, 0 = off)
     if (fwd && c->s_warm && warm_r == 0) {
-        warm_r = c->warm_g;
+        warm_r = fwd2 ? 4 : c->warm_g; // (BayesR's two-panel groups, round 6: 92.1 sweeps/s without, 95.9 / 97.5 / 96.5 with 2 / 4 / 8 workgroups per XCD, profiles/r06_bayesr_conv_warm.txt; the wide BayesCpi shape: no effect, round 5)
         if (const char *e = getenv("HB_WARM_G")) warm_r = std::max(0, std::min(16, atoi(e)));
     }
     if (dense) { // (Lb + 1 target panels are open at any time: Lb ahead for their band, the chain's own for its far sub-blocks)
