@@ -617,8 +617,8 @@ int hb_run::setup(const hb_bayes_args *args)
         adaptive_geo = (model_index == 3 || model_index == 4) && (own_ctx || c->adaptive) && gp == 1 && (gl == 2 || gl == 3) && gd == 7 && c->Lg >= 20;
         geo_wide_lv = gl;
         geo_cur = 0;
-        // round 6, BayesR with up to four classes at panel 512: two panels per launch and the certified group chain (k_chain_group<3, 2, 4, 10>)
-        // once fewer than ~17 markers a panel move, one panel per launch and the per-panel chain with its row cache (k_chain_persist) above ~21
+        // round 6, BayesR with up to four classes at panel 512: two panels per launch and the certified group chain (k_chain_group<3, 2, 2, 15> + k_fwd + warmers)
+        // once fewer than ~22 markers a panel move, one panel per launch and the per-panel chain with its row cache (k_chain_persist) above ~27
         // (measured at n = 50k, m = 500k from a cold start, profiles/r06_bayesr_regime.txt: they cross at 19 moves per panel — 47.5 sweeps/s both;
         // at 51: 37 against 54; at 11: 68 against 60; at 8: 85 against 69)
         if (model_index == 6 && n_fold <= 4 && c->P == 512 && (own_ctx || c->adaptive) && gp == 1 && gl == 2 && gd == 2 && c->Lg >= 5 && !getenv("HB_NO_ADAPTIVE_R")) {
@@ -626,8 +626,8 @@ int hb_run::setup(const hb_bayes_args *args)
             geo_wide_d = 2;
             geo_narrow_lv = 2;
             geo_narrow_d = 1;
-            geo_to_wide = 17.0;
-            geo_to_narrow = 21.0;
+            geo_to_wide = 22.0;   // (re-measured with k_fwd and the warmers beside the group chain, profiles/r06_bayesr_regime2.txt: at 19.6 moves a panel 51.4 against 49.6
+            geo_to_narrow = 27.0; //  sweeps/s, at 11: 78 against 63; at 47: 39 against 54 — no measurement in between)
         }
         if (adaptive_geo) { // the first sweep: as many moves as markers are expected in the model (a cold start) or are in it
             double nz = 0;

@@ -383,8 +383,8 @@ def test_long_chain_draw_for_draw_at_pipeline_depth(big, model, Pi, fold, geo, b
 
 def test_bayesr_geometry_by_regime(big):
     """Round 6: a BayesR run (up to four classes, panel 512) picks its geometry per sweep from the moves of the sweep before — (2, 1) and
-    k_chain_persist while more than ~21 markers a panel move, (2, 2) and the certified group chain below ~17 (hb_run.hip; measured crossing at
-    19, profiles/r06_bayesr_regime.txt). From a cold start (5 % of the markers expected in the model: 26 a panel) the run leaves the stored (2, 2)
+    k_chain_persist while more than ~27 markers a panel move, (2, 2) and the certified group chain below ~22 (hb_run.hip; measured:
+    profiles/r06_bayesr_regime2.txt). From a cold start (5 % of the markers expected in the model: 26 a panel) the run leaves the stored (2, 2)
     before its first sweep; from a sparse state with pi0 = 0.995 it stays there; either way it is the oracle's chain draw for draw."""
     X, y = big["X"][:, :32768], big["y"]
     m = X.shape[1]
