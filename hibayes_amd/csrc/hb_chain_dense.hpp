@@ -330,7 +330,14 @@ __global__ __launch_bounds__(256) void k_fold_dense(chain_view v, persist_view p
     const int np = pv.npanels, D = pv.D;
     const int tq = blockIdx.x >> 3, ch = blockIdx.x & 7;
     const size_t PP = (size_t)P * P, pblk = (size_t)(pv.Lg + 1) * PP;
-    if (t == 0) { s_abort = 0; atomicAdd(pv.flags + 13, 1u); }
+    if (t == 0) {
+        s_abort = 0;
+        if (atomicAdd(pv.flags + 13, 1u) == 0u) { // (diagnostics, HB_DEBUG_STARTS: when the first fold workgroup started, beside the chain's own start in words 16 / 17)
+            const unsigned long long now = wall_clock64();
+            st_flag(pv.flags + 18, (unsigned)now);
+            st_flag(pv.flags + 19, (unsigned)(now >> 32));
+        }
+    }
     __syncthreads();
     const int nfar = ch > HBD_NEAR ? ch - HBD_NEAR : 0; // sub-blocks 0 .. nfar - 1 of the target's own panel
     for (int q = pv.p0 + tq; q < np; q += nsets) {

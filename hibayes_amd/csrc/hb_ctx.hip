@@ -856,6 +856,10 @@ static int fetch_acc(hb_ctx *c)
     if (c->blk_n) HB_HIP(hipMemcpyAsync(c->h_blk, c->blk, sizeof(double) * c->blk_n, hipMemcpyDeviceToHost, c->stream));
     HB_HIP(hipStreamSynchronize(c->stream));
     c->aborted = false;
+    if (getenv("HB_DEBUG_STARTS") && c->h_flags[13]) { // (development aid: how long after the dense chain its fold workgroups started)
+        const long long ch = ((long long)c->h_flags[17] << 32) | c->h_flags[16], fo = ((long long)c->h_flags[19] << 32) | c->h_flags[18];
+        fprintf(stderr, "hibayes_gpu: k_fold_dense's first workgroup started %.1f us after k_chain_dense's first panel (%u fold workgroups started)\n", (double)(fo - ch) * 1e-2, c->h_flags[13]);
+    }
     if (c->ldiag) { // (HB_DEBUG_ABORT) a long wait that flushed its L2 and went on leaves no other trace
         static unsigned seen = 0;
         const unsigned now = hbk_long_wait_flushes();

@@ -764,12 +764,22 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_persist launch: ") + hipGetErrorString(e));
         return HB_OK;
     };
+    bool fold_first = false;
     if (alone) { // (the update rows poll the move counts themselves: "no moves" for every panel)
         HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->flags + HB_FLAG_CHAIN_DONE), 0x7ffffff0, 1, sA));
         HB_HIP(hipMemsetAsync(c->ev_count, 0, sizeof(int32_t) * (size_t)c->npanels * HB_EVS, sA));
         if (fx) HB_HIP(hipMemsetAsync(c->mb + HB_MBS, 0, sizeof(double) * ((size_t)c->npanels + 1) * HB_MBS, sA));
     }
     else {
+        // round 6: k_fold_dense is enqueued BEFORE the chain and the gate. Captured after them, the graph started it ~1 ms late — the dense chain waits for its
+        // first far sums at sub-block 4 of the sweep's first panel, launch 2's update rows wait for the chain: 1 ms of every 18 ms sweep
+        // (tools/r6_long_launch.py, tools/r6_dense_start.py; HB_GATE=0 or HB_GRAPH=0 alone also removed it; HB_FOLD_FIRST=0: the old order)
+        fold_first = dense && !(getenv("HB_FOLD_FIRST") && atoi(getenv("HB_FOLD_FIRST")) == 0);
+        if (fold_first) {
+            HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
+            hipLaunchKernelGGL(k_fold_dense, dim3(8 * (c->L + 1)), dim3(256), 0, c->s_upd, cv, pv, c->ddense, c->fcorr2, c->L + 1);
+            HB_HIP(hipGetLastError());
+        }
         if (int rc = launch_the_chain(sB)) return rc;
         // (the first mat-vec launch starts when the chain is resident; HB_GATE=0 / 1 overrides: by default only where a launch's
         // update blocks can sit on every compute unit)
@@ -796,7 +806,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         warm_r = fwd2 ? 4 : c->warm_g; // (BayesR's two-panel groups, round 6: 92.1 sweeps/s without, 95.9 / 97.5 / 96.5 with 2 / 4 / 8 workgroups per XCD, profiles/r06_bayesr_conv_warm.txt; the wide BayesCpi shape: no effect, round 5)
         if (const char *e = getenv("HB_WARM_G")) warm_r = std::max(0, std::min(16, atoi(e)));
     }
-    if (dense) { // (Lb + 1 target panels are open at any time: Lb ahead for their band, the chain's own for its far sub-blocks)
+    if (dense && !fold_first) { // (Lb + 1 target panels are open at any time: Lb ahead for their band, the chain's own for its far sub-blocks)
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         hipLaunchKernelGGL(k_fold_dense, dim3(8 * (c->L + 1)), dim3(256), 0, c->s_upd, cv, pv, c->ddense, c->fcorr2, c->L + 1);
         HB_HIP(hipGetLastError());
