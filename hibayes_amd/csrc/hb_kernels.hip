@@ -765,6 +765,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         return HB_OK;
     };
     bool fold_first = false;
+    const bool side_first = !alone && getenv("HB_SIDE_FIRST") && atoi(getenv("HB_SIDE_FIRST")) != 0; // (A/B: k_fwd and the warmers enqueued before the chain, as k_fold_dense is)
     if (alone) { // (the update rows poll the move counts themselves: "no moves" for every panel)
         HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->flags + HB_FLAG_CHAIN_DONE), 0x7ffffff0, 1, sA));
         HB_HIP(hipMemsetAsync(c->ev_count, 0, sizeof(int32_t) * (size_t)c->npanels * HB_EVS, sA));
@@ -780,12 +781,14 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
             hipLaunchKernelGGL(k_fold_dense, dim3(8 * (c->L + 1)), dim3(256), 0, c->s_upd, cv, pv, c->ddense, c->fcorr2, c->L + 1);
             HB_HIP(hipGetLastError());
         }
-        if (int rc = launch_the_chain(sB)) return rc;
-        // (the first mat-vec launch starts when the chain is resident; HB_GATE=0 / 1 overrides: by default only where a launch's
-        // update blocks can sit on every compute unit)
-        bool gate = dense;
-        if (const char *e = getenv("HB_GATE")) gate = atoi(e) != 0;
-        if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sA, c->flags);
+        if (!side_first) {
+            if (int rc = launch_the_chain(sB)) return rc;
+            // (the first mat-vec launch starts when the chain is resident; HB_GATE=0 / 1 overrides: by default only where a launch's
+            // update blocks can sit on every compute unit)
+            bool gate = dense;
+            if (const char *e = getenv("HB_GATE")) gate = atoi(e) != 0;
+            if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sA, c->flags);
+        }
     }
     // the L2 warmers (k_warm): a third branch of the graph, 4 workgroups per XCD of which only the chain's XCD's stay
     int warm = 4;
@@ -853,6 +856,12 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         pw.Lb = fwd ? 2 * D - 1 : 1; // (BayesR: the chain folds into the next panel only; the group chain: into its own group's later panels and the next group's)
         hipLaunchKernelGGL(k_warm, dim3(8 * warm_r), dim3(256), 0, c->s_warm, pw, cv, kp, c->gram, c->P, ahead, warm_r, reinterpret_cast<int *>(c->flags + 48));
         HB_HIP(hipGetLastError());
+    }
+    if (side_first) {
+        if (int rc = launch_the_chain(sB)) return rc;
+        bool gate = dense;
+        if (const char *e = getenv("HB_GATE")) gate = atoi(e) != 0;
+        if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sA, c->flags);
     }
     const bool inject = c->inject_abort_panel >= 0 && c->s_dbg && !alone;
     if (inject) { // (debug hook: a fourth branch that aborts the sweep in mid-flight)
