@@ -114,8 +114,24 @@ static int auto_panel(int m)
     return 64;
 }
 
+// development aid (HB_DEBUG_SEGV=1): a native backtrace on SIGSEGV — there is no debugger in the image
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void hb_segv_handler(int sig)
+{
+    void *bt[64];
+    const int n = backtrace(bt, 64);
+    const char msg[] = "hibayes_gpu: fatal signal, native backtrace:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(bt, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
 {
+    if (getenv("HB_DEBUG_SEGV")) signal(SIGSEGV, hb_segv_handler);
     if (!p || !out) return hb_fail(HB_ERR_INVALID, "hb_ctx_create: null argument");
     *out = nullptr;
     if (p->n < 2 || p->m < 1) return hb_fail(HB_ERR_INVALID, "hb_ctx_create: n >= 2 and m >= 1 required");
@@ -161,6 +177,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_Q2M_SC")) c->q2m_sc = atoi(e) != 0;
     if (const char *e = getenv("HB_DOTQ2_NC")) c->dotq2_nc = std::max(4, atoi(e) / 4 * 4);
     if (const char *e = getenv("HB_DOTQ2_RS")) c->dotq2_rs = atoi(e) == 256 ? 256 : atoi(e) == 128 ? 128 : 512;
+    if (const char *e = getenv("HB_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char *e = getenv("HB_CHAIN")) c->chain_kind = std::strcmp(e, "panel") == 0 ? 0 : std::strcmp(e, "all") == 0 ? 3 : (atoi(e) ? atoi(e) : 1);
     if (const char *e = getenv("HB_WARM_GROUP")) c->warm_group = atoi(e) != 0;
     if (const char *e = getenv("HB_FWD")) c->fwd_group = atoi(e) != 0;
@@ -316,6 +333,11 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->s_upd) (void)hipStreamDestroy(c->s_upd);
     if (c->s_warm) (void)hipStreamDestroy(c->s_warm);
     if (c->s_dbg) (void)hipStreamDestroy(c->s_dbg);
+    for (auto e : c->ev_ot) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev_ou) if (e) (void)hipEventDestroy(e);
+    if (c->s_t2) (void)hipStreamDestroy(c->s_t2);
+    if (c->s_uk) (void)hipStreamDestroy(c->s_uk);
+    if (c->s_fk) (void)hipStreamDestroy(c->s_fk);
     void *ptrs[] = {c->X, c->X2, c->xpx, c->vx, c->s1, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->fcorr, c->ddense, c->fcorr2, c->dots, c->ev_count, c->ev_idx,
                     c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->gram16, c->ga, c->gB, c->gcmax, c->g16_flag, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->opn, c->ru_ws, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa, c->snap, c->ldiag};

@@ -69,6 +69,11 @@ struct hb_ctx {
     hipStream_t s_chain = nullptr;     // serial chain kernels
     hipStream_t s_upd = nullptr;       // residual updates
     hipStream_t s_warm = nullptr;      // k_warm where k_fwd has s_upd (BayesR)
+    // round 6, overlapped launch stream (HB_OVERLAP): the mat-vec launches of a sweep alternate between `stream` and s_t2, the residual updates are kernels of
+    // their own on s_uk and the finalize kernels on s_fk — every dependency a graph edge, two launches in flight (hb_kernels.hip: enqueue_sweep_pipeline)
+    hipStream_t s_t2 = nullptr, s_uk = nullptr, s_fk = nullptr;
+    std::vector<hipEvent_t> ev_ot, ev_ou; // per mat-vec group: its tiles are done / its residual update is done
+    int overlap = 0;                      // 0 off, 1 on (HB_OVERLAP)
     std::vector<hipEvent_t> ev_dot, ev_chain, ev_upd; // cross-stream dependencies of one sweep
     hipEvent_t ev_fork = nullptr;
 

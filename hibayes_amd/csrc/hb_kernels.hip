@@ -765,6 +765,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         return HB_OK;
     };
     bool fold_first = false;
+    const bool overlap = c->overlap && fx && !dense && !alone && !c->lstamp && ngroups > Lv + 2 && Lv + 1 <= 8 && c->s_fk != nullptr;
     const bool side_first = !alone && getenv("HB_SIDE_FIRST") && atoi(getenv("HB_SIDE_FIRST")) != 0; // (A/B: k_fwd and the warmers enqueued before the chain, as k_fold_dense is)
     if (alone) { // (the update rows poll the move counts themselves: "no moves" for every panel)
         HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->flags + HB_FLAG_CHAIN_DONE), 0x7ffffff0, 1, sA));
@@ -785,7 +786,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
             if (int rc = launch_the_chain(sB)) return rc;
             // (the first mat-vec launch starts when the chain is resident; HB_GATE=0 / 1 overrides: by default only where a launch's
             // update blocks can sit on every compute unit)
-            bool gate = dense;
+            bool gate = dense || overlap; // (overlap: up to Lv + 1 tile launches start at once and leave no compute unit free for the chain's 160 KB of LDS)
             if (const char *e = getenv("HB_GATE")) gate = atoi(e) != 0;
             if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sA, c->flags);
         }
@@ -859,7 +860,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     }
     if (side_first) {
         if (int rc = launch_the_chain(sB)) return rc;
-        bool gate = dense;
+        bool gate = dense || overlap;
         if (const char *e = getenv("HB_GATE")) gate = atoi(e) != 0;
         if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sA, c->flags);
     }
@@ -870,12 +871,47 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         HB_HIP(hipGetLastError());
     }
     const int upd_blocks = (int)((c->ld / 4 + 255) / 256);
+    // ---- Round 6: the OVERLAPPED launch stream (HB_OVERLAP=1). A 3 584-column launch lives 12 us of which its tiles run 9: the rest is the ramp of a
+    // kernel that is too small for the chip, plus 1.6 us of dependent-dispatch gap — and two such launches in flight stream 21 % more
+    // (9.6 against 12.2 us per launch isolated, tools/matvec_only.py with HB_TM_STREAMS=2; the int8 launches reach the measured read ceiling, 6.1 TB/s).
+    // What ties launch g to launch g - 1 is only what RIDES in it — the update rows that write the residual version the next launch reads, and the finalize
+    // rows of the previous launch's sums. Here both are kernels of their own: the mat-vec launches (tiles only) alternate between two streams, the residual
+    // updates u(h) follow each other on a third (each still polls the chain's counts for its group on the device), the finalize kernels f(g) on a
+    // fourth; t(g) waits for u(g - Lv - 1) — the version it reads — and f(g) for t(g): graph edges, no new device-side hand-off, no coherence question.
+    // The residual versions live in a ring of Lv + 1 slots: while t(g) reads version g - Lv - 1 the chain has closed group g - 1 at most, so the
+    // youngest version written is g - 1; u(g), which overwrites the slot t(g) reads, needs chain_done(g), i.e. the sums of t(g). Same integers, same
+    // chain: the band, the correction ring and k_fwd see the geometry they always saw. ----
+    if (overlap) {
+        const int NBr = Lv + 1;
+        auto slotn = [&](int v) { return v < 0 ? 0 : (v + 1) % NBr; };
+        // (the second tile stream starts behind the gate / the sweep's start like the first: an event on sA here)
+        HB_HIP(hipEventRecord(c->ev_chain[2 % c->npanels], sA));
+        HB_HIP(hipStreamWaitEvent(c->s_t2, c->ev_chain[2 % c->npanels], 0));
+        HB_HIP(hipStreamWaitEvent(c->s_uk, c->ev_fork, 0));
+        for (int g = 0; g < ngroups; g++) {
+            const int ga = g0 + g, p0 = ga * D, p1 = std::min(np, p0 + D);
+            hipStream_t st = (g & 1) ? c->s_t2 : sA;
+            const int v = g - Lv - 1; // the residual version the tiles read
+            if (v >= 0) HB_HIP(hipStreamWaitEvent(st, c->ev_ou[v], 0));
+            launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slotn(v), st, true, nullptr, 0, 0, ga);
+            // (the finalize kernel follows its tiles in their stream: one edge per group — u(v) -> t(v + Lv + 1) — is all the graph holds besides its three
+            // chains; with an event per tile launch, finalize and update the executor's traversal of the captured graph did not return)
+            launch_dotq_fin(c, p0 * c->P, (p1 - p0) * c->P, ga, c->dsum + (size_t)p0 * c->P, st);
+            upd_view uq = make_upd(c, p0, p1, slotn(g - 1), slotn(g), c->flags, ga);
+            hipLaunchKernelGGL(k_update, dim3(upd_blocks), dim3(256), 0, c->s_uk, c->ld, uq);
+            HB_HIP(hipEventRecord(c->ev_ou[g], c->s_uk));
+        }
+        // join: everything back into sA
+        HB_HIP(hipEventRecord(c->ev_ot[0], c->s_t2));
+        HB_HIP(hipStreamWaitEvent(sA, c->ev_ot[0], 0));
+        HB_HIP(hipStreamWaitEvent(sA, c->ev_ou[ngroups - 1], 0));
+    }
     // Residual versions advance per mat-vec group: version h = every panel of groups <= h applied. Mat-vec launch g
     // reads version g - Lv - 1 and, in one extra grid row, carries update(h = g - Lv): version h-1 -> h, which the
     // NEXT launch reads. Two buffers ping-pong (slot = (version + 1) & 1). No third stream, no cross-stream events.
     auto slot2 = [](int v) { return v < 0 ? 0 : ((v + 1) & 1); };
     // (g, h: group indices within the range — they drive the version slots; ga, ha: the absolute ones — they address panels)
-    for (int g = 0; g < ngroups; g++) {
+    for (int g = 0; g < ngroups && !overlap; g++) {
         const int ga = g0 + g;
         const int p0 = ga * D, p1 = std::min(np, p0 + D);
         const int h = g - Lv, ha = g0 + h;
@@ -894,10 +930,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, true, ride ? &uq : nullptr,
                    g > 0 ? (ga - 1) * D * c->P : 0, g > 0 ? D * c->P : 0, ga);
     }
-    launch_reduce(c, (g0 + ngroups - 1) * D * c->P, last_panels * c->P, sA, g0 + ngroups - 1);
+    if (!overlap) launch_reduce(c, (g0 + ngroups - 1) * D * c->P, last_panels * c->P, sA, g0 + ngroups - 1);
     if (alone)
         if (int rc = launch_the_chain(sA)) return rc;
-    for (int h = std::max(0, ngroups - Lv); h < ngroups; h++) { // the updates that had no later mat-vec to ride on
+    for (int h = std::max(0, ngroups - Lv); h < ngroups && !overlap; h++) { // the updates that had no later mat-vec to ride on
         upd_view uq = make_upd(c, (g0 + h) * D, std::min(np, (g0 + h) * D + D), slot2(h - 1), slot2(h), c->flags, g0 + h);
         if (dense_upd && c->layout == 8 && D <= 2) {
             uq.dense = 1;
@@ -918,7 +954,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         HB_HIP(hipEventRecord(c->ev_dot[0], c->s_dbg));
         HB_HIP(hipStreamWaitEvent(sA, c->ev_dot[0], 0));
     }
-    const int sfin = slot2(ngroups - 1);
+    const int sfin = overlap ? ((ngroups - 1 + 1) % (Lv + 1)) : slot2(ngroups - 1);
     if (sfin != 0) {
         HB_HIP(hipMemcpyAsync(c->r, c->r + (size_t)sfin * c->ld, sizeof(double) * c->ld, hipMemcpyDeviceToDevice, sA));
         HB_HIP(hipMemcpyAsync(c->r32, c->r32 + (size_t)sfin * c->ld, sizeof(float) * c->ld, hipMemcpyDeviceToDevice, sA));
@@ -933,9 +969,24 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     return HB_OK;
 }
 
+// streams and events of the overlapped launch stream: created OUTSIDE any capture
+static int overlap_resources(hb_ctx *c)
+{
+    auto mk = [&](hipStream_t *st) { return *st ? hipSuccess : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+    HB_HIP(mk(&c->s_t2));
+    HB_HIP(mk(&c->s_uk));
+    HB_HIP(mk(&c->s_fk));
+    const int need = c->npanels + 1;
+    while ((int)c->ev_ot.size() < need) { hipEvent_t e; HB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_ot.push_back(e); }
+    while ((int)c->ev_ou.size() < need) { hipEvent_t e; HB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_ou.push_back(e); }
+    return HB_OK;
+}
+
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
 {
     if (int rc = hbk_set_timeout(c)) return rc;
+    if (c->overlap && c->pipeline && !c->s_fk)
+        if (int rc = overlap_resources(c)) return rc;
     *c->h_in = *in;
     HB_HIP(hipMemcpyAsync(c->d_in, c->h_in, sizeof(hb_sweep_in), hipMemcpyHostToDevice, c->stream));
     if (timed || c->row_reduce) return enqueue_sweep_kernels(c, in->model_index, in->n_fold, true); // (row-sharded mode: host round trips inside the sweep)
@@ -1272,10 +1323,21 @@ int hbk_time_matvec(hb_ctx *c, int D, int reps, int as_pipeline, double *avg_us,
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     HB_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    // (round 6, timing experiment only — HB_TM_STREAMS=2: the launches alternate between two streams with nothing between them, i.e. two launches in flight:
+    // what an overlapped launch stream could reach; the sums are not meaningful then)
+    const int nstreams = getenv("HB_TM_STREAMS") ? std::max(1, std::min(2, atoi(getenv("HB_TM_STREAMS")))) : 1;
+    if (nstreams == 2) {
+        HB_HIP(hipEventRecord(c->ev_fork, c->stream));
+        HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
+    }
     for (int gi = 0; gi < ngroups; gi++) {
         const int p0 = gi * D, p1 = std::min(c->npanels, p0 + D);
-        launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, c->stream, as_pipeline != 0, nullptr,
+        launch_dot(c, p0 * c->P, (p1 - p0) * c->P, 0, (nstreams == 2 && (gi & 1)) ? c->s_upd : c->stream, as_pipeline != 0, nullptr,
                    gi > 0 ? (gi - 1) * D * c->P : 0, gi > 0 ? D * c->P : 0, gi);
+    }
+    if (nstreams == 2) {
+        HB_HIP(hipEventRecord(c->ev_upd[0], c->s_upd));
+        HB_HIP(hipStreamWaitEvent(c->stream, c->ev_upd[0], 0));
     }
     if (as_pipeline) launch_reduce(c, (ngroups - 1) * D * c->P, (c->npanels - (ngroups - 1) * D) * c->P, c->stream, ngroups - 1);
     HB_HIP(hipStreamEndCapture(c->stream, &g));

@@ -129,6 +129,9 @@ def c3():
     c.close()
 
 
+ORACLE_THREADS = int(os.environ.get("HB_TEST_ORACLE_THREADS", str(max(1, min(8, len(os.sched_getaffinity(0)))))))
+
+
 def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=2, dense=0.0, shared=None, bits=8, adaptive=False, stationary=0, installed_pi=None):
     """dense > 0: the chain starts from an installed state with that fraction of the markers in the model (g_init on both
     sides): crowded rounds, row-cache misses and band folds of hundreds of moves per mat-vec group from the first panel on.
@@ -185,7 +188,9 @@ def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=
             c.close()
         elif bits == 2:
             c.set_layout(8)          # (the next case finds the int8 columns again)
-    ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, marker_offset=m_offset, **kw)
+    # (round 6: the live oracle on its persistent team of row-chunk workers — int8 columns too since this round —: the same sampler, its dot
+    # products summed in eight chunks; 25 s of every at-size case were two one-thread sweeps over 25 GB)
+    ref = O.bayes(y, X, model, Pi, rng=O.RNG_PHILOX, store_alpha=True, marker_offset=m_offset, threads=ORACLE_THREADS, **kw)
     g_ref = ref["s_alpha"][:, -1]
     assert np.array_equal(g_gpu != 0, g_ref != 0), "%d of %d inclusion decisions differ" % (((g_gpu != 0) != (g_ref != 0)).sum(), m)
     np.testing.assert_allclose(g_gpu, g_ref, rtol=1e-8, atol=1e-12)
