@@ -71,10 +71,8 @@
 #define HBG_CERT_MARGIN 1.0
 #endif
 template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false, bool CERT = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
-                                                                                                 persist_view pv)
+__device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__ pin, const chain_view &v, const persist_view &pv, char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int P = v.P, S = P >> 6;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int lgP = 31 - __clz(P);
@@ -822,6 +820,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false, bool CERT = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
+                                                                                                 persist_view pv)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    chain_group_body<K1, HBG_DM, HBG_FW, HBG_CH, G16, CERT>(pin, v, pv, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_fwd: the forward fold of the groups AFTER the next one, on a second compute unit.
 // A move of group g owes corrections to the dots of every panel whose mat-vec ran without it: the D panels of each of the groups
@@ -835,14 +841,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // forward sums: the same chain in exact arithmetic (tests: draw for draw).
 // HBF_D = D panels per group (slot y of fs[] is panel y counted from the first panel of group g + 2), HBF_G = Lv - 1 groups.
 // ---------------------------------------------------------------------------------------------
+// (round 6: the body as a device function on a caller-supplied LDS region, so that it can also run as the SECOND workgroup of the chain's own kernel —
+// k_chain_group_fwd below: one graph branch and one hardware queue instead of two)
+template <int HBF_D, int HBF_G>
+constexpr int hbf_lds_bytes(bool g16) { return HBF_D * 512 * 8 + HBF_D * 512 * 4 + (g16 ? HBF_D * 512 * 4 : 16) + (HBF_D + 1) * 4 + 16; }
 template <int HBF_D, int HBF_G, int HBF_CH, bool G16 = false>
-__global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
+__device__ __forceinline__ void fwd_body(const chain_view &v, const persist_view &pv, char *lds)
 {
     constexpr int NF = HBF_D * HBF_G;
-    __shared__ int s_pos[HBF_D * 512];    // the group's moves: panel * P + marker
-    __shared__ double s_del[HBF_D * 512]; // ... and changes of effect
-    __shared__ int s_ga[G16 ? HBF_D * 512 : 1]; // G16: ga[] of the movers
-    __shared__ int s_cnt[HBF_D + 1], s_ok;
+    double *s_del = reinterpret_cast<double *>(lds);                 // [HBF_D * 512] the group's moves: changes of effect
+    int *s_pos = reinterpret_cast<int *>(s_del + HBF_D * 512);       // [HBF_D * 512] ... panel * P + marker
+    int *s_ga = s_pos + HBF_D * 512;                                 // [G16 ? HBF_D * 512 : 4] G16: ga[] of the movers
+    int *s_cnt = s_ga + (G16 ? HBF_D * 512 : 4);                     // [HBF_D + 1]
+    int &s_ok = s_cnt[HBF_D + 1];
     const int P = v.P, t = threadIdx.x, lgP = 31 - __clz(P);
     const int D = pv.D, np = pv.npanels, G = pv.Lv - 1;
     const size_t PP = (size_t)P * P, pstep = (size_t)(pv.Lg + 2) * PP;
@@ -939,4 +950,25 @@ __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
         for (int x = 0; x < HBF_D; x++) fs[(HBF_G - 1) * HBF_D + x] = 0.0;
         __syncthreads(); // (the lists are rewritten for the next group)
     }
+}
+
+template <int HBF_D, int HBF_G, int HBF_CH, bool G16 = false>
+__global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
+{
+    __shared__ __attribute__((aligned(16))) char lds[hbf_lds_bytes<HBF_D, HBF_G>(G16)];
+    fwd_body<HBF_D, HBF_G, HBF_CH, G16>(v, pv, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_chain_group_fwd (round 6): the chain workgroup and k_fwd as the two workgroups of ONE kernel (each takes a compute unit: both ask for the whole LDS) —
+// one graph branch and one hardware queue instead of two, which is what lets the overlapped launch stream (two tile streams + the update kernels) fit the
+// four queues a process gets (profiles/r06_overlap.txt).
+// ---------------------------------------------------------------------------------------------
+template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool CERT, int HBF_D, int HBF_G, int HBF_CH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group_fwd(const hb_sweep_in *__restrict__ pin, chain_view v,
+                                                                                                     persist_view pv)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.x == 0) chain_group_body<K1, HBG_DM, HBG_FW, HBG_CH, false, CERT>(pin, v, pv, smem);
+    else fwd_body<HBF_D, HBF_G, HBF_CH, false>(v, pv, smem);
 }

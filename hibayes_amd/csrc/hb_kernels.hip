@@ -175,6 +175,8 @@ int hbk_init_attrs()
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 2, 4, 10, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 4, 8, 5, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<3, 2, 2, 15, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group_fwd<1, 8, 7, 4, true, 7, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group_fwd<1, 8, 7, 4, true, 7, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_GROUP_ATTR16(1, 8, 7, 4);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 8, 7, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -718,6 +720,11 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // chain's fold rows leave its compute unit, and a group's ~16 moves fit ONE trip of 62 loads per lane instead of two of 60)
     const bool fwd2 = group_chain && mix_model && Lv == 2 && D == 2 && c->P == 512 && c->fwd_group && !alone && cert && !getenv("HB_FWD2_OFF");
     const bool fwd = (group_chain && (kp == 1 || mix_model) && (Lv == 2 || Lv == 3) && D == 7 && c->P == 512 && c->fwd_group && !alone) || fwd2;
+    const bool warm_r_env_off = !(getenv("HB_WARM_G") && atoi(getenv("HB_WARM_G")) > 0);
+    // (only where chain and k_fwd run as ONE kernel — the wide certified shape of BayesB / BayesC: four branches in all, what a process has queues for)
+    const bool overlap = c->overlap && fx && !dense && !alone && !c->lstamp && ngroups > Lv + 2 && Lv + 1 <= 8 && c->s_fk != nullptr &&
+                         fwd && !fwd2 && cert && kp == 1 && !g16 && warm_r_env_off;
+    const bool merged = overlap;
     if (fwd) pv.fcorr = c->fcorr;
     if (c->L > HB_LBMAX && !fwd)
         return hb_fail(HB_ERR_UNSUPPORTED, "three groups of seven panels of look-ahead need the group chain with k_fwd (BayesB / BayesC, panel 512)");
@@ -737,6 +744,13 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         }
         if (group_chain) {
             const size_t sm = persist_smem(c->P);
+            if (merged) { // chain + k_fwd as the two workgroups of one kernel (the overlapped launch stream)
+                if (Lv == 2) hipLaunchKernelGGL((k_chain_group_fwd<1, 8, 7, 4, true, 7, 1, 8>), dim3(2), dim3(c->P), sm, st, c->d_in, cv, pv);
+                else hipLaunchKernelGGL((k_chain_group_fwd<1, 8, 7, 4, true, 7, 2, 4>), dim3(2), dim3(c->P), sm, st, c->d_in, cv, pv);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return hb_fail(HB_ERR_HIP, std::string("k_chain_group_fwd launch: ") + hipGetErrorString(e));
+                return HB_OK;
+            }
             if (mix_model) {
                 if (fwd2) hipLaunchKernelGGL((k_chain_group<3, 2, 2, 15, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
                 else if (fwd && cert) hipLaunchKernelGGL((k_chain_group<3, 8, 7, 4, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
@@ -765,7 +779,6 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         return HB_OK;
     };
     bool fold_first = false;
-    const bool overlap = c->overlap && fx && !dense && !alone && !c->lstamp && ngroups > Lv + 2 && Lv + 1 <= 8 && c->s_fk != nullptr;
     const bool side_first = !alone && getenv("HB_SIDE_FIRST") && atoi(getenv("HB_SIDE_FIRST")) != 0; // (A/B: k_fwd and the warmers enqueued before the chain, as k_fold_dense is)
     if (alone) { // (the update rows poll the move counts themselves: "no moves" for every panel)
         HB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->flags + HB_FLAG_CHAIN_DONE), 0x7ffffff0, 1, sA));
@@ -827,7 +840,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
             warm_dense = true;
         }
     }
-    if (fwd) {
+    if (fwd && !merged) {
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         if (fwd2) hipLaunchKernelGGL((k_fwd<2, 1, 16>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else if (Lv == 2 && g16) hipLaunchKernelGGL((k_fwd<7, 1, 8, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
@@ -942,7 +955,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     }
     HB_HIP(hipEventRecord(c->ev_chain[0], sB));
     HB_HIP(hipStreamWaitEvent(sA, c->ev_chain[0], 0));
-    if (warm || fwd || dense || warm_dense || fwd_persist) {
+    if (warm || (fwd && !merged) || dense || warm_dense || fwd_persist) {
         HB_HIP(hipEventRecord(c->ev_upd[0], c->s_upd));
         HB_HIP(hipStreamWaitEvent(sA, c->ev_upd[0], 0));
     }
