@@ -835,7 +835,7 @@ def main():
             geo2 = PIPELINE.get(side, (1, 1, 1))
             ctx.set_pipeline(*geo2)
             bits2 = ctx.layout()[0]
-            if bits2 == 2 and geo2[2] <= 2:
+            if bits2 == 2 and geo2[2] <= 2 and not os.environ.get("HB_BENCH_KEEP_2BIT"):
                 # one or two panels per mat-vec launch (the dense models): the sweep is bound by the chain workgroup and the update rows,
                 # and the ALU-heavier 2-bit kernel only lengthens the launches beside them (measured: 31.5 vs 26.4 ms per BayesR sweep)
                 ctx.set_layout(8)
