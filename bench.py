@@ -835,12 +835,17 @@ def main():
             geo2 = PIPELINE.get(side, (1, 1, 1))
             ctx.set_pipeline(*geo2)
             bits2 = ctx.layout()[0]
-            if bits2 == 2 and geo2[2] <= 2 and not os.environ.get("HB_BENCH_KEEP_2BIT"):
-                # one or two panels per mat-vec launch (the dense models): the sweep is bound by the chain workgroup and the update rows,
-                # and the ALU-heavier 2-bit kernel only lengthens the launches beside them (measured: 31.5 vs 26.4 ms per BayesR sweep)
+            if bits2 == 2 and side in ("BayesRR", "BayesA", "BayesL"):
+                # the models in which every marker moves: their dense update rows read int8 columns (hb_kernels.hip: dense_upd). BayesR stays on the
+                # 2-bit layout since the end of round 6 (k_dotq2m beside its chains: 64.5 / 102.8 against 57.8 / 98.3 sweeps/s cold / converged) — which is
+                # also what a run picks by itself (genotype_bits = 0)
                 ctx.set_layout(8)
                 bits2 = 8
             ctx.build_gram()
+            if args.bits == 2 and args.precise == 2 and side not in ("BayesRR", "BayesA", "BayesL") and ctx.layout()[0] != 2:
+                ctx.set_layout(2, keep_int8=True)   # (the int8 leg before this one left the int8 columns resident; the all-move legs need them again)
+                ctx.set_matvec_kernel(kind_main)
+            bits2 = ctx.layout()[0]
             y2 = synth_phenotype(ctx, n, m, m_offset, m_global, args.seed, comm, side)
             el2, ev2, nnz2, miss2 = measure(H, L, ctx, y2, side, K2, W2, args, rank, local_rank, world, m_offset,
                                      m_global, comm, torch, note, burn=burn_s)
@@ -849,7 +854,7 @@ def main():
             iso2, launches2, cols2 = ctx.time_matvec(reps=2)
             curve2 = list(getattr(measure, "curve", []))
             curve2.append({"sweeps": "timed region", "moves_per_sweep": round(ev2, 1), "sweeps_per_s": round(K2 / el2, 2)})
-            blk = leg_block(side, el2, K2, W2, ev2, nnz2, miss2, ins2, iso2, launches2, cols2, bits2, 0, tuple(ctx.pipeline()[:3]), burn_s, curve2)
+            blk = leg_block(side, el2, K2, W2, ev2, nnz2, miss2, ins2, iso2, launches2, cols2, bits2, kind_main if bits2 == 2 else 0, tuple(ctx.pipeline()[:3]), burn_s, curve2)
             if key == "all_move":
                 blk["note"] = ("every marker moves every sweep: a sweep reads the genotypes twice (mat-vec and residual update), 2 n m bytes — "
                                "`achieved_GBps` prices both passes, `roofline` the mat-vec launches (whose update rows ride in them)")
@@ -874,7 +879,7 @@ def main():
                     ins3 = measure.insitu
                     ctx.time_matvec(reps=1)       # (the geometry by regime may have changed the launch width since the first leg: (2, 1) cold, (2, 2) converged)
                     iso3, launches3, cols3 = ctx.time_matvec(reps=2)
-                    blk["converged"] = leg_block(side, el3, K2, SIDE_WARMUP, ev3, nnz3, miss3, ins3, iso3, launches3, cols3, bits2, 0, tuple(ctx.pipeline()[:3]), int(st["sweeps"]))
+                    blk["converged"] = leg_block(side, el3, K2, SIDE_WARMUP, ev3, nnz3, miss3, ins3, iso3, launches3, cols3, bits2, kind_main if bits2 == 2 else 0, tuple(ctx.pipeline()[:3]), int(st["sweeps"]))
                     blk["converged"]["note"] = ("continued (effects + hyper-parameters, hb_warm_state) from the state stored in %s: this model on this synthetic data after %d sweeps "
                                                 "— the chain has found the signal, few markers are left in the model; %d untimed sweeps first"
                                                 % (args.secondary_state, int(st["sweeps"]), SIDE_WARMUP))
@@ -884,7 +889,7 @@ def main():
                                                     burn=args.burnin_converged, g_init=g2, warm=warm2)
                     curve3 = list(getattr(measure, "curve", []))
                     curve3.append({"sweeps": "timed region", "moves_per_sweep": round(ev3, 1), "sweeps_per_s": round(K2 / el3, 2)})
-                    blk["converged"] = leg_block(side, el3, K2, W2, ev3, nnz3, miss3, measure.insitu, iso2, launches2, cols2, bits2, 0, geo2,
+                    blk["converged"] = leg_block(side, el3, K2, W2, ev3, nnz3, miss3, measure.insitu, iso2, launches2, cols2, bits2, kind_main if bits2 == 2 else 0, geo2,
                                                  burn_s + W2 + K2 + args.stamped + 1 + args.burnin_converged, curve3)
                     blk["converged"]["note"] = ("the same run continued (effects + hyper-parameters, hb_warm_state) for %d more sweeps: the chain has "
                                                 "found the signal, few markers are left in the model" % args.burnin_converged)

@@ -40,7 +40,7 @@ def Bayes(y, X, model, Pi, Kival=None, Ki=None, C_=None, R=None, fold=None, nite
     `ctx` (an engine.Context with genotypes already resident) replaces X: one upload serves several fits;
     the context's own pipeline geometry, seed addressing (m_offset) and panel are then used as they are.
     `genotype_bits`: resident layout of the sweep — 0 (default) auto: 2 bits per genotype where that is exact and the faster sweep
-    (every code in 0..3, precise = 2, BayesB / BayesBpi / BayesC / BayesCpi at panel 512), int8 columns otherwise; 8 / 2 force one.
+    (every code in 0..3, precise = 2, BayesB / BayesBpi / BayesC / BayesCpi / BayesR with up to four classes, at panel 512), int8 columns otherwise; 8 / 2 force one.
     The chain is the same bit for bit; the result's "resident_bits" reports what ran.
     `warm` (a dict mu / vare / varg / pi / lambda2 / vargL, or a _lib.WarmState) with `g_init` continues a chain from a reported
     state instead of the prior defaults (hb_warm_state, include/hibayes_gpu.h).

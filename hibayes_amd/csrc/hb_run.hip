@@ -583,15 +583,19 @@ int hb_run::setup(const hb_bayes_args *args)
     // (BayesB / BayesC at panel 512: 450 against 213 sweeps/s at n = 50k, m = 500k; the same chain bit for bit). The models whose
     // launches cover one or two panels are bound by their chain workgroup and run the lighter int8 kernel beside it. 8 forces int8. ----
     int bits_run = a.genotype_bits == 2 ? 2 : 8;
-    if (a.genotype_bits == 0 && own_ctx && !rowmode && a.precise == 2 && (model_index == 3 || model_index == 4) && c->P == 512 &&
+    const bool sparse_bc = model_index == 3 || model_index == 4, mix_r = model_index == 6 && n_fold <= 4;
+    if (a.genotype_bits == 0 && own_ctx && !rowmode && a.precise == 2 && (sparse_bc || mix_r) && c->P == 512 &&
         c->pipeline && c->xmin >= 0 && c->xmax <= 3 && !getenv("HB_NO_AUTO_BITS")) {
-        // the band of the (3, 7) geometry and the packed genotypes must fit beside the int8 columns the band is built from
+        // (BayesR, measured late in round 6 with k_dotq2m beside both of its chains: 64.5 against 57.8 sweeps/s 300 sweeps after a cold start, 102.8 against 98.3
+        // converged — a quarter of the genotype bytes streaming past the chain workgroup's own round trips; round 4's "the 2-bit kernel only lengthens the
+        // launches" was the v_dot4 kernel)
+        // the band of the geometry — (3, 7): 28 blocks, BayesR's (2, 2): 6 — and the packed genotypes must fit beside the int8 columns the band is built from
         size_t fr = 0, tot = 0;
-        const size_t band = (size_t)28 * c->m_pad * c->P * sizeof(int32_t), x2 = (size_t)((c->ld + 511) / 512 * 128) * c->m_pad;
+        const size_t band = (size_t)(sparse_bc ? 28 : 6) * c->m_pad * c->P * sizeof(int32_t), x2 = (size_t)((c->ld + 511) / 512 * 128) * c->m_pad;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > band + x2 + ((size_t)2 << 30)) bits_run = 2;
         else (void)hipGetLastError();
     }
-    if (bits_run == 2 && own_ctx && a.genotype_bits == 0) {
+    if (bits_run == 2 && own_ctx && a.genotype_bits == 0 && sparse_bc) {
         rc = hb_ctx_set_pipeline(c, 1, 3, 7); // (set up as (2, 7) above; the third group of look-ahead pays on the 2-bit layout)
         if (rc) return rc;
     }

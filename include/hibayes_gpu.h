@@ -174,8 +174,9 @@ typedef struct hb_bayes_args {
      * (the dot products are exact integers either way). A context the run creates drops its int8 copy once the Gram blocks
      * are built; with a pre-loaded ctx the layout is the context's (hb_ctx_set_layout).
      * 0 = AUTO (what the Rcpp shim and ibrm() pass): 2 bits where that is exact and the faster sweep — every code in 0..3, precise = 2,
-     * BayesB / BayesBpi / BayesC / BayesCpi at panel 512 (the wide mat-vec launches; 450 against 213 sweeps/s at n = 50k, m = 500k), the
-     * band and the packed copy fitting the device — int8 columns otherwise. hb_bayes_out.resident_bits / hb_run_info.resident_bits
+     * BayesB / BayesBpi / BayesC / BayesCpi (450 against 213 sweeps/s at n = 50k, m = 500k) and BayesR with up to four classes (103 against 98
+     * converged, 64.5 against 58 cold) at panel 512, the band and the packed copy fitting the device — int8 columns otherwise (the models in which
+     * every marker moves, other genotype codes, small problems). hb_bayes_out.resident_bits / hb_run_info.resident_bits
      * report the choice. HB_NO_AUTO_BITS=1 in the environment keeps int8. */
     int32_t genotype_bits;
     /* Exact multi-GPU cross-check mode (ABI 4; SURVEY §8e "alternative rejected ... keep only as a correctness cross-check mode"):

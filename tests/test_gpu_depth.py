@@ -154,8 +154,15 @@ def test_auto_layout_picks_two_bits_where_exact_and_faster_and_is_the_same_chain
     assert rs["timing"]["resident_bits"] == 8
     with pytest.raises(H.HibayesError, match="codes 0..3"):
         H.Bayes(y, Xs, "BayesCpi", [0.95, 0.05], genotype_bits=2, **kw)
-    # a model whose launches cover one panel (chain-bound): int8; a small problem (panel < 512): int8
-    assert H.Bayes(y, X[:, :8192], "BayesR", [0.95, 0.02, 0.02, 0.01], fold=[0, 1e-4, 1e-3, 1e-2], **kw)["timing"]["resident_bits"] == 8
+    # BayesR with up to four classes at panel 512: 2 bits too (k_dotq2m beside both of its chains); the models in which every marker moves
+    # (dense update rows read int8 columns) and a small problem (panel < 512): int8
+    kr = dict(kw, fold=[0, 1e-4, 1e-3, 1e-2])
+    rr2 = H.Bayes(y, X[:, :8192], "BayesR", [0.95, 0.02, 0.02, 0.01], **kr)
+    rr8 = H.Bayes(y, X[:, :8192], "BayesR", [0.95, 0.02, 0.02, 0.01], genotype_bits=8, **kr)
+    assert (rr2["timing"]["resident_bits"], rr8["timing"]["resident_bits"]) == (2, 8)
+    for k in ("alpha", "pip", "g", "pi"):
+        assert np.array_equal(rr2[k], rr8[k]), k
+    assert H.Bayes(y, X[:, :8192], "BayesRR", [0.95, 0.05], **kw)["timing"]["resident_bits"] == 8
     assert H.Bayes(y, X[:, :2048], "BayesCpi", [0.95, 0.05], **kw)["timing"]["resident_bits"] == 8
 
 
