@@ -67,10 +67,15 @@
 #ifndef HBG_CH2MAX
 #define HBG_CH2MAX 31
 #endif
+#ifndef HB_CHAINDBG
+#define HB_CHAINDBG 0 /* development aid: progress markers of the chain workgroup in flags[20..22] (group, phase, rounds) */
+#endif
+#define HBG_DBGW(code) do { if (HB_CHAINDBG && lane == 0) st_flag(pv.flags + 24 + wave, (unsigned)(code)); } while (0)
+#define HBG_DBG(code) do { if (HB_CHAINDBG && t == 0) { st_flag(pv.flags + 20, (unsigned)gcount); st_flag(pv.flags + 21, (unsigned)(code)); } } while (0)
 #ifndef HBG_CERT_MARGIN
 #define HBG_CERT_MARGIN 1.0
 #endif
-template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false, bool CERT = false>
+template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false, bool CERT = false, bool FRESH = false>
 __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__ pin, const chain_view &v, const persist_view &pv, char *smem)
 {
     const int P = v.P, S = P >> 6;
@@ -152,6 +157,8 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
         __syncthreads();
     }
     int gslot = 0; // ring slot of the group's first panel
+    HBG_DBG(100); // staged, about to open the first group
+    if (HB_CHAINDBG && t == 0) st_flag(pv.flags + 43, (unsigned)wall_clock64());
     for (int gp0 = pv.p0; ok && gp0 < np; gp0 += D) {
         const int Dg = min(D, np - gp0);
         HBG_BEGIN();
@@ -218,14 +225,19 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
             HBG_MARK(19); // (the opening's values are in registers)
             if (__any(bad)) { // the mat-vec (or k_fwd) has not delivered (all of) this group yet: look again
                 const unsigned long long t0 = wall_clock64();
+                if (HB_CHAINDBG && t == 0) st_flag(pv.flags + 44, (unsigned)t0);
                 for (unsigned looks = 0;; looks++) {
                     bad = false;
-                    if (hb_fresh_look(looks)) { // (uniform; once in HB_FRESH_EVERY looks what is still missing is read at the memory side: ld_fresh, hb_kernels.hip)
+                    if (HB_CHAINDBG && t == 0) st_flag(pv.flags + 45, (unsigned)wall_clock64());
+                    if (FRESH || hb_fresh_look(looks)) { // (uniform; what is still missing is read at the memory side, ld_fresh in hb_handoff.hpp: once in
+                        // HB_FRESH_EVERY looks — or, beside the persistent mat-vec (FRESH: an instantiation of its own — as a run-time switch this branch cost the headline kernel, which sits at 256 registers, six spilled ones and 446 -> 421 sweeps/s), at every look: there no kernel boundary ever drops a line this XCD's L2
+                        // took before its words were published, and a word that HAS arrived is kept — it never changes again)
 #pragma unroll
                         for (int i = 0; i < HBG_DM; i++) {
                             const size_t j = (size_t)(gp0 + min(i, Dg - 1)) * P + t;
                             if (__double_as_longlong(dj[i]) == -1ll) dj[i] = ld_fresh(&v.dsum[j]);
                             if (far_in && __double_as_longlong(fc[i]) == -1ll) fc[i] = ld_fresh(&fcp[j]);
+                            if (!far_in) fc[i] = dj[i]; // (fc[] aliases the dots there: it must not keep the sum a NaN once the dots are in hand)
                         }
                     } else {
 #pragma unroll
@@ -242,6 +254,11 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
                         bad = sdf != sdf;
                     }
                     if (!__any(bad)) break;
+                    if (HB_CHAINDBG) { // what is missing, as the chain sees it: lanes with a NaN sum per wave, and thread 0's first words
+                        const unsigned long long bm = __ballot(bad);
+                        if (lane == 0) st_flag(pv.flags + 32 + wave, (unsigned)__popcll(bm));
+                        if (t == 0) { st_flag(pv.flags + 22, looks); st_flag(pv.flags + 40, (unsigned)(__double_as_longlong(dj[0]) >> 32)); st_flag(pv.flags + 41, (unsigned)(__double_as_longlong(fc[0]) >> 32)); st_flag(pv.flags + 42, far_in ? 1u : 0u); }
+                    }
                     {   // (advisor finding, round 5) "not delivered" is the sentinel's BIT PATTERN; a delivered word that is a NaN or an infinity (an upstream
                         // overflow) makes the sum a NaN too and would be polled until the time-out, replayed three times and reported as a time-out. If
                         // every word of a lane with a NaN sum is there, the fault is numerical: stop now and say so (fetch_acc: h_flags[15])
@@ -276,6 +293,7 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
             }
         }
         HBG_ACC(0);
+        HBG_DBG(1); // the group's dots are in hand
         const int32_t *gblk0 = v.gram + (size_t)gp0 * (pv.Lg + 1) * PP; // block l = 0 of the group's first panel
         const size_t pstep = (size_t)(pv.Lg + 2) * PP;                   // block l of panel p -> block l + 1 of panel p + 1
         // panels ahead that are owed the corrections by THIS workgroup (with k_fwd beside it: the next group's only)
@@ -313,6 +331,7 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
             if (lane < HBG_DM) wcnt[lane * 8 + wave] = cntv; // (one write per wave)
             if (t == 0) misc[1] = Dg * P;
             __syncthreads(); // B1
+            HBG_DBG(2);
             if (misc[2]) { ok = false; break; }
             int total, myscan;
             {   // exclusive scan of the (panel, wave) counts in every wave: lane = panel * 8 + wave
@@ -341,7 +360,9 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
                     inrm |= 1u << i;
                 }
             }
+            HBG_DBGW(21);
             __syncthreads(); // B2
+            HBG_DBGW(22);
             HBG_ACC(2);
             const int pos_hi = misc[1];
             // (2b) + (3) ONE round trip for both (round 5: they used to be two, the gather's loads issued only after the exact data had come back —
@@ -367,6 +388,7 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
                 for (int q = 1; q < 8; q++)
                     if (q < nq) gq[q] = gather_one(q); // (round 6: seven unconditional batches above eight candidates cost BayesR's 17-candidate rounds five batches of index arithmetic for nothing)
             }
+            HBG_DBGW(23);
             for (unsigned left = inrm; __any(left != 0u);) {
                 const bool mine = left != 0u;
                 const int i = mine ? __ffs((int)left) - 1 : 0;
@@ -423,7 +445,9 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
                     cg[idx] = gval;
                 }
             }
+            HBG_DBGW(25);
             __syncthreads(); // B3
+            HBG_DBG(3);
             HBG_ACC(3);
             bool stage_wait = false; // (per wave) this wave has pieces in flight
             if constexpr (CERT) {    // (the next group's records: by the waves that would otherwise stand at B4 while wave 0 walks the serial chain)
@@ -523,6 +547,7 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
                 if (stage_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the pieces have landed: these waves had nothing else to do)
             }
             __syncthreads(); // B4
+            HBG_DBG(4);
             HBG_ACC(4);
             const int nmoves = misc[0];
             // ---- (4b) CERT: decide the passed-over markers from the rank-one part of the moves and the bound on the rest ----
@@ -787,6 +812,7 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
             // the next group's first barrier the whole workgroup, ~25 000 cycles per group: profiles/r04_group_timeline_*.txt)
             if (lane == 0) st_flag(pv.flags + HB_FLAG_CHAIN_DONE, (unsigned)(gp0 + Dg));
         }
+        HBG_DBG(9);
         HBG_ACC(8);
         HBG_CNT(10, nmv_grp);
         HBG_CNT(13, nround);
@@ -820,12 +846,12 @@ __device__ __forceinline__ void chain_group_body(const hb_sweep_in *__restrict__
     }
 }
 
-template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false, bool CERT = false>
+template <int K1, int HBG_DM, int HBG_FW, int HBG_CH, bool G16 = false, bool CERT = false, bool FRESH = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_chain_group(const hb_sweep_in *__restrict__ pin, chain_view v,
                                                                                                  persist_view pv)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    chain_group_body<K1, HBG_DM, HBG_FW, HBG_CH, G16, CERT>(pin, v, pv, smem);
+    chain_group_body<K1, HBG_DM, HBG_FW, HBG_CH, G16, CERT, FRESH>(pin, v, pv, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -845,7 +871,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // k_chain_group_fwd below: one graph branch and one hardware queue instead of two)
 template <int HBF_D, int HBF_G>
 constexpr int hbf_lds_bytes(bool g16) { return HBF_D * 512 * 8 + HBF_D * 512 * 4 + (g16 ? HBF_D * 512 * 4 : 16) + (HBF_D + 1) * 4 + 16; }
-template <int HBF_D, int HBF_G, int HBF_CH, bool G16 = false>
+template <int HBF_D, int HBF_G, int HBF_CH, bool G16 = false, bool FRESH = false>
 __device__ __forceinline__ void fwd_body(const chain_view &v, const persist_view &pv, char *lds)
 {
     constexpr int NF = HBF_D * HBF_G;
@@ -875,9 +901,10 @@ __device__ __forceinline__ void fwd_body(const chain_view &v, const persist_view
             for (int i = 0; i < t && i < Dg; i++) {
                 int c = ld_sc1(&v.ev_count[(size_t)(gp0 + i) * HB_EVS]);
                 const unsigned long long t0 = wall_clock64();
+                unsigned looks = 0;
                 while (c < 0 && !ld_flag(pv.flags + HB_FLAG_ABORT) && wall_clock64() - t0 < HB_TIMEOUT_TICKS) {
                     __builtin_amdgcn_s_sleep(2);
-                    c = ld_sc1(&v.ev_count[(size_t)(gp0 + i) * HB_EVS]);
+                    c = ld_poll(&v.ev_count[(size_t)(gp0 + i) * HB_EVS], looks++, FRESH ? 4u : 0u);
                 }
                 if (c < 0) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); c = 0; s_ok = 0; }
                 a += c;
@@ -894,10 +921,12 @@ __device__ __forceinline__ void fwd_body(const chain_view &v, const persist_view
                 int ix = ld_sc1(&v.ev_idx[src]);
                 double dl = ld_sc1(&v.ev_delta[src]);
                 const unsigned long long t0 = wall_clock64();
+                unsigned looks = 0;
                 while ((ix < 0 || __double_as_longlong(dl) == -1ll) && !ld_flag(pv.flags + HB_FLAG_ABORT) && wall_clock64() - t0 < HB_TIMEOUT_TICKS) {
                     __builtin_amdgcn_s_sleep(2);
-                    ix = ld_sc1(&v.ev_idx[src]);
-                    dl = ld_sc1(&v.ev_delta[src]);
+                    ix = ld_poll(&v.ev_idx[src], looks, FRESH ? 4u : 0u);
+                    dl = ld_poll(&v.ev_delta[src], looks, FRESH ? 4u : 0u);
+                    looks++;
                 }
                 if (ix < 0 || __double_as_longlong(dl) == -1ll) { st_flag(pv.flags + HB_FLAG_ABORT, 1u); ix = 0; dl = 0.0; }
                 s_pos[b + k] = i * P + ix;
@@ -952,11 +981,11 @@ __device__ __forceinline__ void fwd_body(const chain_view &v, const persist_view
     }
 }
 
-template <int HBF_D, int HBF_G, int HBF_CH, bool G16 = false>
+template <int HBF_D, int HBF_G, int HBF_CH, bool G16 = false, bool FRESH = false>
 __global__ __launch_bounds__(512) void k_fwd(chain_view v, persist_view pv)
 {
     __shared__ __attribute__((aligned(16))) char lds[hbf_lds_bytes<HBF_D, HBF_G>(G16)];
-    fwd_body<HBF_D, HBF_G, HBF_CH, G16>(v, pv, lds);
+    fwd_body<HBF_D, HBF_G, HBF_CH, G16, FRESH>(v, pv, lds);
 }
 
 // ---------------------------------------------------------------------------------------------

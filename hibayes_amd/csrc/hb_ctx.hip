@@ -178,6 +178,7 @@ int hb_ctx_create(const hb_ctx_params *p, hb_ctx **out)
     if (const char *e = getenv("HB_DOTQ2_NC")) c->dotq2_nc = std::max(4, atoi(e) / 4 * 4);
     if (const char *e = getenv("HB_DOTQ2_RS")) c->dotq2_rs = atoi(e) == 256 ? 256 : atoi(e) == 128 ? 128 : 512;
     if (const char *e = getenv("HB_OVERLAP")) c->overlap = atoi(e) != 0;
+    if (const char *e = getenv("HB_MVP")) c->mvp = atoi(e) != 0;
     if (const char *e = getenv("HB_CHAIN")) c->chain_kind = std::strcmp(e, "panel") == 0 ? 0 : std::strcmp(e, "all") == 0 ? 3 : (atoi(e) ? atoi(e) : 1);
     if (const char *e = getenv("HB_WARM_GROUP")) c->warm_group = atoi(e) != 0;
     if (const char *e = getenv("HB_FWD")) c->fwd_group = atoi(e) != 0;
@@ -340,7 +341,7 @@ void hb_ctx_destroy(hb_ctx *c)
     if (c->s_fk) (void)hipStreamDestroy(c->s_fk);
     void *ptrs[] = {c->X, c->X2, c->xpx, c->vx, c->s1, c->g, c->vargL, c->alpha_sum, c->alpha_sq, c->tracker, c->nzrate, c->r, c->u,
                     c->r32, c->rq, c->vexp, c->gexp, c->mb, c->accq, c->gram, c->xinfo, c->thr, c->invv, c->sdz, c->partial, c->dsum, c->fcorr, c->ddense, c->fcorr2, c->dots, c->ev_count, c->ev_idx,
-                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->gram16, c->ga, c->gB, c->gcmax, c->g16_flag, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->opn, c->ru_ws, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa, c->snap, c->ldiag};
+                    c->ev_delta, c->acc, c->d_in, c->scratch, c->dbg, c->lstamp, c->flags, c->gram16, c->ga, c->gB, c->gcmax, c->g16_flag, c->hot_slot, c->hot_list, c->hot_n, c->thr0f, c->opn, c->ru_ws, c->mvp_ho, c->Cmat, c->zid, c->lev_buf, c->wind, c->wflag, c->wppa, c->snap, c->ldiag};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     blocks_free(c);
@@ -898,6 +899,29 @@ static int fetch_acc(hb_ctx *c)
                  c->h_flags[0], c->h_flags[8], c->h_flags[9], c->h_flags[10], c->h_flags[11], c->h_flags[12], c->h_flags[13], c->h_flags[14],
                  c->h_flags[1] ? "" : "; raised on another rank");
         if (getenv("HB_DEBUG_ABORT") && c->h_flags[1]) print_abort_diagnostics(c);
+        if (getenv("HB_DEBUG_ABORT") && c->mvp_ho) { // (the persistent mat-vec's hand-over counters: versions signed off, finalize tickets of the first groups)
+            const int ng = (c->npanels + c->D - 1) / c->D;
+            std::vector<unsigned> ho((size_t)ng + 1 + 4 * 64);
+            if (hipMemcpy(ho.data(), c->mvp_ho, sizeof(unsigned) * ho.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "  chain progress markers (HB_CHAINDBG builds): group %u phase %u; waves %u %u %u %u %u %u %u %u\n", c->h_flags[20], c->h_flags[21], c->h_flags[24], c->h_flags[25], c->h_flags[26], c->h_flags[27], c->h_flags[28], c->h_flags[29], c->h_flags[30], c->h_flags[31]);
+                fprintf(stderr, "  chain opening: looks %u, lanes still missing per wave %u %u %u %u %u %u %u %u, thread 0: dj[0] hi %08x fc[0] hi %08x far_in %u\n", c->h_flags[22], c->h_flags[32], c->h_flags[33], c->h_flags[34], c->h_flags[35], c->h_flags[36], c->h_flags[37], c->h_flags[38], c->h_flags[39], c->h_flags[40], c->h_flags[41], c->h_flags[42]);
+                fprintf(stderr, "  chain clocks (low 32 bits, 100 MHz): staged %u, poll loop entered %u, last look began %u (the abort log's clocks modulo 2^32 are on the same scale)\n", c->h_flags[43], c->h_flags[44], c->h_flags[45]);
+                fprintf(stderr, "  mvp: versions signed off by update workgroups: slots 0..7 =");
+                for (int i = 0; i < 8 && i <= ng; i++) fprintf(stderr, " %u", ho[i]);
+                fprintf(stderr, "; finalize tickets of group 0, column groups 0..15 =");
+                for (int i = 0; i < 64; i++) fprintf(stderr, " %u", ho[(size_t)ng + 1 + i]);
+                fprintf(stderr, "; of group 3 =");
+                for (int i = 0; i < 8; i++) fprintf(stderr, " %u", ho[(size_t)ng + 1 + 3 * 64 + i]);
+                std::vector<double> ds((size_t)c->D * c->P);
+                if (hipMemcpy(ds.data(), c->dsum, sizeof(double) * ds.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+                    int bad = 0, first = -1;
+                    for (size_t i = 0; i < ds.size(); i++)
+                        if (ds[i] != ds[i]) { if (first < 0) first = (int)i; bad++; }
+                    fprintf(stderr, "; dsum of group 0: %d of %zu words not a number (first at %d); [0..3] = %g %g %g %g", bad, ds.size(), first, ds[0], ds[1], ds[2], ds[3]);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
         if (c->h_flags[15]) // (k_chain_group: every word of a group was delivered and one of them is not finite — a numerical fault upstream, not a lost hand-off)
             return hb_fail(HB_ERR_ABORTED, std::string("a non-finite right-hand side reached the chain (dot product or correction overflowed): ") + msg);
         return hb_fail(HB_ERR_ABORTED, msg);

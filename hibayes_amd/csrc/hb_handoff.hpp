@@ -116,16 +116,23 @@ __device__ __forceinline__ int ld_fresh(const int *p)
 {
     return (int)__hip_atomic_fetch_or(reinterpret_cast<unsigned *>(const_cast<int *>(p)), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Round 6: the same decided by the CALLER (`every`: 0 = never; a kernel argument or a template constant — never a device global: read in the update rows'
+// first look, its scalar load cost every launch of the pipeline 0.6 us, 446 -> 421 sweeps/s). Under the launches of the pipeline a reader's stale line lives
+// at most until the next launch starts — every kernel begins by invalidating its XCD's L2 — which is why the stale-line stall was rare. With the PERSISTENT
+// mat-vec (hb_mvp.hpp) nothing is launched for the whole sweep: a line fetched before its word was published is served from the reader's L2 until something
+// evicts it (the chain workgroup polled its first group's dots too early and never saw them: every sweep timed out). Every fourth look of every wait is
+// then a memory-side one.
 // (uniform) is this look of a wait a memory-side one?
-__device__ __forceinline__ bool hb_fresh_look(unsigned looks)
+__device__ __forceinline__ bool hb_fresh_look(unsigned looks, unsigned every = 0u)
 {
 #if HB_FRESH_EVERY > 0
-    return (looks % HB_FRESH_EVERY) == HB_FRESH_EVERY - 1;
-#else
-    (void)looks;
-    return false;
+    if ((looks % HB_FRESH_EVERY) == HB_FRESH_EVERY - 1) return true;
 #endif
+    return every != 0u && (looks % every) == every - 1u;
 }
+__device__ __forceinline__ int ld_poll(const int *p, unsigned looks, unsigned every = 0u) { return hb_fresh_look(looks, every) ? ld_fresh(p) : ld_sc1(p); }
+__device__ __forceinline__ double ld_poll(const double *p, unsigned looks, unsigned every = 0u) { return hb_fresh_look(looks, every) ? ld_fresh(p) : ld_sc1(p); }
+__device__ __forceinline__ unsigned ld_poll_flag(const unsigned *p, unsigned looks, unsigned every = 0u) { return hb_fresh_look(looks, every) ? ld_flag_fresh(p) : ld_flag(p); }
 
 // A wait that has lasted a few hundred looks writes back the dirty lines of ITS OWN XCD's L2 (buffer_wbl2 sc1). What the launch
 // stamps and the memory-side looks of round 4 showed about the dense stall (profiles/r04_dense_stall_diagnostics.txt): once in a few

@@ -74,6 +74,10 @@ struct hb_ctx {
     hipStream_t s_t2 = nullptr, s_uk = nullptr, s_fk = nullptr;
     std::vector<hipEvent_t> ev_ot, ev_ou; // per mat-vec group: its tiles are done / its residual update is done
     int overlap = 0;                      // 0 off, 1 on (HB_OVERLAP)
+    // round 6: the persistent mat-vec (hb_mvp.hpp; HB_MVP): digit planes and exponents per residual VERSION (rq / vexp grown to rq_slots slots), hand-over counters
+    int mvp = 0;
+    int rq_slots = 8;
+    unsigned *mvp_ho = nullptr;
     std::vector<hipEvent_t> ev_dot, ev_chain, ev_upd; // cross-stream dependencies of one sweep
     hipEvent_t ev_fork = nullptr;
 

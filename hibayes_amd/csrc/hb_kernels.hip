@@ -41,6 +41,16 @@
 #include "hb_update.hpp"
 #include "hb_matvec.hpp"
 #include "hb_dotq2.hpp"
+// The persistent mat-vec is an EXPERIMENT (round 6; DESIGN section 6.0: it does not hold the pace of the launches and stalls at the wide geometry): built only
+// with -DHB_WITH_MVP=1 (tools/build_variant.sh mvp "-DHB_WITH_MVP=1"; then HB_MVP=1 selects it). Its instantiations stay out of the default library on
+// purpose: merely having them in this translation unit changed the inlining around the headline chain kernel, which sits at 256 registers — five spilled
+// registers, 446 -> 421 sweeps/s (tools/kernel_resources.sh shows the spills per kernel).
+#ifndef HB_WITH_MVP
+#define HB_WITH_MVP 0
+#endif
+#if HB_WITH_MVP
+#include "hb_mvp.hpp"
+#endif
 
 // Sweep start of the fixed-point path: max |yadj| -> mb[0] and the exponent of slot 0, then slot 0's digit planes.
 // One workgroup (n is a few hundred KB).
@@ -179,6 +189,10 @@ int hbk_init_attrs()
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group_fwd<1, 8, 7, 4, true, 7, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_GROUP_ATTR16(1, 8, 7, 4);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 8, 7, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#if HB_WITH_MVP
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 8, 7, 4, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 2, 4, 10, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_dense<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -725,6 +739,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     const bool overlap = c->overlap && fx && !dense && !alone && !c->lstamp && ngroups > Lv + 2 && Lv + 1 <= 8 && c->s_fk != nullptr &&
                          fwd && !fwd2 && cert && kp == 1 && !g16 && warm_r_env_off;
     const bool merged = overlap;
+    // round 6: the persistent mat-vec (hb_mvp.hpp, HB_MVP=1): 2-bit genotypes, matrix-core tiles on 512-individual stages, whole sweeps
+    const bool mvp = HB_WITH_MVP && c->mvp && fx && c->layout == 2 && c->X2 && c->dotq2_kind == 2 && (c->q2m_g == 0) && c->ld % 512 == 0 && !dense && !alone && !overlap &&
+                     pb == 0 && ngroups > Lv + 2 && c->rq_slots >= ngroups + 1 && c->mvp_ho != nullptr &&
+                     kp == 1 && group_chain && !g16 && ((fwd && cert) || (!fwd && shape == 1)); // (the two chain shapes instantiated with memory-side looks)
     if (fwd) pv.fcorr = c->fcorr;
     if (c->L > HB_LBMAX && !fwd)
         return hb_fail(HB_ERR_UNSUPPORTED, "three groups of seven panels of look-ahead need the group chain with k_fwd (BayesB / BayesC, panel 512)");
@@ -761,6 +779,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
                 else if (cert && c->P == 512 && !getenv("HB_CERT_NARROW_OFF")) hipLaunchKernelGGL((k_chain_group<3, 2, 4, 10, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv); // (shape 1: D = 2, certified)
                 else hipLaunchKernelGGL((k_chain_group<3, 2, 4, 10>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv); // (shape 1: D = 2; shape 2 needs D <= 1)
             }
+#if HB_WITH_MVP
+            else if (mvp && fwd) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, false, true, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+            else if (mvp) hipLaunchKernelGGL((k_chain_group<1, 2, 4, 10, false, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
+#endif
             else if (fwd && g16) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (fwd && cert) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (fwd) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
@@ -799,7 +821,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
             if (int rc = launch_the_chain(sB)) return rc;
             // (the first mat-vec launch starts when the chain is resident; HB_GATE=0 / 1 overrides: by default only where a launch's
             // update blocks can sit on every compute unit)
-            bool gate = dense || overlap; // (overlap: up to Lv + 1 tile launches start at once and leave no compute unit free for the chain's 160 KB of LDS)
+            bool gate = dense || overlap || mvp; // (overlap / persistent mat-vec: tiles from the first microsecond on, no compute unit left free for the chain's 160 KB of LDS)
             if (const char *e = getenv("HB_GATE")) gate = atoi(e) != 0;
             if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sA, c->flags);
         }
@@ -843,6 +865,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     if (fwd && !merged) {
         HB_HIP(hipStreamWaitEvent(c->s_upd, c->ev_fork, 0));
         if (fwd2) hipLaunchKernelGGL((k_fwd<2, 1, 16>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+#if HB_WITH_MVP
+        else if (mvp && Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8, false, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+        else if (mvp) hipLaunchKernelGGL((k_fwd<7, 2, 4, false, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
+#endif
         else if (Lv == 2 && g16) hipLaunchKernelGGL((k_fwd<7, 1, 8, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else if (Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else if (g16) hipLaunchKernelGGL((k_fwd<7, 2, 4, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
@@ -873,7 +899,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     }
     if (side_first) {
         if (int rc = launch_the_chain(sB)) return rc;
-        bool gate = dense || overlap;
+        bool gate = dense || overlap || mvp;
         if (const char *e = getenv("HB_GATE")) gate = atoi(e) != 0;
         if (gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, sA, c->flags);
     }
@@ -919,12 +945,61 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         HB_HIP(hipStreamWaitEvent(sA, c->ev_ot[0], 0));
         HB_HIP(hipStreamWaitEvent(sA, c->ev_ou[ngroups - 1], 0));
     }
+#if HB_WITH_MVP
+    if (mvp) {
+        const int ncols = D * c->P, nst = (int)(c->ld / 512), ncg = ncols / 64, nupd_blk = (int)(c->ld / 256);
+        // tiles per group: as a k_dotq2m launch sizes them (launch_dotq2) — all workgroups of the kernel resident at once
+        int ns = std::max(1, std::min(std::max(1, nst / 4), (int)(900.0 / ncg + 0.5)));
+        const int ns_min = std::max(1, (int)(((int64_t)nst * 512 + 131071) / 131072));
+        ns = std::max(ns, ns_min);
+        {
+            const int lds = q2m512_lds<false>(), per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, lds))), cus_per_xcd = std::max(1, c->num_cus / 8);
+            const int budget = 8 * (cus_per_xcd * per_cu - (per_cu + 3));
+            auto total = [&](int k) { const int NSk = (nst + k - 1) / k; return nupd_blk + ncg * ((nst + NSk - 1) / NSk); };
+            while (ns > ns_min && total(ns) > budget) ns--;
+        }
+        const int NS = (nst + ns - 1) / ns, nsplit = (nst + NS - 1) / NS;
+        mvp_view mv{};
+        mv.v0.X = nullptr;
+        mv.v0.X2 = reinterpret_cast<const uint8_t *>(c->X2) + (int64_t)(g0 * D) * c->P * c->ld2;
+        mv.v0.ld2 = c->ld2;
+        mv.v0.ld = c->ld;
+        mv.v0.gexp_out = c->gexp + g0;
+        mv.v0.accq = c->accq + (int64_t)(g0 * D) * c->P;
+        mv.v0.accstride = c->m_pad;
+        mv.v0.nstages = nst;
+        mv.v0.NS = NS;
+        mv.v0.ncg = ncg;
+        mv.u0 = make_upd(c, 0, 0, 0, 0, c->flags, 0);
+        auto envi = [](const char *k, int d) { const char *e = getenv(k); return e ? atoi(e) : d; };
+        mv.ufresh = std::max(1, envi("HB_MVP_UFRESH", 4));
+        mv.usleep = std::max(0, envi("HB_MVP_USLEEP", 0));
+        mv.tfresh = std::max(1, envi("HB_MVP_TFRESH", 4));
+        mv.tsleep = std::max(0, envi("HB_MVP_TSLEEP", 0));
+        mv.ngroups = ngroups; mv.D = D; mv.np = np; mv.g0 = g0; mv.Lv = Lv;
+        mv.ntile = ncg * nsplit; mv.nupd = nupd_blk; mv.nsplit = nsplit;
+        mv.rqv = c->rq; mv.vexpv = c->vexp; mv.r = c->r; mv.mb = c->mb; mv.r32 = c->r32; mv.dsum = c->dsum;
+        mv.ho = c->mvp_ho; mv.flags = c->flags;
+        mv.rel = c->mvp_ho + ((size_t)(c->npanels + 2) * 65); // (behind the counters: 64 lines)
+        mv.stamp = nullptr;
+        const int nblk = mv.nupd + mv.ntile;
+        if (c->lstamp && nblk <= HB_LSTAMP_BLOCKS) {
+            mv.stamp = c->lstamp;
+            for (int g = 0; g < ngroups; g++) { c->lstamp_nblk[g0 + g] = nblk; c->lstamp_cols[g0 + g] = (std::min(np, (g0 + g + 1) * D) - (g0 + g) * D) * c->P; }
+        }
+        HB_HIP(hipMemsetAsync(c->mvp_ho, 0, sizeof(unsigned) * ((size_t)(ngroups + 1) + (size_t)ngroups * 64), sA));
+        HB_HIP(hipMemsetAsync(mv.rel, 0, sizeof(unsigned) * 64 * 32, sA));
+        if (c->q2m_sc) hipLaunchKernelGGL((k_mvp2<true>), dim3(nblk), dim3(64), q2m512_lds<false>(), sA, mv);
+        else hipLaunchKernelGGL((k_mvp2<false>), dim3(nblk), dim3(64), q2m512_lds<false>(), sA, mv);
+        HB_HIP(hipGetLastError());
+    }
+#endif
     // Residual versions advance per mat-vec group: version h = every panel of groups <= h applied. Mat-vec launch g
     // reads version g - Lv - 1 and, in one extra grid row, carries update(h = g - Lv): version h-1 -> h, which the
     // NEXT launch reads. Two buffers ping-pong (slot = (version + 1) & 1). No third stream, no cross-stream events.
     auto slot2 = [](int v) { return v < 0 ? 0 : ((v + 1) & 1); };
     // (g, h: group indices within the range — they drive the version slots; ga, ha: the absolute ones — they address panels)
-    for (int g = 0; g < ngroups && !overlap; g++) {
+    for (int g = 0; g < ngroups && !overlap && !mvp; g++) {
         const int ga = g0 + g;
         const int p0 = ga * D, p1 = std::min(np, p0 + D);
         const int h = g - Lv, ha = g0 + h;
@@ -943,10 +1018,10 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         launch_dot(c, p0 * c->P, (p1 - p0) * c->P, slot2(g - Lv - 1), sA, true, ride ? &uq : nullptr,
                    g > 0 ? (ga - 1) * D * c->P : 0, g > 0 ? D * c->P : 0, ga);
     }
-    if (!overlap) launch_reduce(c, (g0 + ngroups - 1) * D * c->P, last_panels * c->P, sA, g0 + ngroups - 1);
+    if (!overlap && !mvp) launch_reduce(c, (g0 + ngroups - 1) * D * c->P, last_panels * c->P, sA, g0 + ngroups - 1);
     if (alone)
         if (int rc = launch_the_chain(sA)) return rc;
-    for (int h = std::max(0, ngroups - Lv); h < ngroups && !overlap; h++) { // the updates that had no later mat-vec to ride on
+    for (int h = std::max(0, ngroups - Lv); h < ngroups && !overlap && !mvp; h++) { // the updates that had no later mat-vec to ride on
         upd_view uq = make_upd(c, (g0 + h) * D, std::min(np, (g0 + h) * D + D), slot2(h - 1), slot2(h), c->flags, g0 + h);
         if (dense_upd && c->layout == 8 && D <= 2) {
             uq.dense = 1;
@@ -995,9 +1070,34 @@ static int overlap_resources(hb_ctx *c)
     return HB_OK;
 }
 
+// the persistent mat-vec's buffers (outside any capture): digit planes and exponents for every residual version of a sweep, the hand-over counters
+static int mvp_resources(hb_ctx *c)
+{
+    const int need = c->npanels + 2;
+    if (c->rq_slots < need) {
+        HB_HIP(hipStreamSynchronize(c->stream));
+        int8_t *rq = nullptr;
+        int *vexp = nullptr;
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&rq), (size_t)c->ld * HB_ND * need));
+        HB_HIP(hipMalloc(reinterpret_cast<void **>(&vexp), sizeof(int) * need));
+        HB_HIP(hipMemset(rq, 0, (size_t)c->ld * HB_ND * need));
+        HB_HIP(hipMemset(vexp, 0, sizeof(int) * need));
+        (void)hipFree(c->rq);
+        (void)hipFree(c->vexp);
+        c->rq = rq;
+        c->vexp = vexp;
+        c->rq_slots = need;
+        c->graph_model = -1; // (the captured sweeps hold the old pointers)
+    }
+    if (!c->mvp_ho) HB_HIP(hipMalloc(reinterpret_cast<void **>(&c->mvp_ho), sizeof(unsigned) * ((size_t)(c->npanels + 2) * 65 + 64 * 32)));
+    return HB_OK;
+}
+
 int hb_sweep_enqueue(hb_ctx *c, const hb_sweep_in *in, bool timed)
 {
     if (int rc = hbk_set_timeout(c)) return rc;
+    if (c->mvp && c->pipeline && c->precise == 2 && c->layout == 2 && (c->rq_slots < c->npanels + 2 || !c->mvp_ho))
+        if (int rc = mvp_resources(c)) return rc;
     if (c->overlap && c->pipeline && !c->s_fk)
         if (int rc = overlap_resources(c)) return rc;
     *c->h_in = *in;

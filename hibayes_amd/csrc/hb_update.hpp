@@ -47,6 +47,7 @@ __device__ __forceinline__ int hb_fix_exp(double bound)
 }
 
 // balanced base-256 digits of four fixed-point values, packed per plane (byte b = row b)
+template <bool WT = false>
 __device__ __forceinline__ void hb_store_digits(int8_t *rq, int64_t ld, int64_t row0, int E, double r0, double r1, double r2, double r3)
 {
     long long q[4] = {__double2ll_rn(ldexp(r0, E)), __double2ll_rn(ldexp(r1, E)), __double2ll_rn(ldexp(r2, E)),
@@ -60,13 +61,18 @@ __device__ __forceinline__ void hb_store_digits(int8_t *rq, int64_t ld, int64_t 
             q[b] = (q[b] - d) >> 8;
             w |= ((unsigned)d & 0xffu) << (8 * b);
         }
-        *reinterpret_cast<unsigned *>(rq + (int64_t)k * ld + row0) = w;
+        if constexpr (WT) __hip_atomic_store(reinterpret_cast<unsigned *>(rq + (int64_t)k * ld + row0), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *reinterpret_cast<unsigned *>(rq + (int64_t)k * ld + row0) = w;
     }
 }
 
 // rows [row0, row0 + 4) of the residual: yadj -= sum_e x_e D_e, u += the same, r32 = (float)yadj
+// (MVP: inside the persistent mat-vec, hb_mvp.hpp — memory-side looks every fourth look of a wait, planes and exponent written through; a template
+// constant, so that the update rows of the pipeline's launches are the code they were)
+template <bool MVP = false>
 __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int blk, int *s_ix,
-                                            double *s_dl, int *s_ok, unsigned long long *ust = nullptr)
+                                            double *s_dl, int *s_ok, unsigned long long *ust = nullptr, int mvp_fresh = 0, int mvp_sleep = 0)
+// (mvp_fresh, mvp_sleep — update_rows<true> only: every mvp_fresh-th look of a wait at the memory side, mvp_sleep extra naps of 64 x 64 cycles per look)
 {
     // (ust: HB_DEBUG_ABORT diagnostics — block 64 of the launch leaves the lengths of its phases, four 16-bit counts of 100 MHz ticks:
     // poll of counts and bound | move lists | columns and sums | stores; tools/launch_roles.py prints their means)
@@ -106,10 +112,19 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
         }
 #endif
         const unsigned long long t0 = wall_clock64();
+        unsigned looks = 0;
+        (void)looks;
         for (;;) {
+            if constexpr (MVP) {
+                if (q.rq) mbv = ld_poll(q.mbv, looks, (unsigned)mvp_fresh);
+#pragma unroll
+                for (int i = 0; i < 8; i++) nevs[i] = ld_poll(q.ev_count + (size_t)min(q.p0 + i, q.p1 - 1) * HB_EVS, looks, (unsigned)mvp_fresh);
+                looks++;
+            } else {
             if (q.rq) mbv = ld_sc1(q.mbv); // (every thread the same word: one broadcast load per wave, in flight with the counts)
 #pragma unroll
             for (int i = 0; i < 8; i++) nevs[i] = ld_sc1(q.ev_count + (size_t)min(q.p0 + i, q.p1 - 1) * HB_EVS);
+            }
             if (!poll) break; // (the per-panel kernels: a kernel boundary separates this from the chain)
             bool bad = q.rq && __double_as_longlong(mbv) == -1ll;
 #pragma unroll
@@ -124,10 +139,11 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
                 return;
             }
             __builtin_amdgcn_s_sleep(8);
+            if constexpr (MVP) for (int z = 0; z < mvp_sleep; z++) __builtin_amdgcn_s_sleep(64);
         }
         if (q.rq) { // (uniform) exponent of the new version, the same number in every workgroup
             fixE = hb_fix_exp(mbv);
-            if (blk == 0 && threadIdx.x == 0) *q.vexp_out = fixE;
+            if (blk == 0 && threadIdx.x == 0) { if constexpr (MVP) st_sc1(q.vexp_out, fixE); else *q.vexp_out = fixE; }
         }
     }
     if (ust) tB = tC = tD = wall_clock64();
@@ -158,11 +174,19 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
             double dl = ld_sc1(q.ev_delta + src);
             if (q.flags) { // (an entry whose count is already visible may itself still be on its way: pre-filled like the counts)
                 const unsigned long long t1 = wall_clock64();
+                unsigned looks = 0;
+                (void)looks;
                 while (ix < 0 || __double_as_longlong(dl) == -1ll) {
                     if (ld_flag(q.flags + HB_FLAG_ABORT) || wall_clock64() - t1 > HB_TIMEOUT_TICKS) { st_flag(q.flags + HB_FLAG_ABORT, 1u); ix = 0; dl = 0.0; break; }
                     __builtin_amdgcn_s_sleep(2);
+                    if constexpr (MVP) {
+                        ix = ld_poll(q.ev_idx + src, looks, (unsigned)mvp_fresh);
+                        dl = ld_poll(q.ev_delta + src, looks, (unsigned)mvp_fresh);
+                        looks++;
+                    } else {
                     ix = ld_sc1(q.ev_idx + src);
                     dl = ld_sc1(q.ev_delta + src);
+                    }
                 }
             }
             s_ix[e] = i * q.P + ix; // the move's COLUMN, counted from the group's first (a 32-bit byte offset from a scalar base then addresses it: one register per load in flight instead of two)
@@ -222,7 +246,7 @@ __device__ __forceinline__ void update_rows(int64_t ld, const upd_view &q, int b
     *reinterpret_cast<double2 *>(q.r + row0) = r01;
     *reinterpret_cast<double2 *>(q.r + row0 + 2) = r23;
     *reinterpret_cast<float4 *>(q.r32 + row0) = make_float4((float)r01.x, (float)r01.y, (float)r23.x, (float)r23.y);
-    if (q.rq) hb_store_digits(q.rq, ld, row0, fixE, r01.x, r01.y, r23.x, r23.y);
+    if (q.rq) hb_store_digits<MVP>(q.rq, ld, row0, fixE, r01.x, r01.y, r23.x, r23.y);
     if (total) {
         u01.x += a0; u01.y += a1; u23.x += a2; u23.y += a3;
         *reinterpret_cast<double2 *>(q.u + row0) = u01;

@@ -235,3 +235,34 @@ def test_bench_line_stays_small_enough_for_the_driver_to_parse():
                allreduce={"ms_per_call_back_to_back": 0.05, "bytes": 400128}, strong={"value": 900.0, "m_global": 2000000, "m_per_gpu": 250000, "ms_per_step": 4.4, "model": "BayesCpi"})
     out8 = json.loads(bench.compact_line(res, "x"))
     assert out8["strong_value"] == 900.0 and out8["ranks_counted_by_all_reduce"] == 8 and out8["per_rank_ms_per_step"]["max"] == 2.3 and out8["allreduce"]["ms_per_call"] == 0.05
+
+
+def test_hot_kernels_are_built_without_register_spills():
+    """The compiler's per-kernel resource report of the last build (hibayes_amd/csrc/hb_kernels.res.txt, written by the Makefile).
+    The headline chain kernel sits at the 256-register limit of a 512-thread workgroup: in round 6 five spilled registers — caused by nothing
+    more than other instantiations being added to the translation unit — cost 446 -> 421 sweeps/s without any test noticing."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hibayes_amd", "csrc", "hb_kernels.res.txt")
+    if not os.path.exists(path):
+        pytest.skip("no resource report: the library was not built by the Makefile here")
+    rows, cur = {}, None
+    for line in open(path):
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            rows[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+) \[-Rpass", line)
+        if m and cur:
+            rows[cur][m.group(1).replace(" ", "")] = int(m.group(2))
+    hot = {
+        "headline chain (BayesB / BayesC, wide certified groups)": "_Z13k_chain_groupILi1ELi8ELi7ELi4ELb0ELb1E",
+        "BayesR group chain": "_Z13k_chain_groupILi3ELi2ELi2ELi15ELb0ELb1E",
+        "2-bit matrix-core mat-vec": "_Z8k_dotq2mILi4E",
+        "int8 mat-vec": "_Z6k_dotq7dq_view",
+    }  # (k_chain_dense does spill — 11 registers, 28 bytes —, has since round 4, and only outside its sub-block loop: eleven scratch instructions at the head and the tail of the panel loop)
+    for what, prefix in hot.items():
+        found = [k for k in rows if k.startswith(prefix)]
+        assert found, "kernel missing from the report: %s (%s)" % (what, prefix)
+        for k in found:
+            assert rows[k].get("ScratchSize", 0) == 0 and rows[k].get("VGPRsSpill", 0) == 0, "%s spills: %s %s" % (what, k, rows[k])
