@@ -157,6 +157,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 #define HBD_STEP(s, BUF)                                                                                                          \
     do {                                                                                                                          \
+        if (HB_STAMPS && (s) == 2 && t == 128 && v.dbg) v.dbg[(size_t)p * 32 + 13] = clock64(); /* the serial wave of step 2 enters the step */ \
         if ((s) > 0 && wave >= (s) && wave - ((s) - 1) <= HBD_NEAR) { /* the changes of sub-block s - 1 onto the NEAR later markers of the panel */                    \
             const double2 *d2_ = reinterpret_cast<const double2 *>(dl + 64 * ((s) - 1));                                          \
             _Pragma("unroll") for (int k = 0; k < 64; k += 2) {                                                                   \
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             /* itself is fma - sub - readlane - fma on the chain: 70 cycles per marker, the first version).                        */ \
             double sv_ = fma(rhs, invv, sdz) - gold;                                                                              \
             const double ninvv_ = -invv;                                                                                          \
+            if (HB_STAMPS && (s) == 2 && lane == 0 && v.dbg) v.dbg[(size_t)p * 32 + 14] = clock64(); /* ... starts its serial pass */ \
             if (!LASSO) {                                                                                                         \
                 _Pragma("unroll") for (int k = 0; k < 64; k++) sv_ = fma((double)dg[k] * ninvv_, readlane_f64(sv_, k), sv_);      \
                 gn_f = act ? gold + sv_ : 0.0;                                                                                    \
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 gn_f = act ? (cl_ ? 1e-6 : gold + sv_) : 0.0;                                                                     \
                 dmine = act ? (cl_ ? forced_ : sv_) : 0.0;                                                                        \
             }                                                                                                                     \
+            if (HB_STAMPS && (s) == 2 && lane == 0 && v.dbg) v.dbg[(size_t)p * 32 + 15] = clock64(); /* ... has finished it */    \
             dl[t] = dmine;                                                                                                        \
             st_sc1(&dd[j], dmine); /* k_fold_dense is waiting for exactly this */                                                 \
         }                                                                                                                         \

@@ -65,4 +65,6 @@ with H.Context(n, m, panel=512, seed=20240901) as c:
         ref = a[:, 3]  # after barrier 1 = start of step 2
         print("step 2, cycles after its start, by wave: apply done %s; at the barrier %s; barrier released %d" % (
             [int((a[:, 24 + w] - ref).mean()) for w in range(8)], [int((a[:, 16 + w] - ref).mean()) for w in range(8)], (a[:, 4] - ref).mean()))
+        print("step 2, its serial wave (wave 2), cycles after the step's start: enters %d | strips applied %d | serial pass starts %d | ends %d | at the barrier %d (a stamp costs ~400 cycles itself)" % (
+            (a[:, 13] - ref).mean(), (a[:, 26] - ref).mean(), (a[:, 14] - ref).mean(), (a[:, 15] - ref).mean(), (a[:, 18] - ref).mean()))
         print("poll percentiles", np.percentile(a[:, 0] - a[:, 11], [10, 50, 90]).astype(int), "panel percentiles", np.percentile(per, [10, 50, 90]).astype(int))
