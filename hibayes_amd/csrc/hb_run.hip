@@ -93,6 +93,7 @@ struct hb_run {
     double mu_sum = 0, vara_sum = 0, vare_sum = 0, hsq_sum = 0, events_sum = 0, miss_sum = 0, redo_sum = 0;
     int sync_blocks = 1;       // runs of mat-vec groups per sweep, an exchange after each (hb_bayes_args.sync_blocks)
     bool recover_on = true;    // replay a sweep whose pipeline timed out (HB_RECOVER=0: fail the run, as before round 4)
+    int pipeline_setup = -1;   // sharded runs: the context's pipeline switch as the ranks agreed on it in setup (checked at every step)
     int aborts = 0;            // sweeps replayed so far
     int abort_win_start = 0, abort_win_count = 0, slow_timeout = 0; // three aborts within 64 iterations: a slow device, the run's time-out is raised
     bool adaptive_geo = false; // choose (Lv, D) per sweep from the previous sweep's moves (BayesB/C; round 6: BayesR)
@@ -577,6 +578,7 @@ int hb_run::setup(const hb_bayes_args *args)
                 fprintf(stderr, "hibayes_gpu: rank %d: sweep replay switched off — not every rank can replay (HB_RECOVER / pipeline availability differ)\n", a.rank);
             recover_on = false;
         }
+        pipeline_setup = c->pipeline ? 1 : 0;
     }
     // ---- resident layout (round 6): genotype_bits = 0 is "auto" — 2 bits per genotype where that is exact AND the faster sweep: codes
     // 0..3 (PLINK's own alphabet, src/read_bed.cpp:116-120), the fixed-point mat-vec, and the point-mass models' wide launches
@@ -850,6 +852,11 @@ int hb_run::step()
     // saved here: effects, residual, u and the posterior counters, a few MB copied by one kernel. The draws are counter-based, so the
     // replay is the same chain. A second failure of the same sweep replays it on the event-ordered per-panel kernels, which wait
     // for nothing on the device; sharded, the abort reaches every rank through the exchange and all of them replay.
+    // (advisor finding, round 5) the replay decision was agreed by all ranks in setup on the context's pipeline switch as it was then; a caller that flips
+    // it on one rank afterwards (hb_ctx_set_pipeline between steps) would make that rank's decision differ and the others hang in the exchange: refuse loudly.
+    // (The adaptive geometry changes Lv and D, never this switch; the replay's own fallback flips it inside this function and puts it back.)
+    if (pipeline_setup >= 0 && (c->pipeline ? 1 : 0) != pipeline_setup)
+        return hb_fail(HB_ERR_INVALID, "the context's pipeline switch changed during a sharded run (the ranks agreed on their replay decision with the setting at set-up)");
     const bool recover = recover_on && c->pipeline && !rowmode;
     // Whatever way this iteration ends, the context gets back the wait bound and the geometry it came with (a caller-owned context
     // outlives the run): a scope guard, not a line after the loop that the error returns inside it would skip.
