@@ -424,7 +424,7 @@ def pmc_traffic(n, cols, kernel):
 SIDE_WARMUP = 40
 
 PIPELINE = {  # (pipeline, look-ahead groups, panels per mat-vec launch): see DESIGN.md §2
-    "BayesCpi": (1, 3, 7), "BayesC": (1, 3, 7), "BayesB": (1, 3, 7), "BayesBpi": (1, 3, 7),
+    "BayesCpi": (1, 2, 7), "BayesC": (1, 2, 7), "BayesB": (1, 2, 7), "BayesBpi": (1, 2, 7),
     "BayesR": (1, 2, 2), "BayesRR": (1, 2, 2), "BayesA": (1, 2, 2), "BayesL": (1, 2, 2),   # (RR / A / L at panel 512: k_chain_dense, hb_run's own choice; BayesR: (2, 2) = the certified group chain, with the geometry chosen by regime — (2, 1) / k_chain_persist while many markers move)
 }
 

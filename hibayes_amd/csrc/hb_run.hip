@@ -324,6 +324,7 @@ int hb_run::setup(const hb_bayes_args *args)
     }
     sync_blocks = std::max(1, std::min(64, (int)a.sync_blocks));
     if (const char *e = getenv("HB_RECOVER")) recover_on = atoi(e) != 0;
+    const int wide_lv = (getenv("HB_WIDE_LV") && atoi(getenv("HB_WIDE_LV")) == 3) ? 3 : 2; // look-ahead groups of the point-mass models' wide geometry
     m_global = (!rowmode && (world > 1 || a.m_global > 0)) ? a.m_global : m;
     if (!rowmode && world > 1 && ((!a.allreduce && !a.comm) || m_global < m))
         return hb_fail(HB_ERR_INVALID, "hb_bayes_run: sharded run needs a communicator (comm or allreduce) and m_global");
@@ -489,8 +490,8 @@ int hb_run::setup(const hb_bayes_args *args)
         // all markers move the forward corrections dominate: one panel per launch, two groups of look-ahead (with one, the
         // chain idles for an update + launch boundary per panel)
         if (rowmode) rc = hb_ctx_set_pipeline(c, 0, 0, 1); // per-panel kernels: an exchange sits between each mat-vec and its chain
-        else if (model_index == 3 || model_index == 4) // three groups of look-ahead pay where the chain, not HBM, sets the pace: 2-bit genotypes
-            rc = hb_ctx_set_pipeline(c, 1, a.genotype_bits == 2 ? 3 : 2, 7); // ((2, 7) where k_fwd is not available: panels other than 512)
+        else if (model_index == 3 || model_index == 4) // (2, 7): seven panels per launch, two groups of look-ahead. (Round 5 ran three on the 2-bit layout — 2 % faster then; with
+            rc = hb_ctx_set_pipeline(c, 1, wide_lv, 7);   // round 6's chain it is 2.4 % SLOWER, 445-449 against 456-462 sweeps/s, and its band is 28 blocks instead of 21: HB_WIDE_LV=3 brings it back)
         else if (always_in && c->P == 512) // k_chain_dense: two panels per launch (45.6 against 39.4 sweeps/s at n=50k, m=500k; (1, 1) 24.8, (1, 2) 27.7)
             rc = hb_ctx_set_pipeline(c, 1, 2, 2);
         else if (model_index == 6 && n_fold <= 4 && c->P == 512 && !getenv("HB_NO_ADAPTIVE_R")) // BayesR: (2, 2) stored, (2, 1) while many markers move (geometry by regime, below)
@@ -591,14 +592,14 @@ int hb_run::setup(const hb_bayes_args *args)
         // (BayesR, measured late in round 6 with k_dotq2m beside both of its chains: 64.5 against 57.8 sweeps/s 300 sweeps after a cold start, 102.8 against 98.3
         // converged — a quarter of the genotype bytes streaming past the chain workgroup's own round trips; round 4's "the 2-bit kernel only lengthens the
         // launches" was the v_dot4 kernel)
-        // the band of the geometry — (3, 7): 28 blocks, BayesR's (2, 2): 6 — and the packed genotypes must fit beside the int8 columns the band is built from
+        // the band of the geometry — (2, 7): 21 blocks ((3, 7): 28), BayesR's (2, 2): 6 — and the packed genotypes must fit beside the int8 columns the band is built from
         size_t fr = 0, tot = 0;
-        const size_t band = (size_t)(sparse_bc ? 28 : 6) * c->m_pad * c->P * sizeof(int32_t), x2 = (size_t)((c->ld + 511) / 512 * 128) * c->m_pad;
+        const size_t band = (size_t)(sparse_bc ? 7 * (wide_lv + 1) : 6) * c->m_pad * c->P * sizeof(int32_t), x2 = (size_t)((c->ld + 511) / 512 * 128) * c->m_pad;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > band + x2 + ((size_t)2 << 30)) bits_run = 2;
         else (void)hipGetLastError();
     }
-    if (bits_run == 2 && own_ctx && a.genotype_bits == 0 && sparse_bc) {
-        rc = hb_ctx_set_pipeline(c, 1, 3, 7); // (set up as (2, 7) above; the third group of look-ahead pays on the 2-bit layout)
+    if (bits_run == 2 && own_ctx && a.genotype_bits == 0 && sparse_bc && wide_lv != 2) {
+        rc = hb_ctx_set_pipeline(c, 1, wide_lv, 7); // (HB_WIDE_LV=3: round 5's third group of look-ahead on the 2-bit layout)
         if (rc) return rc;
     }
     if (!c->gram_ready) {
