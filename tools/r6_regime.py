@@ -18,6 +18,8 @@ y = B.synth_phenotype(ctx, n, m, 0, m, 20240901, None, model)
 Pi, fold = B.prior(model)
 ctx.set_pipeline(1, max(g[0] for g in geos), max(g[1] for g in geos))
 ctx.build_gram()
+if os.environ.get("R6_BITS") == "2":
+    ctx.set_layout(2, keep_int8=False)  # (the headline's layout: k_dotq2m)
 for lv, d in geos:
     ctx.set_pipeline(1, lv, d)
     a = BayesArgs()
