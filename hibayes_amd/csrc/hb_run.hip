@@ -624,6 +624,13 @@ int hb_run::setup(const hb_bayes_args *args)
         adaptive_geo = (model_index == 3 || model_index == 4) && (own_ctx || c->adaptive) && gp == 1 && (gl == 2 || gl == 3) && gd == 7 && c->Lg >= 20;
         geo_wide_lv = gl;
         geo_cur = 0;
+        // round 6, re-measured at n = 50k, m = 500k from a cold start with this round's chains (profiles/r06_regime_bayescpi*.txt; round 3's 2.0 / 2.6 were taken when
+        // the wide geometry ran 166 sweeps/s): 2-bit genotypes — at 3.6 moves a panel (2, 2) 148 against (2, 7) 141 sweeps/s, at 2.6: 173 against 189, at 2.1: 187
+        // against 233; int8 columns — at 5.8: 97 against 80, at 3.6: 124 against 131, at 2.6: 131 against 168
+        if (model_index == 3 || model_index == 4) {
+            geo_to_wide = c->layout == 2 ? 3.0 : 3.8;
+            geo_to_narrow = c->layout == 2 ? 3.6 : 4.6;
+        }
         // round 6, BayesR with up to four classes at panel 512: two panels per launch and the certified group chain (k_chain_group<3, 2, 2, 15> + k_fwd + warmers)
         // once fewer than ~22 markers a panel move, one panel per launch and the per-panel chain with its row cache (k_chain_persist) above ~27
         // (measured at n = 50k, m = 500k from a cold start, profiles/r06_bayesr_regime.txt: they cross at 19 moves per panel — 47.5 sweeps/s both;
