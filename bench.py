@@ -683,7 +683,7 @@ def main():
     if geo == (1, 3, 7) and args.bits != 2:
         geo = (1, 2, 7)  # int8 columns: the sweep is as long as the HBM-bound mat-vec stream, the third group of look-ahead buys nothing (205 vs 200 sweeps/s)
     ctx.set_pipeline(*geo)
-    adaptive = (geo in ((1, 2, 7), (1, 3, 7)) or (args.model == "BayesR" and geo == (1, 2, 2))) and not os.environ.get("HB_NO_ADAPTIVE")
+    adaptive = (geo in ((1, 2, 7), (1, 3, 7), (1, 2, 8)) or (args.model == "BayesR" and geo == (1, 2, 2))) and not os.environ.get("HB_NO_ADAPTIVE")
     if adaptive:
         ctx.set_adaptive(True)  # narrow band while many markers move (burn-in), this geometry once few do (the timed region)
     gram_s = ctx.build_gram()

@@ -80,7 +80,7 @@ static void hb_pipeline_geometry(hb_ctx *c)
     // Lv counts mat-vec GROUPS of look-ahead; the Gram band then spans (Lv + 1) * D - 1 earlier panels
     // (20 = HB_LBMAX in hb_kernels.hip, what k_chain_persist folds; 27 with k_fwd beside the group chain — three groups of seven
     // panels of look-ahead — which the sweep refuses for the models that run k_chain_persist)
-    const int lbmax = (c->fwd_group && c->Lv == 3 && c->D == 7 && c->P == 512) ? 27 : 20;
+    const int lbmax = (c->fwd_group && c->P == 512 && ((c->Lv == 3 && c->D == 7) || (c->Lv == 2 && c->D == 8))) ? 27 : 20; // ((2, 8): 23, round 6)
     while ((c->Lv + 1) * c->D - 1 > lbmax) {
         if (c->Lv > 1) c->Lv--; else c->D--;
     }

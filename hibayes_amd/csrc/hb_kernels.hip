@@ -48,6 +48,9 @@
 #ifndef HB_WITH_MVP
 #define HB_WITH_MVP 0
 #endif
+#ifndef HB_W8_CH
+#define HB_W8_CH 3 /* moves per trip of the eight-panel group chain (4 spills nine registers, 3 four) */
+#endif
 #if HB_WITH_MVP
 #include "hb_mvp.hpp"
 #endif
@@ -189,6 +192,7 @@ int hbk_init_attrs()
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group_fwd<1, 8, 7, 4, true, 7, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_GROUP_ATTR16(1, 8, 7, 4);
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 8, 7, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 8, 8, HB_W8_CH, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #if HB_WITH_MVP
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 8, 7, 4, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chain_group<1, 2, 4, 10, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -721,7 +725,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     const bool alone = c->chain_alone || getenv("HB_CHAIN_ALONE") != nullptr;
     // the point-mass models run the group-granular chain (hb_chain_group.hpp); HB_CHAIN=panel keeps the per-panel one
     // (chain_kind bit 0: BayesB / BayesC; bit 1: the dense models too — BayesR and RR / A / L at one panel per group)
-    const int shape = (D <= 1 && Lv * D <= 2) ? 2 : (D <= 2 && Lv * D <= 4) ? 1 : (D <= 8 && Lv * D <= 14) ? 0 : (c->fwd_group && Lv == 3 && D == 7 && c->P == 512) ? 0 : -1;
+    const int shape = (D <= 1 && Lv * D <= 2) ? 2 : (D <= 2 && Lv * D <= 4) ? 1 : (D <= 8 && Lv * D <= 14) ? 0 : (c->fwd_group && c->P == 512 && ((Lv == 3 && D == 7) || (Lv == 2 && D == 8))) ? 0 : -1;
     const bool sparse_model = kp == 1 && (model == 3 || model == 4);
     // round 6: BayesR with up to four classes (kp == 3) runs the group chain too wherever a launch covers more than one panel (chain_kind bit 2
     // clear; HB_CHAIN=panel keeps k_chain_persist). K1 nested thresholds per candidate instead of one; everything else — candidates, certificate
@@ -733,7 +737,9 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
     // round 6: also beside BayesR's two-panel groups ((2, 2): the chain folds a move into the next group's two panels, k_fwd into the two after — half of the
     // chain's fold rows leave its compute unit, and a group's ~16 moves fit ONE trip of 62 loads per lane instead of two of 60)
     const bool fwd2 = group_chain && mix_model && Lv == 2 && D == 2 && c->P == 512 && c->fwd_group && !alone && cert && !getenv("HB_FWD2_OFF");
-    const bool fwd = (group_chain && (kp == 1 || mix_model) && (Lv == 2 || Lv == 3) && D == 7 && c->P == 512 && c->fwd_group && !alone) || fwd2;
+    // round 6: eight panels per launch (Lv = 2 only, point-mass models, certified): k_chain_group<1, 8, 8, CH, CERT> + k_fwd<8, 1, 8>
+    const bool wide8 = group_chain && kp == 1 && Lv == 2 && D == 8 && c->P == 512 && c->fwd_group && !alone && cert;
+    const bool fwd = (group_chain && (kp == 1 || mix_model) && (Lv == 2 || Lv == 3) && D == 7 && c->P == 512 && c->fwd_group && !alone) || fwd2 || wide8;
     const bool warm_r_env_off = !(getenv("HB_WARM_G") && atoi(getenv("HB_WARM_G")) > 0);
     // (only where chain and k_fwd run as ONE kernel — the wide certified shape of BayesB / BayesC: four branches in all, what a process has queues for)
     const bool overlap = c->overlap && fx && !dense && !alone && !c->lstamp && ngroups > Lv + 2 && Lv + 1 <= 8 && c->s_fk != nullptr &&
@@ -783,6 +789,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
             else if (mvp && fwd) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, false, true, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (mvp) hipLaunchKernelGGL((k_chain_group<1, 2, 4, 10, false, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
 #endif
+            else if (wide8) hipLaunchKernelGGL((k_chain_group<1, 8, 8, HB_W8_CH, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (fwd && g16) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (fwd && cert) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4, false, true>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
             else if (fwd) hipLaunchKernelGGL((k_chain_group<1, 8, 7, 4>), dim3(1), dim3(c->P), sm, st, c->d_in, cv, pv);
@@ -869,6 +876,7 @@ static int enqueue_sweep_pipeline(hb_ctx *c, int model, int n_fold, int pb, int 
         else if (mvp && Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8, false, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else if (mvp) hipLaunchKernelGGL((k_fwd<7, 2, 4, false, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
 #endif
+        else if (wide8) hipLaunchKernelGGL((k_fwd<8, 1, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else if (Lv == 2 && g16) hipLaunchKernelGGL((k_fwd<7, 1, 8, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else if (Lv == 2) hipLaunchKernelGGL((k_fwd<7, 1, 8>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);
         else if (g16) hipLaunchKernelGGL((k_fwd<7, 2, 4, true>), dim3(1), dim3(c->P), 0, c->s_upd, cv, pv);

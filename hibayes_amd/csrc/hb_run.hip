@@ -621,8 +621,9 @@ int hb_run::setup(const hb_bayes_args *args)
     {   // geometry by regime: only from the wide-band geometry of the point-mass models, whose stored band serves the narrow one
         int32_t gp = 0, gl = 0, gd = 0, gb = 0;
         (void)hb_ctx_get_pipeline(c, &gp, &gl, &gd, &gb);
-        adaptive_geo = (model_index == 3 || model_index == 4) && (own_ctx || c->adaptive) && gp == 1 && (gl == 2 || gl == 3) && gd == 7 && c->Lg >= 20;
+        adaptive_geo = (model_index == 3 || model_index == 4) && (own_ctx || c->adaptive) && gp == 1 && (((gl == 2 || gl == 3) && gd == 7) || (gl == 2 && gd == 8)) && c->Lg >= 20;
         geo_wide_lv = gl;
+        if (adaptive_geo) geo_wide_d = gd;
         geo_cur = 0;
         // round 6, re-measured at n = 50k, m = 500k from a cold start with this round's chains (profiles/r06_regime_bayescpi*.txt; round 3's 2.0 / 2.6 were taken when
         // the wide geometry ran 166 sweeps/s): 2-bit genotypes — at 3.6 moves a panel (2, 2) 148 against (2, 7) 141 sweeps/s, at 2.6: 173 against 189, at 2.1: 187

@@ -204,7 +204,7 @@ def _full_size_vs_oracle(n, m, model, Pi, fold, geo, m_offset, niter=2, precise=
 # (1, 2, 7) on 2-bit genotypes with the int8 copy dropped is THE shape bench.py's `value` is measured on since the end of round 6 (ld2 = 98 x 128 bytes, a
 # ragged last stage; rounds 4-5 and most of 6: (1, 3, 7), still selectable with HB_WIDE_LV=3 and still tested here); (1, 2, 7) on int8 columns: the
 # layout north_star names ((1, 3, 7) on int8 columns is covered at n = 32 768 in test_gpu_depth.py)
-@pytest.mark.parametrize("geo,bits", [((1, 2, 7), 2), ((1, 3, 7), 2), ((1, 2, 7), 8)])
+@pytest.mark.parametrize("geo,bits", [((1, 2, 7), 2), ((1, 3, 7), 2), ((1, 2, 7), 8), ((1, 2, 8), 2)])
 def test_config3_bayescpi_n50k_m500k_draw_for_draw_against_live_oracle(c3, geo, bits):
     _full_size_vs_oracle(50000, 500000, "BayesCpi", [0.95, 0.05], None, geo, 0, shared=c3, bits=bits)
 

@@ -35,6 +35,8 @@ def pheno(rng, X, ncausal=40):
 CASES = [  # model, Pi, fold, expected default geometry (pipeline, look-ahead groups, panels per mat-vec)
     ("BayesCpi", [0.95, 0.05], None, (1, 3, 7)),   # (three groups of look-ahead with k_fwd beside the chain: panel 512; else (1, 2, 7))
     ("BayesB", [0.8, 0.2], None, (1, 3, 7)),
+    ("BayesCpi", [0.95, 0.05], None, (1, 2, 8)),   # round 6: eight panels per launch (k_chain_group<1, 8, 8, 3, CERT> + k_fwd<8, 1, 8>)
+    ("BayesB", [0.8, 0.2], None, (1, 2, 8)),
     ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1)),   # k_chain_persist: the geometry a BayesR run holds while many markers move
     ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 2)),   # round 6: the certified group chain (k_chain_group<3, 2, 4, 10>), its geometry once few do
     ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 3, 7)),   # ... and BayesR on the wide group chain with k_fwd (k_chain_group<3, 8, 7, 4>)
@@ -86,6 +88,8 @@ def test_default_geometry_draw_for_draw_at_pipeline_depth(big, model, Pi, fold, 
         c.set_pipeline(*geo)
         if geo == (1, 3, 7) and c.panel != 512:
             geo = (1, 2, 7)
+        if geo == (1, 2, 8) and c.panel != 512:
+            geo = (1, 1, 8)    # (eight panels per launch with two groups of look-ahead need k_fwd: panel 512)
         assert c.pipeline()[:3] == geo
         if geo[2] == 7:
             assert (m + c.panel - 1) // c.panel >= 9 * 7 + 1      # >= 10 mat-vec groups
@@ -343,6 +347,7 @@ def test_dense_update_rows_are_the_old_update_rows_bit_for_bit(big, monkeypatch)
 
 LONG = [  # model, Pi, fold, geometry, resident bits, adaptive geometry, markers, sweeps, tolerance
     ("BayesCpi", [0.95, 0.05], None, (1, 3, 7), 2, True, 32768, 200, 1e-9),     # (measured on MI355X: 1.4e-15, 1.1e-14, 7e-15 of max |alpha|)
+    ("BayesCpi", [0.95, 0.05], None, (1, 2, 8), 2, True, 32768, 200, 1e-9),     # round 6: eight panels per launch, with the adaptive switch to (2, 2) and back
     ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 8, False, 32768, 200, 1e-9),
     # round 6: BayesR on the certified group chain (k_chain_group<3, 2, 4, 10>) for 200 sweeps (this small problem keeps ~40 moves a panel: its crowded
     # rounds and its certified ones; the sparse regime and the switch are test_bayesr_geometry_by_regime's)

@@ -20,6 +20,7 @@ CASES = [  # model, Pi, fold, geometry, panel, columns
     ("BayesRR", [0.95, 0.05], None, (1, 2, 2), 512, 8192),      # k_chain_dense + k_fold_dense + dense update rows
     ("BayesL", [0.95, 0.05], None, (1, 2, 2), 512, 8192),
     ("BayesCpi", [0.95, 0.05], None, (1, 3, 7), 512, 32768),    # k_chain_group + k_fwd
+    ("BayesCpi", [0.95, 0.05], None, (1, 2, 8), 512, 32768),    # round 6: eight panels per launch
     ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 1), 512, 16384),  # k_chain_persist
     ("BayesR", [0.95, 0.02, 0.02, 0.01], [0, 1e-4, 1e-3, 1e-2], (1, 2, 2), 512, 16384),  # round 6: BayesR on the certified group chain
 ]
