@@ -381,7 +381,10 @@ int hb_ctx_marker_stats(hb_ctx *c, double *xpx, double *vx, double *sumvx, int32
 /* Pipeline geometry of the sweep: pipeline 0 = one kernel per step and panel, 1 = persistent
  * chain workgroup overlapped with the mat-vec stream; `lookahead` mat-vec groups of `dotgroup` panels each run
  * ahead of the chain. Results do not depend on it: the same chain — identical decisions and move lists, effects to 1e-9 (two
- * geometries add the band corrections to a right-hand side in different orders). A band wider than the stored one rebuilds the Gram blocks. */
+ * geometries add the band corrections to a right-hand side in different orders). A band wider than the stored one rebuilds the Gram blocks.
+ * What hb_bayes_run picks for a context it creates (end of round 6): (1, 2, 7) for BayesB / BayesC, with (1, 2, 2) while many markers move; (1, 2, 2) /
+ * (1, 2, 1) for BayesR; (1, 2, 2) for BayesRR / A / L at panel 512. A geometry the band limit cannot hold is narrowed (hb_ctx_get_pipeline tells): at most 20
+ * panels of band, 27 with the forward workgroup beside the group chain — panel 512: (3, 7) and (2, 8). */
 int hb_ctx_set_pipeline(hb_ctx *c, int32_t pipeline, int32_t lookahead, int32_t dotgroup);
 /* per-panel Gram blocks G = X_p' X_p (int32, exact) plus the look-ahead band; also reports seconds spent */
 int hb_ctx_build_gram(hb_ctx *c, double *seconds);
