@@ -628,9 +628,12 @@ int hb_run::setup(const hb_bayes_args *args)
         // round 6, re-measured at n = 50k, m = 500k from a cold start with this round's chains (profiles/r06_regime_bayescpi*.txt; round 3's 2.0 / 2.6 were taken when
         // the wide geometry ran 166 sweeps/s): 2-bit genotypes — at 3.6 moves a panel (2, 2) 148 against (2, 7) 141 sweeps/s, at 2.6: 173 against 189, at 2.1: 187
         // against 233; int8 columns — at 5.8: 97 against 80, at 3.6: 124 against 131, at 2.6: 131 against 168
+        // One pair of thresholds for both layouts (the geometries cross at 3.2 moves a panel on 2-bit genotypes, at 4.2 on int8 columns): a run on 2-bit genotypes
+        // is the int8 run BIT FOR BIT only if both take the same geometry in every sweep (tests/test_gpu_depth.py test_two_bit_resident_layout_is_the_same_chain;
+        // per-layout thresholds broke exactly that), and between 3.2 and 4.2 the int8 run loses 5 % for a handful of sweeps.
         if (model_index == 3 || model_index == 4) {
-            geo_to_wide = c->layout == 2 ? 3.0 : 3.8;
-            geo_to_narrow = c->layout == 2 ? 3.6 : 4.6;
+            geo_to_wide = 3.2;
+            geo_to_narrow = 4.0;
         }
         // round 6, BayesR with up to four classes at panel 512: two panels per launch and the certified group chain (k_chain_group<3, 2, 2, 15> + k_fwd + warmers)
         // once fewer than ~22 markers a panel move, one panel per launch and the per-panel chain with its row cache (k_chain_persist) above ~27
